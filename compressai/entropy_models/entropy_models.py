@@ -1,0 +1,200 @@
+"""Entropy models of the MASIC codec, HIP-backed (reference
+compressai/entropy_models/entropy_models.py:56-866).
+
+On the hot path: `EntropyBottleneck.forward/loss`, `_quantize`, and
+`GaussianMixtureConditional(_gf).forward`.  Bitstream methods (`update`, `compress`, `decompress`)
+belong to the rANS row of SURVEY.md section 8(f) and raise until that row is built.
+Parameter / buffer names are the reference's, so state dicts interchange (248 tensors for HSIC).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from compressai.ops import LowerBound
+from masic_amd import ops as _hip
+
+_NEXT = "bitstream coding (rANS tables / compress / decompress) is the 'next' row 8(f)-2 of SURVEY.md; not built yet"
+
+
+class EntropyModel(nn.Module):
+    def __init__(self, likelihood_bound=1e-9, entropy_coder=None, entropy_coder_precision=16):
+        super().__init__()
+        from compressai import available_entropy_coders, get_entropy_coder
+        coder = get_entropy_coder() if entropy_coder is None else entropy_coder
+        if coder not in available_entropy_coders():
+            raise ValueError(f'Unknown entropy coder "{coder}" (available: {", ".join(available_entropy_coders())})')
+        self.entropy_coder_name = coder
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.likelihood_bound = float(likelihood_bound)
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        # filled by update()
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+
+    def forward(self, *args):
+        raise NotImplementedError()
+
+    def _get_noise_cached(self, x):
+        """One cached buffer per module, redrawn from the device's global generator on every call
+        (reference :89-96) -- keeps the training-mode draw order of SURVEY.md appendix D."""
+        if not hasattr(self, "_noise"):
+            setattr(self, "_noise", x.new(x.size()))
+        self._noise.resize_(x.size())
+        self._noise.uniform_(-0.5, 0.5)
+        return self._noise
+
+    def _quantize(self, inputs, mode, means=None):
+        if mode not in ("noise", "dequantize", "symbols"):
+            raise ValueError(f'Invalid quantization mode: "{mode}"')
+        if mode == "noise":
+            return _hip.quantize(inputs.contiguous(), "noise", noise=self._get_noise_cached(inputs))
+        if mode == "symbols":
+            med = None if means is None else means.reshape(-1).contiguous()
+            if med is not None and med.numel() != inputs.shape[1]:
+                raise NotImplementedError("per-element means in 'symbols' mode are outside the MASIC path")
+            return _hip.symbols(inputs.contiguous(), med)
+        if means is not None:
+            raise NotImplementedError("'dequantize' with means is only reached through EntropyBottleneck.forward (fused)")
+        return _hip.quantize(inputs.contiguous(), "dequantize")
+
+    @staticmethod
+    def _dequantize(inputs, means=None):
+        if means is not None:
+            return inputs.type_as(means) + means
+        return inputs.float()
+
+    def compress(self, *args, **kwargs):
+        raise NotImplementedError(_NEXT)
+
+    def decompress(self, *args, **kwargs):
+        raise NotImplementedError(_NEXT)
+
+
+class EntropyBottleneck(EntropyModel):
+    """Factorized prior of Balle et al. 2018 with per-channel 1-3-3-3-3-1 cumulative nets."""
+
+    def __init__(self, channels, *args, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), **kwargs):
+        super().__init__(*args, **kwargs)
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+
+        self._biases = nn.ParameterList()
+        self._factors = nn.ParameterList()
+        self._matrices = nn.ParameterList()
+        dims = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            fill = float(np.log(np.expm1(1 / scale / dims[i + 1])))
+            self._matrices.append(nn.Parameter(torch.full((self.channels, dims[i + 1], dims[i]), fill)))
+            self._biases.append(nn.Parameter(torch.empty(self.channels, dims[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self._factors.append(nn.Parameter(torch.zeros(self.channels, dims[i + 1], 1)))
+        q = torch.Tensor([-self.init_scale, 0, self.init_scale])
+        self.quantiles = nn.Parameter(q.repeat(self.channels, 1, 1))
+        t = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.Tensor([-t, 0, t]))
+
+    def _medians(self):
+        return self.quantiles[:, :, 1:2]
+
+    def _table(self):
+        return _hip.eb_param_table([m.detach() for m in self._matrices], [b.detach() for b in self._biases],
+                                   [f.detach() for f in self._factors])
+
+    def loss(self):
+        """sum |logits(quantiles) - target| with all density parameters detached (reference :345-348)."""
+        return _hip.entropy_bottleneck_auxloss(self._table(), self.quantiles.detach().contiguous(), self.tail_mass)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        noise = None
+        if self.training:
+            # drawn in the reference's (C, 1, H*W*B) layout (reference :386-394)
+            noise = self._get_noise_cached(x.new_empty((C, 1, H * W * B)))
+        medians = self.quantiles.detach()[:, 0, 1].contiguous()
+        return _hip.entropy_bottleneck(x.contiguous(), self._table(), medians, training=self.training, noise=noise,
+                                       lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
+
+    @staticmethod
+    def _build_indexes(size):
+        N, C, H, W = size
+        return torch.arange(C).view(1, -1, 1, 1).int().repeat(N, 1, H, W)
+
+    def update(self, force=False):
+        raise NotImplementedError(_NEXT)
+
+
+class _GaussianBase(EntropyModel):
+    def __init__(self, scale_table, *args, scale_bound=0.11, tail_mass=1e-9, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not isinstance(scale_table, (type(None), list, tuple)):
+            raise ValueError(f'Invalid type for scale_table "{type(scale_table)}"')
+        if isinstance(scale_table, (list, tuple)) and len(scale_table) < 1:
+            raise ValueError(f'Invalid scale_table length "{len(scale_table)}"')
+        if scale_table and (scale_table != sorted(scale_table) or any(s <= 0 for s in scale_table)):
+            raise ValueError(f'Invalid scale_table "({scale_table})"')
+        self.register_buffer("scale_table", self._prepare_scale_table(scale_table) if scale_table else torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
+        self.tail_mass = float(tail_mass)
+        if scale_bound is None and scale_table:
+            self._scale_bound_value = float(self.scale_table[0])
+        elif scale_bound is not None and scale_bound > 0:
+            self._scale_bound_value = float(scale_bound)
+        else:
+            raise ValueError("Invalid parameters")
+        self.lower_bound_scale = LowerBound(self._scale_bound_value)
+
+    @staticmethod
+    def _prepare_scale_table(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    def _standardized_cumulative(self, inputs):
+        return 0.5 * torch.erfc(float(-(2 ** -0.5)) * inputs)
+
+    def update_scale_table(self, scale_table, force=False):
+        raise NotImplementedError(_NEXT)
+
+    def update(self):
+        raise NotImplementedError(_NEXT)
+
+
+class GaussianConditional(_GaussianBase):
+    """Single-Gaussian conditional (reference :433-562). Import surface only: MASIC uses the mixture."""
+
+    def __init__(self, scale_table, *args, **kwargs):
+        super().__init__(scale_table, *args, **kwargs)
+
+    def forward(self, inputs, scales, means=None):
+        raise NotImplementedError("GaussianConditional is not on the MASIC path; use GaussianMixtureConditional_gf")
+
+
+class GaussianMixtureConditional(_GaussianBase):
+    """K-component Gaussian mixture conditional (reference :566-710); quantisation ignores the means
+    (:695-697).  scales/means/weights carry K*M channels, component k of channel m at k*M + m."""
+
+    def __init__(self, K, scale_table=None, mean_table=None, weight_table=None, *args, **kwargs):
+        super().__init__(scale_table, *args, **kwargs)
+        self.K = K
+
+    def _likelihood(self, inputs, scales, means=None, weights=None):
+        _, lik = _hip.gmm_likelihood(inputs.contiguous(), scales.contiguous(), means.contiguous(), weights.contiguous(),
+                                     self.K, training=True, noise=torch.zeros_like(inputs),
+                                     scale_bound=self._scale_bound_value, lik_bound=0.0)
+        return lik
+
+    def forward(self, inputs, scales, means=None, weights=None, weights_are_logits=False):
+        noise = self._get_noise_cached(inputs) if self.training else None
+        return _hip.gmm_likelihood(inputs.contiguous(), scales.contiguous(), means.contiguous(), weights.contiguous(),
+                                   self.K, training=self.training, noise=noise, weights_are_logits=weights_are_logits,
+                                   scale_bound=self._scale_bound_value,
+                                   lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
+
+
+class GaussianMixtureConditional_gf(GaussianMixtureConditional):
+    """Pixel-wise ("gmm full") variant used by HSIC (reference :713-866; MASIC.py:658-659): same
+    arithmetic, every latent position has its own K weights."""

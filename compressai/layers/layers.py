@@ -1,0 +1,61 @@
+"""Conv building blocks used by MASIC (reference compressai/layers/layers.py:52-95,160-190).
+Blocks that only the upstream cheng2020/ssf models use (AttentionBlock, ResidualBlockWithStride,
+ResidualBlockUpsample, subpel_conv3x3, QReLU) are outside the hot path and not provided."""
+import torch
+import torch.nn as nn
+
+from masic_amd import ops as _hip
+from masic_amd.nn import Conv2d
+
+__all__ = ["MaskedConv2d", "ResidualBlock", "conv3x3", "conv1x1"]
+
+
+class MaskedConv2d(Conv2d):
+    """PixelCNN-style masked convolution (type 'A' hides the current and all later positions).
+
+    As in the reference (layers.py:77) the stored weight is multiplied by the mask in place on every
+    forward, so masked taps read exactly 0 in state dicts; the kernel then contracts only the live
+    taps (12 of 25 for the 5x5 context model)."""
+
+    def __init__(self, *args, mask_type="A", **kwargs):
+        super().__init__(*args, **kwargs)
+        if mask_type not in ("A", "B"):
+            raise ValueError(f'Invalid "mask_type" value "{mask_type}"')
+        if mask_type != "A":
+            raise NotImplementedError("only mask type 'A' is on the MASIC path")
+        self.masked_conv = True
+        mask = torch.ones_like(self.weight.data)
+        _, _, kh, kw = mask.shape
+        mask[:, :, kh // 2, kw // 2:] = 0
+        mask[:, :, kh // 2 + 1:] = 0
+        self.register_buffer("mask", mask)
+
+    def zero_masked_taps(self):
+        _hip.mul_inplace(self.weight.data, self.mask)
+
+    def run(self, x, **kw):
+        self.zero_masked_taps()
+        return super().run(x, **kw)
+
+
+def conv3x3(in_ch, out_ch, stride=1):
+    return Conv2d(in_ch, out_ch, kernel_size=3, stride=stride, padding=1)
+
+
+def conv1x1(in_ch, out_ch, stride=1):
+    return Conv2d(in_ch, out_ch, kernel_size=1, stride=stride)
+
+
+class ResidualBlock(nn.Module):
+    """conv3x3 -> LeakyReLU -> conv3x3 -> LeakyReLU, plus identity (1x1-projected if widths differ).
+    Used by the CQE network (MASIC.py:149-164)."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
+
+    def forward(self, x):
+        raise NotImplementedError("ResidualBlock (CQE network) is scheduled after the HSIC path; see DESIGN.md")

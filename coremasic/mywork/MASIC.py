@@ -1,0 +1,494 @@
+"""MASIC stereo codec, MI355X-native (module signature of the reference's coremasic/mywork/MASIC.py).
+
+`from MASIC import *` gives the unchanged drivers the same names (HSIC, Independent_EN, GMM_together,
+mask, RateDistortionLoss, AverageMeter, ...) and `HSIC(N,M,K)` has the reference's 17 child modules and
+248 state-dict tensors, but `forward` is a schedule of fused HIP launches (masic_amd/csrc/*.hip), not
+a graph of ATen ops:
+
+  * convs write straight into the channel slices that the reference builds with torch.cat
+    (MASIC.py:765, 827) and fold in bias, ReLU/LeakyReLU, |y| and round();
+  * the three mask2weights gates multiply inside the producing kernels' epilogues;
+  * the softmax over the K mixture weights runs inside the GMM likelihood kernel;
+  * `x1_hat` is warped once (the reference warps it twice with identical arguments, :821 and :833);
+  * the masked context convs contract only their 12 live taps.
+
+There is no CPU path: tensors must live on an MI355X (`cuda`) device.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401  (re-exported through `from MASIC import *`)
+
+from compressai.entropy_models import (EntropyBottleneck, GaussianConditional, GaussianMixtureConditional,  # noqa: F401
+                                       GaussianMixtureConditional_gf)
+from compressai.layers import GDN, MaskedConv2d, ResidualBlock, conv3x3  # noqa: F401
+from compressai.models.utils import conv, deconv, update_registered_buffers  # noqa: F401
+from masic_amd import ops as _hip
+
+_RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
+
+
+class CompressionModel(nn.Module):
+    """Two-bottleneck base class (reference MASIC.py:40-109). `parameters()` hides the entropy
+    bottlenecks, `aux_parameters()` yields all of their parameters."""
+
+    def __init__(self, entropy_bottleneck_channels, init_weights=True):
+        super().__init__()
+        self.entropy_bottleneck1 = EntropyBottleneck(entropy_bottleneck_channels)
+        self.entropy_bottleneck2 = EntropyBottleneck(entropy_bottleneck_channels)
+        if init_weights:
+            self._initialize_weights()
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, *args):
+        raise NotImplementedError()
+
+    def parameters(self):
+        for child in self.children():
+            if not isinstance(child, EntropyBottleneck):
+                yield from child.parameters()
+
+    def aux_parameters(self):
+        for child in self.children():
+            if isinstance(child, EntropyBottleneck):
+                yield from child.parameters()
+
+    def update(self, force=False):
+        for child in self.children():
+            if isinstance(child, EntropyBottleneck):
+                child.update(force=force)
+
+
+class RateDistortionLoss(nn.Module):
+    """Single-view RD loss kept for `from MASIC import *` (reference MASIC.py:113-132); the stereo
+    loss the trainers use lives in masic_amd/loss.py."""
+
+    def __init__(self, lmbda=1e-2):
+        super().__init__()
+        self.lmbda = lmbda
+
+    def forward(self, output, target):
+        N, _, H, W = target.size()
+        n = N * H * W
+        bpp = sum(_hip.sum_log(l.contiguous()) for l in output["likelihoods"].values()) / (-math.log(2) * n)
+        mse = _hip.sse(output["x_hat"].contiguous(), target.contiguous()) / target.numel()
+        return {"bpp_loss": bpp.float(), "mse_loss": mse.float(), "loss": (self.lmbda * 255 ** 2 * mse + bpp).float()}
+
+
+class AverageMeter:
+    def __init__(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+# ------------------------------------------------------------------------------------------ sub-networks
+class encode_hyper(nn.Module):
+    """|y| -> conv5x5 s1 -> ReLU -> conv5x5 s2 -> ReLU -> conv5x5 s2 (reference :170-187)."""
+
+    def __init__(self, N, M):
+        super().__init__()
+        self.encode_hyper = nn.Sequential(
+            conv(M, N, kernel_size=5, stride=1), nn.ReLU(inplace=True),
+            conv(N, N, kernel_size=5), nn.ReLU(inplace=True),
+            conv(N, N, kernel_size=5))
+
+    def forward(self, y):
+        s = self.encode_hyper
+        t = s[0].run(y, in_op=_hip.INOP_ABS, act=_RELU)
+        t = s[2].run(t, act=_RELU)
+        return s[4].run(t)
+
+
+class _GmmHeads(nn.Module):
+    """Three 3-layer 1x1 stacks -> sigma (ReLU), means, mixture-weight logits (reference :330-468)."""
+
+    def _branch(self, seq, x, acts):
+        t = seq[0].run(x, act=acts[0])
+        t = seq[2].run(t, act=acts[1])
+        return seq[4].run(t, act=acts[2])
+
+    def heads(self, x):
+        sigma = self._branch(self.gmm_sigma, x, (_RELU, _RELU, _RELU))
+        means = self._branch(self.gmm_means, x, (_LEAKY, _LEAKY, _NONE))
+        logits = self._branch(self.gmm_weights, x, (_LEAKY, _LEAKY, _NONE))
+        return sigma, means, logits
+
+    def forward(self, x):
+        sigma, means, logits = self.heads(x)
+        return sigma, means, _hip.softmax_k(logits, self.K)
+
+
+class gmm_hyper_y1_same_resolution(_GmmHeads):
+    """Left-view heads: the first two layers of each branch are ConvTranspose2d(k=1) (reference :338-376)."""
+
+    def __init__(self, N, M, K):
+        super().__init__()
+        self.N, self.M, self.K = N, M, K
+        self.gmm_sigma = nn.Sequential(
+            deconv(4 * M, 6 * M, kernel_size=1, stride=1), nn.ReLU(inplace=True),
+            deconv(6 * M, 4 * M, kernel_size=1, stride=1), nn.ReLU(inplace=True),
+            conv(4 * M, M * K, kernel_size=1, stride=1), nn.ReLU(inplace=True))
+        self.gmm_means = nn.Sequential(
+            deconv(4 * M, 6 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            deconv(6 * M, 4 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(4 * M, M * K, kernel_size=1, stride=1))
+        self.gmm_weights = nn.Sequential(
+            deconv(4 * M, 6 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            deconv(6 * M, M * K, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(M * K, M * K, kernel_size=1, stride=1))
+
+
+class gmm_hyper_y2_same_resolution(_GmmHeads):
+    """Right-view heads on the 5M-channel gated concat (reference :399-468)."""
+
+    def __init__(self, N, M, K):
+        super().__init__()
+        self.N, self.M, self.K = N, M, K
+        self.gmm_sigma = nn.Sequential(
+            conv(5 * M, 6 * M, kernel_size=1, stride=1), nn.ReLU(inplace=True),
+            conv(6 * M, 4 * M, kernel_size=1, stride=1), nn.ReLU(inplace=True),
+            conv(4 * M, M * K, kernel_size=1, stride=1), nn.ReLU(inplace=True))
+        self.gmm_means = nn.Sequential(
+            conv(5 * M, 6 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(6 * M, 4 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(4 * M, M * K, kernel_size=1, stride=1))
+        self.gmm_weights = nn.Sequential(
+            conv(5 * M, 6 * M, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(6 * M, M * K, kernel_size=1, stride=1), nn.LeakyReLU(inplace=True),
+            conv(M * K, M * K, kernel_size=1, stride=1))
+
+
+class mask2weights(nn.Module):
+    """Right-view mask -> Kw softmax-normalised gate maps at latent resolution (reference :472-506)."""
+
+    def __init__(self, N, M, Kw):
+        super().__init__()
+        self.maskconv = nn.Sequential(
+            conv(1, 3, kernel_size=3, stride=2), nn.ReLU(inplace=True),
+            conv(3, 6, kernel_size=3), nn.ReLU(inplace=True),
+            conv(6, 6, kernel_size=3), nn.ReLU(inplace=True),
+            conv(6, 3, kernel_size=3))
+        self.N, self.M, self.Kw = N, M, Kw
+
+    def forward(self, m):
+        s = self.maskconv
+        t = s[0].run(m, act=_RELU)
+        t = s[2].run(t, act=_RELU)
+        t = s[4].run(t, act=_RELU)
+        return s[6].run(t, act=_hip.ACT_SOFTMAX_C)
+
+
+class Encoder1(nn.Module):
+    """Left analysis transform (reference :510-531)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__()
+        self.g_a_conv1 = conv(3, N)
+        self.g_a_gdn1 = GDN(N)
+        self.g_a_conv2 = conv(N, N)
+        self.g_a_gdn2 = GDN(N)
+        self.g_a_conv3 = conv(N, N)
+        self.g_a_gdn3 = GDN(N)
+        self.g_a_conv4 = conv(N, M)
+
+    def forward(self, x):
+        g1 = self.g_a_gdn1(self.g_a_conv1(x))
+        g2 = self.g_a_gdn2(self.g_a_conv2(g1))
+        g3 = self.g_a_gdn3(self.g_a_conv3(g2))
+        return self.g_a_conv4(g3), g1, g2, g3
+
+
+class Decoder1(nn.Module):
+    """Left synthesis transform (reference :533-554)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__()
+        self.g_s_conv1 = deconv(M, N)
+        self.g_s_gdn1 = GDN(N, inverse=True)
+        self.g_s_conv2 = deconv(N, N)
+        self.g_s_gdn2 = GDN(N, inverse=True)
+        self.g_s_conv3 = deconv(N, N)
+        self.g_s_gdn3 = GDN(N, inverse=True)
+        self.g_s_conv4 = deconv(N, 3)
+
+    def forward(self, y_hat):
+        g1 = self.g_s_gdn1(self.g_s_conv1(y_hat))
+        g2 = self.g_s_gdn2(self.g_s_conv2(g1))
+        g3 = self.g_s_gdn3(self.g_s_conv3(g2))
+        return self.g_s_conv4(g3), g1, g2, g3
+
+
+class Encoder2(nn.Module):
+    """Right analysis transform conditioned on the warped left view (reference :556-585)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__()
+        self.pre_conv = conv(6, 3, stride=1)
+        self.pre_gdn = GDN(3)
+        self.g_a_conv1 = conv(3, N)
+        self.g_a_gdn1 = GDN(N)
+        self.g_a_conv2 = conv(N, N)
+        self.g_a_gdn2 = GDN(N)
+        self.g_a_conv3 = conv(N, N)
+        self.g_a_gdn3 = GDN(N)
+        self.g_a_conv4 = conv(N, M)
+
+    def forward(self, x1_warp, x2):
+        B, _, H, W = x2.shape
+        pair = torch.empty((B, 6, H, W), dtype=x2.dtype, device=x2.device)
+        _hip.copy_view(x1_warp, pair, 0)
+        _hip.copy_view(x2, pair, 3)
+        return self.forward_pair(pair)
+
+    def forward_pair(self, pair):
+        t = self.pre_gdn(self.pre_conv(pair))
+        t = self.g_a_gdn1(self.g_a_conv1(t))
+        t = self.g_a_gdn2(self.g_a_conv2(t))
+        t = self.g_a_gdn3(self.g_a_conv3(t))
+        return self.g_a_conv4(t)
+
+
+class Decoder2(nn.Module):
+    """Right synthesis transform; its tail fuses the warped left reconstruction (reference :587-622)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__()
+        self.g_s_conv1 = deconv(M, N)
+        self.g_s_gdn1 = GDN(N, inverse=True)
+        self.g_s_conv2 = deconv(N, N)
+        self.g_s_gdn2 = GDN(N, inverse=True)
+        self.g_s_conv3 = deconv(N, N)
+        self.g_s_gdn3 = GDN(N, inverse=True)
+        self.g_s_conv4 = deconv(N, 3)
+        self.after_gdn = GDN(3, inverse=True)
+        self.after_conv = deconv(6, 3, stride=1)
+
+    def forward(self, y_hat, x1_hat_warp):
+        t = self.g_s_gdn1(self.g_s_conv1(y_hat))
+        t = self.g_s_gdn2(self.g_s_conv2(t))
+        t = self.g_s_gdn3(self.g_s_conv3(t))
+        t = self.after_gdn(self.g_s_conv4(t))
+        B, _, H, W = t.shape
+        pair = torch.empty((B, 6, H, W), dtype=t.dtype, device=t.device)
+        _hip.copy_view(t, pair, 0)
+        _hip.copy_view(x1_hat_warp, pair, 3)
+        return self.after_conv(pair)
+
+
+def mask(im1, H_inv):
+    """Validity masks of the left->right->left warp (reference :627-649). As there, the masks are NOT
+    binarised (the reference discards its torch.where results) and keep bilinear border values."""
+    B, _, h, w = im1.shape
+    m_fwd = _hip.warp_matrix(H_inv.contiguous(), (h, w), (h, w))
+    m_back = _hip.warp_matrix(H_inv.contiguous(), (h, w), (h, w), invert_first=True)
+    mask_r = _hip.warp_perspective(None, m_fwd, (h, w), ones_like=(B, h, w))
+    mask_l = _hip.warp_perspective(mask_r, m_back, (h, w))
+    return mask_r, mask_l
+
+
+class HSIC(CompressionModel):
+    """Homography-aware stereo image codec (reference :652-851)."""
+
+    def __init__(self, N=128, M=192, K=5, **kwargs):
+        super().__init__(entropy_bottleneck_channels=N, **kwargs)
+        self.gaussian1 = GaussianMixtureConditional_gf(K=K)
+        self.gaussian2 = GaussianMixtureConditional_gf(K=K)
+        self.N, self.M, self.K = int(N), int(M), int(K)
+        self.encoder1 = Encoder1(N, M)
+        self.encoder2 = Encoder2(N, M)
+        self.decoder1 = Decoder1(N, M)
+        self.decoder2 = Decoder2(N, M)
+        self._h_a1 = encode_hyper(N=N, M=M)
+        self._h_a2 = encode_hyper(N=N, M=M)
+
+        def up():
+            return nn.Sequential(
+                deconv(N, M, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                deconv(M, M * 3 // 2, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+
+        self.h_s1_up = up()
+        self.h_s2_up = up()
+        self.context_prediction1 = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.context_prediction2 = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self._h_s1_same_resolution = gmm_hyper_y1_same_resolution(N=N, M=M, K=K)
+        self._h_s2_same_resolution = gmm_hyper_y2_same_resolution(N=N, M=M, K=K)
+        self.mask2weights_unit = mask2weights(N=N, M=M, Kw=3)
+        # NB: as in the reference, _initialize_weights() ran inside super().__init__() before any of
+        # these children existed, so the convs keep torch's default initialisation.
+
+    # `_quantize` / `_standardized_cumulative` duplicates of the reference (:710-742) for callers that
+    # reach into the model
+    def _quantize(self, inputs, mode, means=None):
+        return self.gaussian1._quantize(inputs, mode, means)
+
+    def _standardized_cumulative(self, inputs):
+        return self.gaussian1._standardized_cumulative(inputs)
+
+    def _hyper_up(self, seq, z_hat, out, out_coff, gate=None, gate_c=0):
+        t = seq[0].run(z_hat, act=_LEAKY)
+        t = seq[2].run(t, act=_LEAKY)
+        return seq[4].run(t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+
+    def forward(self, x1, x2, h_matrix):
+        M, K = self.M, self.K
+        x1 = x1.contiguous()
+        x2 = x2.contiguous()
+        B, _, H, W = x1.shape
+        train = self.training
+        mode = "noise" if train else "dequantize"
+
+        # ---- left view
+        y1 = self.encoder1(x1)[0]
+        z1 = self._h_a1(y1)
+        z1_hat, z1_lik = self.entropy_bottleneck1(z1)
+        h, w = y1.shape[-2:]
+        cat1 = torch.empty((B, 4 * M, h, w), dtype=x1.dtype, device=x1.device)      # params1 | ctx_params1
+        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0)
+        if train:
+            y1_ctx = self.gaussian1._quantize(y1, "noise")
+            self.context_prediction1.run(y1_ctx, out=cat1, out_coff=2 * M)
+        else:
+            self.context_prediction1.run(y1, in_op=_hip.INOP_ROUND, out=cat1, out_coff=2 * M)
+        s1, m1, l1 = self._h_s1_same_resolution.heads(cat1)
+        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
+        x1_hat = self.decoder1(y1_hat)[0]
+
+        # ---- right view
+        m_fwd = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W))
+        pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
+        _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
+        _hip.copy_view(x2, pair, 3)
+        y2 = self.encoder2.forward_pair(pair)
+        z2 = self._h_a2(y2)
+        z2_hat, z2_lik = self.entropy_bottleneck2(z2)
+
+        m_back = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W), invert_first=True)
+        x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
+        gates = self.mask2weights_unit(x1_mask_R)                                    # [B,3,h,w]
+
+        cat2 = torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)      # params2*g0 | ctx2*g1 | y1_warp_hat*g2
+        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
+        if train:
+            y2_ctx = self.gaussian2._quantize(y2, "noise")
+            self.context_prediction2.run(y2_ctx, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
+        else:
+            self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
+
+        x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
+        y1_warp = self.encoder1(x1_hat_warp)[0]
+        noise = self.gaussian1._get_noise_cached(y1_warp) if train else None
+        _hip.quantize(y1_warp, mode, noise=noise, out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+
+        s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
+        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+
+        return {
+            "x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "z1_hat": z1_hat,
+            "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L,
+            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
+        }
+
+    def latents(self, x1, x2, h_matrix):
+        """Unquantised latents (y1, y2, z1, z2) -- the inputs of the int32 symbol streams that feed the
+        range coder (reference compress(): MASIC.py:855-868)."""
+        x1 = x1.contiguous()
+        B, _, H, W = x1.shape
+        y1 = self.encoder1(x1)[0]
+        z1 = self._h_a1(y1)
+        m_fwd = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W))
+        x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
+        y2 = self.encoder2(x1_warp, x2.contiguous())
+        z2 = self._h_a2(y2)
+        return y1, y2, z1, z2
+
+    def symbol_streams(self, x1, x2, h_matrix):
+        """int32 symbols round(y1), round(y2), round(z1 - med1), round(z2 - med2)."""
+        y1, y2, z1, z2 = self.latents(x1, x2, h_matrix)
+        med1 = self.entropy_bottleneck1.quantiles.detach()[:, 0, 1].contiguous()
+        med2 = self.entropy_bottleneck2.quantiles.detach()[:, 0, 1].contiguous()
+        return {"y1": _hip.symbols(y1), "y2": _hip.symbols(y2), "z1": _hip.symbols(z1, med1), "z2": _hip.symbols(z2, med2)}
+
+    def compress(self, x1, x2, h_matrix, output_name, output_path="", device="cpu"):
+        raise NotImplementedError("HSIC.compress (range-coder bitstream, reference :855-1158) is row 8(f)-1 of SURVEY.md: next")
+
+    def decompress(self, *args, **kwargs):
+        raise NotImplementedError("HSIC.decompress (reference :1161-1408) is row 8(f)-1 of SURVEY.md: next")
+
+
+# ------------------------------------------------------------------------------------------ CQE network
+class Enhancement_Block(nn.Module):
+    def __init__(self, shape):
+        super().__init__()
+        self.RB1 = ResidualBlock(shape, shape)
+        self.RB2 = ResidualBlock(shape, shape)
+        self.RB3 = ResidualBlock(shape, shape)
+
+    def forward(self, x):
+        raise NotImplementedError("Independent_EN is scheduled after the HSIC path; see DESIGN.md")
+
+
+class mask2weights_EN(nn.Module):
+    def __init__(self, Kw=2):
+        super().__init__()
+        self.maskconv = nn.Sequential(
+            conv(1, Kw, kernel_size=3, stride=1), nn.ReLU(inplace=True),
+            conv(Kw, Kw * 2, kernel_size=3, stride=1), nn.ReLU(inplace=True),
+            conv(Kw * 2, Kw * 2, kernel_size=3, stride=1), nn.ReLU(inplace=True),
+            conv(Kw * 2, Kw, kernel_size=3, stride=1))
+
+    def forward(self, m):
+        s = self.maskconv
+        t = s[0].run(m, act=_RELU)
+        t = s[2].run(t, act=_RELU)
+        t = s[4].run(t, act=_RELU)
+        return s[6].run(t, act=_hip.ACT_SOFTMAX_C)
+
+
+class Independent_EN(nn.Module):
+    """Cross quality-enhancement network (reference :1436-1501): module tree / state dict only for now."""
+
+    def __init__(self):
+        super().__init__()
+        self.EBl1 = Enhancement_Block(shape=32)
+        self.EBl2 = Enhancement_Block(shape=64)
+        self.EBl3 = Enhancement_Block(shape=96)
+        self.EBr1 = Enhancement_Block(shape=32)
+        self.EBr2 = Enhancement_Block(shape=64)
+        self.EBr3 = Enhancement_Block(shape=96)
+        self.conv0 = conv3x3(3, 32)
+        self.conv1 = conv3x3(6, 32)
+        self.conv2 = conv3x3(96, 3)
+        self.mask2weights_unit = mask2weights_EN()
+
+    def forward(self, x1_hat, x2_hat, h_matrix):
+        raise NotImplementedError("Independent_EN.forward: SURVEY.md section 8(a) row 15, scheduled after the HSIC path")
+
+
+class GMM_together(nn.Module):
+    def __init__(self, N=128, M=192, K=5, **kwargs):
+        super().__init__()
+        self.m1 = HSIC(N, M, K)
+        self.m2 = Independent_EN()
+
+    def forward(self, x1, x2, h):
+        out1 = self.m1(x1, x2, h)
+        out2 = self.m2(out1["x1_hat"], out1["x2_hat"], h)
+        return {"x1_hat": out2["x1_hat"], "x2_hat": out2["x2_hat"], "likelihoods": out1["likelihoods"]}

@@ -1,0 +1,166 @@
+/* masic_hip.h -- C ABI of libmasic_hip.so: the MI355X (gfx950) implementation of the MASIC
+ * stereo-codec hot path (reference: ywz978020607/MASIC, coremasic/mywork/MASIC.py:744-851
+ * `HSIC.forward`, and the compressai layers/entropy models it calls).
+ *
+ * The reference has no FFI on this path -- the path sits behind a Python nn.Module API and
+ * every op below is an ATen call there.  This header is therefore the boundary a maintainer
+ * of the reference binds with ctypes (INTEGRATION.md shows the stub); each entry point cites
+ * the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no C++/torch types.  All tensors are NCHW,
+ *     contiguous, float32 unless stated; int32 for symbol streams.
+ *   - the library never allocates, frees or retains device memory: inputs, outputs and
+ *     workspaces are caller-owned (torch tensors in the Python host layer).
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*); no implicit
+ *     synchronisation, safe to capture into a hipGraph.
+ *   - return value: 0 = MASIC_OK, negative = error; masic_last_error() returns a thread-local
+ *     message.  Nothing throws, nothing calls exit().
+ */
+#ifndef MASIC_HIP_H
+#define MASIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MASIC_ABI_VERSION 1
+
+enum { MASIC_OK = 0, MASIC_ERR_ARG = -1, MASIC_ERR_SHAPE = -2, MASIC_ERR_LAUNCH = -3, MASIC_ERR_UNSUPPORTED = -4 };
+
+/* activation fused into conv epilogues (nn.ReLU / nn.LeakyReLU(0.01), MASIC.py:176-182,338-376,679-689) */
+enum { MASIC_ACT_NONE = 0, MASIC_ACT_RELU = 1, MASIC_ACT_LEAKY = 2,
+       MASIC_ACT_SOFTMAX_C = 3 /* softmax over the output channels (mask2weights, MASIC.py:497-502); Cout <= 8 only */ };
+/* transform applied to conv inputs while they are staged (torch.abs MASIC.py:185; torch.round
+ * of `_quantize(...,'dequantize')` entropy_models.py:116 feeding context_prediction MASIC.py:755-757) */
+enum { MASIC_INOP_NONE = 0, MASIC_INOP_ABS = 1, MASIC_INOP_ROUND = 2 };
+/* operand precision of the MFMA contraction; accumulation is always float32 */
+enum { MASIC_PREC_F32 = 0, MASIC_PREC_BF16 = 1 };
+
+int masic_version(void);
+const char* masic_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions.  Replaces torch.nn.Conv2d / ConvTranspose2d as built by
+ * compressai/models/utils.py:128-146 (`conv`: padding=k//2; `deconv`: padding=k//2,
+ * output_padding=stride-1), compressai/layers/layers.py:52-78 (MaskedConv2d type 'A') and
+ * layers.py:81-83 (conv3x3).
+ *
+ * Input  view: channels [in_coff, in_coff+Cin)  of a buffer [B, in_ctot,  Hi, Wi]
+ * Output view: channels [out_coff,out_coff+Cout) of a buffer [B, out_ctot, Ho, Wo]
+ * (views let producers write straight into torch.cat targets, MASIC.py:765,827, and consumers
+ * read slices of them).  Optional gate: out *= gate[b, gate_c, oh, ow] from a buffer
+ * [B, gate_ctot, Ho, Wo] (the mask2weights products of MASIC.py:827).
+ */
+typedef struct {
+    int32_t B, Cin, Hi, Wi, in_ctot, in_coff;
+    int32_t Cout, Ho, Wo, out_ctot, out_coff;
+    int32_t KH, KW, stride, pad;
+    int32_t transposed;   /* 0: Conv2d weight [Cout,Cin,KH,KW]; 1: ConvTranspose2d weight [Cin,Cout,KH,KW] */
+    int32_t masked;       /* 1: MaskedConv2d type 'A' -- only the taps before the centre are live */
+    int32_t in_op;        /* MASIC_INOP_* */
+    int32_t act;          /* MASIC_ACT_*  */
+    int32_t gate_ctot, gate_c;   /* used when the gate pointer is non-NULL */
+    int32_t prec;         /* MASIC_PREC_* */
+} masic_conv_desc_t;
+
+/* bytes of the packed-weight buffer for this layer (weights are re-laid out once per weight
+ * version into the K-major, Cout-contiguous order the implicit-GEMM kernel stages into LDS) */
+size_t masic_conv_packed_bytes(const masic_conv_desc_t* d);
+int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
+/* y = act(conv(in_op(x), w) + bias) [* gate].  bias may be NULL. */
+int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
+                     float* y, const masic_conv_desc_t* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of
+ * compressai/ops/parametrizers.py:47-64 applied to the *stored* beta[C], gamma[C,C] inside the
+ * kernel: y = x * rsqrt(beta^ + gamma^ . x^2)  (inverse: * sqrt).  beta_min as gdn.py:57.
+ */
+int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* y,
+                  int B, int C, int H, int W, int inverse, double beta_min, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Quantisation: compressai/entropy_models/entropy_models.py:98-125 with means=None.
+ *   mode 0 'dequantize': y = round(x)      (torch.round: half to even)
+ *   mode 1 'noise'     : y = x + noise     (noise drawn by the caller, same shape)
+ *   mode 2 'symbols'   : sym = (int32) round(x - median[c])   (median may be NULL -> 0)
+ * Optional gate as above (y *= gate[b,gate_c,h,w]); output view as for convs.
+ */
+int masic_quantize_fwd(const float* x, const float* noise, const float* gate, float* y,
+                       int B, int C, int H, int W, int out_ctot, int out_coff,
+                       int gate_ctot, int gate_c, int mode, void* stream);
+int masic_symbols_fwd(const float* x, const float* median, int32_t* sym,
+                      int B, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * EntropyBottleneck.forward: entropy_models.py:384-411 (+ _likelihood :372-382,
+ * _logits_cumulative :350-369, LowerBound 1e-9).  z [B,C,H,W]; params are the module's raw
+ * parameters, concatenated per channel by the host into one table [C, 58]:
+ *   matrices (3 + 9 + 9 + 9 + 3), biases (3 + 3 + 3 + 3 + 1), factors (3 + 3 + 3 + 3)
+ * (filters (3,3,3,3), entropy_models.py:258); medians = quantiles[:,0,1].
+ * training=1: z_hat = z + noise, noise given in the reference's draw layout (C, 1, B*H*W)
+ * (entropy_models.py:386-394); training=0: z_hat = round(z - med) + med.
+ */
+#define MASIC_EB_PARAMS_PER_CHANNEL 58
+int masic_entropy_bottleneck_fwd(const float* z, const float* params, const float* medians,
+                                 const float* noise, float* z_hat, float* lik,
+                                 int B, int C, int H, int W, int training, float lik_bound, void* stream);
+/* EntropyBottleneck.loss(): entropy_models.py:345-348. out[0] = sum |logits(quantiles) - target| */
+int masic_entropy_bottleneck_auxloss(const float* params, const float* quantiles, float* out,
+                                     int C, double tail_mass, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GaussianMixtureConditional_gf.forward: entropy_models.py:808-858.
+ *   y_hat = quantize(y) (mode as masic_quantize_fwd 0/1), K-component mixture likelihood with
+ *   sigma lower-bounded at scale_bound (0.11) and the result at lik_bound (1e-9).
+ * sigma, mu, wts: [B, K*M, H, W], component k of channel m at k*M+m (MASIC.py:389-393).
+ * weights_are_logits=1 fuses the softmax over K of MASIC.py:389-393/459-464 into the kernel
+ * (wts then holds the raw gmm_weights head output, and wts_out, if non-NULL, receives the
+ * normalised weights).
+ */
+int masic_gmm_likelihood_fwd(const float* y, const float* noise, const float* sigma, const float* mu,
+                             const float* wts, float* y_hat, float* lik, float* wts_out,
+                             int B, int M, int K, int H, int W, int training, int weights_are_logits,
+                             float scale_bound, float lik_bound, void* stream);
+/* softmax over K on the (B,K,M,H,W) view: MASIC.py:389-393 */
+int masic_softmax_k_fwd(const float* x, float* y, int B, int M, int K, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Perspective warp: kornia==0.5.0 warp_perspective(src, M, dsize) as called at
+ * MASIC.py:638,644,781,821,833 (bilinear, zeros padding, align_corners=True).
+ * minv_norm [B,3,3] = inverse(N_dst . M . N_src^-1) (normalised coordinates), computed by
+ * masic_warp_matrix from the pixel-space M [B,3,3] in float64 and rounded to float32.
+ * src NULL => warp an all-ones image (the mask of MASIC.py:636-638) with C=1.
+ */
+int masic_warp_matrix(const float* M, float* minv_norm, int B, int Hs, int Ws, int Hd, int Wd,
+                      int invert_first, void* stream);
+int masic_warp_perspective_fwd(const float* src, const float* minv_norm, float* dst,
+                               int B, int C, int Hs, int Ws, int Hd, int Wd,
+                               int out_ctot, int out_coff, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small elementwise / reduction helpers.
+ *   mul_inplace : MaskedConv2d's `weight.data *= mask` (layers.py:77)
+ *   copy_view   : write a [B,C,H,W] tensor into a channel slice of a wider buffer (torch.cat)
+ *   sum_log / sse : the reductions of RateDistortionLoss (newtrain_codec_real.py:79-83):
+ *                   out[0] = sum(log(x)), out[0] = sum((a-b)^2); deterministic two-stage, fp64 final.
+ *   workspace: at least masic_reduce_workspace_bytes() bytes.
+ */
+int masic_mul_inplace(float* x, const float* m, size_t n, void* stream);
+/* LowerBound / LowerBoundFunction: compressai/ops/bound_ops.py:36-56 (standalone form; the hot path
+ * fuses the bound into the GDN / EB / GMM kernels) */
+int masic_lower_bound_fwd(const float* x, float* y, float bound, size_t n, void* stream);
+int masic_lower_bound_bwd(const float* x, const float* g, float* gx, float bound, size_t n, void* stream);
+int masic_copy_view(const float* x, float* y, int B, int C, int HW, int out_ctot, int out_coff, void* stream);
+size_t masic_reduce_workspace_bytes(void);
+int masic_sum_log(const float* x, size_t n, double* out, void* workspace, void* stream);
+int masic_sse(const float* a, const float* b, size_t n, double* out, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASIC_HIP_H */

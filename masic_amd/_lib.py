@@ -1,0 +1,75 @@
+"""ctypes binding of libmasic_hip.so (include/masic_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol declared in
+the header is not exported, importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmasic_hip.so")
+
+c_int, c_float, c_double, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p
+
+EB_PARAMS_PER_CHANNEL = 58
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SOFTMAX_C = 0, 1, 2, 3
+INOP_NONE, INOP_ABS, INOP_ROUND = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class ConvDesc(ctypes.Structure):
+    """masic_conv_desc_t"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "Cin", "Hi", "Wi", "in_ctot", "in_coff",
+        "Cout", "Ho", "Wo", "out_ctot", "out_coff",
+        "KH", "KW", "stride", "pad", "transposed", "masked", "in_op", "act",
+        "gate_ctot", "gate_c", "prec")]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); every symbol of include/masic_hip.h
+SIGNATURES = {
+    "masic_version": (c_int, []),
+    "masic_last_error": (ctypes.c_char_p, []),
+    "masic_conv_packed_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "masic_conv_pack_weight": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
+    "masic_quantize_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    "masic_symbols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "masic_entropy_bottleneck_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [c_float, _P]),
+    "masic_entropy_bottleneck_auxloss": (c_int, [_P, _P, _P, c_int, c_double, _P]),
+    "masic_gmm_likelihood_fwd": (c_int, [_P] * 8 + [c_int] * 7 + [c_float, c_float, _P]),
+    "masic_softmax_k_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "masic_warp_matrix": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_warp_perspective_fwd": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
+    "masic_mul_inplace": (c_int, [_P, _P, c_size_t, _P]),
+    "masic_lower_bound_fwd": (c_int, [_P, _P, c_float, c_size_t, _P]),
+    "masic_lower_bound_bwd": (c_int, [_P, _P, _P, c_float, c_size_t, _P]),
+    "masic_copy_view": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_reduce_workspace_bytes": (c_size_t, []),
+    "masic_sum_log": (c_int, [_P, c_size_t, _P, _P, _P]),
+    "masic_sse": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"masic_amd: {LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C masic_amd/csrc`). There is no CPU fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.masic_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"masic_hip {what}: error {rc}: {msg}")

@@ -1,0 +1,414 @@
+// conv.hip -- convolutions of the MASIC hot path for gfx950 (MI355X).
+//
+// Replaces every nn.Conv2d / nn.ConvTranspose2d / MaskedConv2d the reference issues from
+// HSIC.forward (coremasic/mywork/MASIC.py:744-851; factories compressai/models/utils.py:128-146,
+// compressai/layers/layers.py:52-83).
+//
+// One formulation covers all of them: an output "phase plane" pixel (r,c) accumulates, over live
+// taps (a,b) and input channels ci,
+//     In[ci, r*is + dh0 + a*dsh, c*is + dw0 + b*dsw] * W[co, ci, kh0 + a*khs, kw0 + b*kws]
+// and lands at output (r*os + oph, c*os + opw).  A strided Conv2d is one phase (is = stride);
+// a ConvTranspose2d with stride s is s*s phases with is = 1, os = s (no multiplies by the zeros of
+// the zero-insertion form); a type-'A' masked conv is one phase that keeps only its 12 live taps.
+//
+// Kernel 1 (implicit GEMM on the matrix cores): the GEMM is  Out[co, pixel] = W[co, k] * Im2col[k, pixel]
+// with k = (tap, ci).  NCHW rows are read coalesced into an LDS patch [ci][row][col] (halo
+// included, padding zero-filled) once per KC input channels and re-used by every tap; the weights
+// arrive pre-packed as [tap][ci][co] so their LDS image is a straight copy.  Each of the 4 waves
+// owns a 32(co) x WN*32(pixel) block of the 64 x BN tile and issues v_mfma_f32_32x32x2_f32
+// (float32 operands, float32 accumulate: bitwise a k-ordered fmaf chain).  The bf16-operand
+// variant of the same structure is selected with desc.prec.
+//
+// Kernel 2 (direct): Cout <= 8 layers (128->3 synthesis output, 6->3 pre/after convs, the
+// mask2weights chain) are HBM/L2-bound, so they skip the matrix cores: one thread per output pixel,
+// all output channels in registers, weights through scalar loads.
+#include "common.h"
+
+namespace {
+
+struct ConvGeom {
+    int ntaps, nth, ntw;
+    int dh0, dsh, dw0, dsw;   // input offset of tap (a,b): ih = r*is + dh0 + a*dsh
+    int kh0, khs, kw0, kws;   // kernel index of tap (a,b): kh = kh0 + a*khs
+    int is;                   // input step per phase-plane pixel
+    int os, oph, opw;         // output coordinate: oh = r*os + oph
+    int Hp, Wp;               // phase-plane size
+    int tap_base;             // first tap of this phase in the packed weights
+    int dh_min, dw_min;       // smallest tap offsets (patch origin)
+};
+
+// Phases of a layer (host side). Returns the number of phases (1 for Conv2d, s*s for transposed).
+int build_geoms(const masic_conv_desc_t& d, ConvGeom* g) {
+    int n = 0, tap_base = 0;
+    if (!d.transposed) {
+        ConvGeom& q = g[n++];
+        q.nth = d.KH; q.ntw = d.KW; q.ntaps = d.KH * d.KW;
+        if (d.masked) {                                   // layers.py:69-75, mask type 'A'
+            q.ntaps = (d.KH / 2) * d.KW + d.KW / 2;
+            q.nth = d.KH / 2 + 1;
+        }
+        q.dh0 = -d.pad; q.dsh = 1; q.dw0 = -d.pad; q.dsw = 1;
+        q.kh0 = 0; q.khs = 1; q.kw0 = 0; q.kws = 1;
+        q.is = d.stride; q.os = 1; q.oph = 0; q.opw = 0;
+        q.Hp = d.Ho; q.Wp = d.Wo; q.tap_base = 0;
+        q.dh_min = -d.pad; q.dw_min = -d.pad;
+        return 1;
+    }
+    const int s = d.stride;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            ConvGeom& q = g[n++];
+            q.kh0 = (ph + d.pad) % s; q.khs = s;
+            q.kw0 = (pw + d.pad) % s; q.kws = s;
+            q.nth = (d.KH - q.kh0 + s - 1) / s;
+            q.ntw = (d.KW - q.kw0 + s - 1) / s;
+            q.ntaps = q.nth * q.ntw;
+            q.dh0 = (ph + d.pad - q.kh0) / s; q.dsh = -1;
+            q.dw0 = (pw + d.pad - q.kw0) / s; q.dsw = -1;
+            q.is = 1; q.os = s; q.oph = ph; q.opw = pw;
+            q.Hp = (d.Ho - ph + s - 1) / s; q.Wp = (d.Wo - pw + s - 1) / s;
+            q.tap_base = tap_base; tap_base += q.ntaps;
+            q.dh_min = q.dh0 - (q.nth - 1); q.dw_min = q.dw0 - (q.ntw - 1);
+        }
+    return n;
+}
+
+struct ConvCfg {
+    int direct;         // 1: direct kernel (Cout <= 8)
+    int wn;             // pixel sub-tiles (of 32) per wave: 4 -> 64x256 block tile, 1 -> 64x64
+    int KC, KClog;      // input channels per LDS chunk
+    int TW, TWlog, SR, TH;
+    int Cin_pad, Cout_pad;
+    int PH, PW, PWp, PSZ;
+    int max_taps;
+    size_t lds_bytes;
+};
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
+    ConvCfg c{};
+    if (d.Cout <= 8) {
+        c.direct = 1; c.Cin_pad = d.Cin; c.Cout_pad = 8;
+        return c;
+    }
+    int Hp = g[0].Hp, Wp = g[0].Wp, is = g[0].is;
+    int span_h = 0, span_w = 0, max_taps = 0;
+    for (int p = 0; p < nphase; ++p) {
+        span_h = span_h > g[p].nth ? span_h : g[p].nth;
+        span_w = span_w > g[p].ntw ? span_w : g[p].ntw;
+        max_taps = max_taps > g[p].ntaps ? max_taps : g[p].ntaps;
+    }
+    c.max_taps = max_taps;
+    c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
+    c.TWlog = ilog2(c.TW);
+    c.SR = 32 / c.TW;
+    c.Cout_pad = round_up(d.Cout, 64);
+    const int mtiles = c.Cout_pad / 64;
+    // large tile only when it still fills the 256 CUs a few times over
+    auto nblocks = [&](int wn) {
+        int TH = c.SR * 2 * wn;
+        return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * mtiles * d.B * nphase;
+    };
+    c.wn = nblocks(4) >= 768 ? 4 : (nblocks(2) >= 512 ? 2 : 1);
+    c.TH = c.SR * 2 * c.wn;
+    c.PH = (c.TH - 1) * is + span_h;
+    c.PW = (c.TW - 1) * is + span_w;
+    c.PWp = c.PW | 1;                                   // odd pitch: fewer LDS bank conflicts across rows
+    c.PSZ = round_up(c.PH * c.PWp, 4);
+    const int cin4 = round_up(d.Cin, 4);
+    int KC = 32;
+    while (KC > 4 && ((size_t)KC * (c.PSZ + max_taps * 64) * 4 > 48 * 1024 || KC > cin4)) KC >>= 1;
+    c.KC = KC; c.KClog = ilog2(KC);
+    c.Cin_pad = round_up(d.Cin, KC);
+    c.lds_bytes = (size_t)KC * (c.PSZ + max_taps * 64) * 4;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------ pack
+struct PackArgs {
+    const float* w; float* wp;
+    int Cin, Cout, KH, KW, Cin_pad, Cout_pad, transposed;
+    ConvGeom g;
+};
+
+__global__ void pack_weight_kernel(const PackArgs a) {
+    const size_t per_tap = (size_t)a.Cin_pad * a.Cout_pad;
+    const size_t total = (size_t)a.g.ntaps * per_tap;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / per_tap);
+        const int rem = (int)(i - (size_t)t * per_tap);
+        const int ci = rem / a.Cout_pad, co = rem - ci * a.Cout_pad;
+        float v = 0.0f;
+        if (ci < a.Cin && co < a.Cout) {
+            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
+            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const size_t src = a.transposed ? (((size_t)ci * a.Cout + co) * a.KH + kh) * a.KW + kw
+                                            : (((size_t)co * a.Cin + ci) * a.KH + kh) * a.KW + kw;
+            v = a.w[src];
+        }
+        a.wp[(size_t)a.g.tap_base * per_tap + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ igemm
+struct IgemmArgs {
+    const float* x; const float* wp; const float* bias; const float* gate; float* y;
+    int Cin, Hi, Wi, in_ctot, in_coff;
+    int Cout, Ho, Wo, out_ctot, out_coff;
+    int Cin_pad, Cout_pad, KC, KClog;
+    int TW, TWlog, SR, TH, tiles_w;
+    int PH, PW, PWp, PSZ;
+    int in_op, act, gate_ctot, gate_c;
+    ConvGeom g;
+};
+
+template <int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;                        // [KC][PH][PWp] (PSZ floats per channel)
+    float* wts = lds + a.KC * a.PSZ;           // [ntaps][KC][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int j = lane & 31, h = lane >> 5;
+
+    const int tw_i = blockIdx.x % a.tiles_w, th_i = blockIdx.x / a.tiles_w;
+    const int m0 = blockIdx.y * 64;
+    const int b = blockIdx.z;
+    const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
+    const int ih0 = r0 * a.g.is + a.g.dh_min, iw0 = c0 * a.g.is + a.g.dw_min;
+
+    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
+    int pixoff[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int r = (wn * WN + n) * a.SR + jr;
+        pixoff[n] = (r * a.g.is) * a.PWp + jc * a.g.is;
+    }
+    f32x16 acc[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+
+    for (int cc = 0; cc < a.Cin_pad; cc += a.KC) {
+        // ---- stage the input patch: coalesced NCHW row segments -> LDS [ci][row][col]
+        for (int ci = 0; ci < a.KC; ++ci) {
+            const int cg = cc + ci;
+            const float* xc = xb + (size_t)cg * plane;
+            float* pc = patch + ci * a.PSZ;
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int ih = ih0 + pr;
+                const bool rowok = (cg < a.Cin) && (ih >= 0) && (ih < a.Hi);
+                const float* src = xc + (size_t)ih * a.Wi;
+                float* dst = pc + pr * a.PWp;
+                for (int pcx = lane; pcx < a.PW; pcx += 64) {
+                    const int iw = iw0 + pcx;
+                    float v = 0.0f;
+                    if (rowok && iw >= 0 && iw < a.Wi) v = apply_inop(src[iw], a.in_op);
+                    dst[pcx] = v;
+                }
+            }
+        }
+        // ---- stage the packed weights [tap][ci][64 co] (straight 16-byte copies)
+        {
+            const int nvec = a.g.ntaps * a.KC * 16;
+            for (int idx = tid; idx < nvec; idx += 256) {
+                const int row = idx >> 4, q = idx & 15;
+                const int t = row >> a.KClog, ci = row & (a.KC - 1);
+                const float4* src = reinterpret_cast<const float4*>(
+                    a.wp + ((size_t)(a.g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0) + q;
+                reinterpret_cast<float4*>(wts)[idx] = *src;
+            }
+        }
+        __syncthreads();
+        // ---- contraction over (tap, ci) for this chunk
+        for (int t = 0; t < a.g.ntaps; ++t) {
+            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
+            const int toff = (a.g.dh0 + ta * a.g.dsh - a.g.dh_min) * a.PWp + (a.g.dw0 + tb * a.g.dsw - a.g.dw_min);
+            const float* wrow = wts + (t * a.KC + h) * 64 + wm * 32 + j;
+            const float* prow = patch + h * a.PSZ + toff;
+            for (int kk = 0; kk < a.KC; kk += 2) {
+                const float av = wrow[kk * 64];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    const float bv = prow[kk * a.PSZ + pixoff[n]];
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, activation, gate, NCHW store (32 consecutive pixels per half-wave)
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
+        if (r >= a.g.Hp || c >= a.g.Wp) continue;
+        const int oh = r * a.g.os + a.g.oph, ow = c * a.g.os + a.g.opw;
+        const size_t opix = (size_t)oh * a.Wo + ow;
+        float gv = 1.0f;
+        if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (co < a.Cout) {
+                float v = acc[n][e] + (a.bias ? a.bias[co] : 0.0f);
+                v = apply_act(v, a.act);
+                if (a.gate) v *= gv;
+                a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ direct
+struct DirectArgs {
+    const float* x; const float* wp; const float* bias; const float* gate; float* y;
+    int Cin, Hi, Wi, in_ctot, in_coff;
+    int Cout, Ho, Wo, out_ctot, out_coff;
+    int in_op, act, gate_ctot, gate_c;
+    ConvGeom g;
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv_direct_f32(const DirectArgs a) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int npix = a.g.Hp * a.g.Wp;
+    const bool live = pix < npix;
+    const int r = live ? pix / a.g.Wp : 0, c = live ? pix - r * a.g.Wp : 0;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.0f;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    for (int t = 0; t < a.g.ntaps; ++t) {
+        const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
+        const int ih = r * a.g.is + a.g.dh0 + ta * a.g.dsh;
+        const int iw = c * a.g.is + a.g.dw0 + tb * a.g.dsw;
+        const bool ok = live && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        const float* xp = xb + (size_t)ih * a.Wi + iw;
+        const float* wt = a.wp + (size_t)(a.g.tap_base + t) * a.Cin * 8;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            const float v = ok ? apply_inop(xp[(size_t)ci * plane], a.in_op) : 0.0f;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] = fmaf(v, wt[ci * 8 + o], acc[o]);
+        }
+    }
+    if (!live) return;
+    const int oh = r * a.g.os + a.g.oph, ow = c * a.g.os + a.g.opw;
+    const size_t oplane = (size_t)a.Ho * a.Wo, opix = (size_t)oh * a.Wo + ow;
+    float gv = 1.0f;
+    if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = (o < a.Cout) ? acc[o] + (a.bias ? a.bias[o] : 0.0f) : 0.0f;
+    if (a.act == MASIC_ACT_SOFTMAX_C) {   // mask2weights: softmax over the output channels (MASIC.py:497-502)
+        float mx = acc[0], sum = 0.0f;
+#pragma unroll
+        for (int o = 1; o < CO; ++o) if (o < a.Cout) mx = fmaxf(mx, acc[o]);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) if (o < a.Cout) { acc[o] = expf(acc[o] - mx); sum += acc[o]; }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = acc[o] / sum;
+    } else {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = apply_act(acc[o], a.act);
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+        if (o < a.Cout) a.y[((size_t)b * a.out_ctot + a.out_coff + o) * oplane + opix] = a.gate ? acc[o] * gv : acc[o];
+}
+
+int check_desc(const masic_conv_desc_t* d) {
+    MASIC_REQUIRE(d != nullptr, MASIC_ERR_ARG, "conv: null descriptor");
+    MASIC_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Hi > 0 && d->Wi > 0, MASIC_ERR_SHAPE,
+                  "conv: non-positive dimension");
+    MASIC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7, MASIC_ERR_UNSUPPORTED, "conv: kernel size %dx%d", d->KH, d->KW);
+    MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv: stride %d", d->stride);
+    MASIC_REQUIRE(d->in_coff >= 0 && d->in_coff + d->Cin <= d->in_ctot, MASIC_ERR_SHAPE, "conv: input channel view out of range");
+    MASIC_REQUIRE(d->out_coff >= 0 && d->out_coff + d->Cout <= d->out_ctot, MASIC_ERR_SHAPE, "conv: output channel view out of range");
+    MASIC_REQUIRE(!(d->masked && d->transposed), MASIC_ERR_UNSUPPORTED, "conv: masked transposed conv");
+    int ho, wo;
+    if (!d->transposed) {
+        ho = (d->Hi + 2 * d->pad - d->KH) / d->stride + 1;
+        wo = (d->Wi + 2 * d->pad - d->KW) / d->stride + 1;
+    } else {
+        ho = (d->Hi - 1) * d->stride - 2 * d->pad + d->KH + (d->stride - 1);
+        wo = (d->Wi - 1) * d->stride - 2 * d->pad + d->KW + (d->stride - 1);
+    }
+    MASIC_REQUIRE(ho == d->Ho && wo == d->Wo, MASIC_ERR_SHAPE, "conv: output size %dx%d given, %dx%d expected", d->Ho, d->Wo, ho, wo);
+    MASIC_REQUIRE(d->act != MASIC_ACT_SOFTMAX_C || d->Cout <= 8, MASIC_ERR_UNSUPPORTED, "conv: channel softmax needs Cout <= 8");
+    MASIC_REQUIRE(d->prec == MASIC_PREC_F32, MASIC_ERR_UNSUPPORTED, "conv: precision %d not built", d->prec);
+    return MASIC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
+    if (check_desc(d) != MASIC_OK) return 0;
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const ConvCfg c = choose_cfg(*d, g, np);
+    int taps = 0;
+    for (int p = 0; p < np; ++p) taps += g[p].ntaps;
+    return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
+}
+
+extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(w && w_packed, MASIC_ERR_ARG, "conv_pack_weight: null pointer");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const ConvCfg c = choose_cfg(*d, g, np);
+    for (int p = 0; p < np; ++p) {
+        PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, g[p]};
+        const size_t total = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return masic_launch_status("conv_pack_weight");
+}
+
+extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
+                                float* y, const masic_conv_desc_t* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(x && w_packed && y, MASIC_ERR_ARG, "conv2d_fwd: null pointer");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const ConvCfg c = choose_cfg(*d, g, np);
+    hipStream_t st = (hipStream_t)stream;
+    for (int p = 0; p < np; ++p) {
+        if (g[p].Hp <= 0 || g[p].Wp <= 0) continue;
+        if (c.direct) {
+            DirectArgs a{x, (const float*)w_packed, bias, gate, y,
+                         d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
+                         d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+                         d->in_op, d->act, d->gate_ctot, d->gate_c, g[p]};
+            dim3 grid(ceil_div(g[p].Hp * g[p].Wp, 256), d->B);
+            if (d->Cout <= 3) hipLaunchKernelGGL(conv_direct_f32<3>, grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(conv_direct_f32<8>, grid, dim3(256), 0, st, a);
+            continue;
+        }
+        IgemmArgs a{x, (const float*)w_packed, bias, gate, y,
+                    d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
+                    d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+                    c.Cin_pad, c.Cout_pad, c.KC, c.KClog,
+                    c.TW, c.TWlog, c.SR, c.TH, ceil_div(g[p].Wp, c.TW),
+                    c.PH, c.PW, c.PWp, c.PSZ,
+                    d->in_op, d->act, d->gate_ctot, d->gate_c, g[p]};
+        dim3 grid(ceil_div(g[p].Wp, c.TW) * ceil_div(g[p].Hp, c.TH), c.Cout_pad / 64, d->B);
+        if (c.wn == 4) hipLaunchKernelGGL(conv_igemm_f32<4>, grid, dim3(256), c.lds_bytes, st, a);
+        else if (c.wn == 2) hipLaunchKernelGGL(conv_igemm_f32<2>, grid, dim3(256), c.lds_bytes, st, a);
+        else hipLaunchKernelGGL(conv_igemm_f32<1>, grid, dim3(256), c.lds_bytes, st, a);
+    }
+    return masic_launch_status("conv2d_fwd");
+}

@@ -1,0 +1,136 @@
+// warp.hip -- perspective warp of the MASIC hot path (gfx950).
+//
+// Reference call sites: coremasic/mywork/MASIC.py:638,644 (mask), 781 (x1), 821/833 (x1_hat):
+// kornia==0.5.0 `warp_perspective(src, M, dsize)` with defaults (bilinear, zeros, align_corners
+// -> True).  kornia is a pip dependency that is not vendored in the reference; its algorithm
+// (normalize_homography -> inverse -> create_meshgrid(normalized) -> transform_points ->
+// convert_points_from_homogeneous(eps=1e-8) -> F.grid_sample) is restated here and in
+// oracle/hsic_oracle.py:warp_perspective with the same float32 operation order for the sampling
+// coordinates (explicit __fmul_rn/__fadd_rn: no FMA contraction), because sub-pixel coordinate
+// rounding dominates the error budget of this op.
+//
+// HBM-bound gather: one thread per destination pixel computes the source location once and
+// samples every channel (4 taps each); destination stores are coalesced along W.
+#include "common.h"
+
+namespace {
+
+// M (pixel space, dst <- src) -> inverse(N_dst . M . N_src^-1), float64 internally.
+__global__ void warp_matrix_kernel(const float* __restrict__ M, float* __restrict__ out, int B,
+                                   int Hs, int Ws, int Hd, int Wd, int invert_first) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double m[9];
+    for (int i = 0; i < 9; ++i) m[i] = (double)M[b * 9 + i];
+    auto inv3 = [](const double* a, double* r) {
+        const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+        const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+        const double id = 1.0 / det;
+        r[0] = c00 * id; r[1] = (a[2] * a[7] - a[1] * a[8]) * id; r[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+        r[3] = c01 * id; r[4] = (a[0] * a[8] - a[2] * a[6]) * id; r[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+        r[6] = c02 * id; r[7] = (a[1] * a[6] - a[0] * a[7]) * id; r[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    };
+    if (invert_first) { double t[9]; inv3(m, t); for (int i = 0; i < 9; ++i) m[i] = t[i]; }
+    // N(h,w) = [[2/(w-1),0,-1],[0,2/(h-1),-1],[0,0,1]];  N^-1 = [[(w-1)/2,0,(w-1)/2],[0,(h-1)/2,(h-1)/2],[0,0,1]]
+    const double sxs = Ws == 1 ? 1e-14 : (double)(Ws - 1), sys = Hs == 1 ? 1e-14 : (double)(Hs - 1);
+    const double sxd = Wd == 1 ? 1e-14 : (double)(Wd - 1), syd = Hd == 1 ? 1e-14 : (double)(Hd - 1);
+    double t[9];   // M . N_src^-1
+    for (int r = 0; r < 3; ++r) {
+        t[3 * r + 0] = m[3 * r + 0] * (sxs / 2.0);
+        t[3 * r + 1] = m[3 * r + 1] * (sys / 2.0);
+        t[3 * r + 2] = m[3 * r + 0] * (sxs / 2.0) + m[3 * r + 1] * (sys / 2.0) + m[3 * r + 2];
+    }
+    double u[9];   // N_dst . t
+    for (int c = 0; c < 3; ++c) {
+        u[0 + c] = (2.0 / sxd) * t[0 + c] - t[6 + c];
+        u[3 + c] = (2.0 / syd) * t[3 + c] - t[6 + c];
+        u[6 + c] = t[6 + c];
+    }
+    double r9[9];
+    inv3(u, r9);
+    for (int i = 0; i < 9; ++i) out[b * 9 + i] = (float)r9[i];
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, const float* __restrict__ minv,
+                                                   float* __restrict__ dst, int C, int Hs, int Ws, int Hd, int Wd,
+                                                   int out_ctot, int out_coff) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hd * Wd) return;
+    const int oy = pix / Wd, ox = pix - oy * Wd;
+    const float* m = minv + b * 9;
+    // create_meshgrid(normalized_coordinates=True): (i / (n-1) - 0.5) * 2
+    const float gx = __fmul_rn(__fsub_rn(__fdiv_rn((float)ox, (float)(Wd - 1)), 0.5f), 2.0f);
+    const float gy = __fmul_rn(__fsub_rn(__fdiv_rn((float)oy, (float)(Hd - 1)), 0.5f), 2.0f);
+    const float X = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[0]), __fmul_rn(gy, m[1])), m[2]);
+    const float Y = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[3]), __fmul_rn(gy, m[4])), m[5]);
+    const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
+    const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
+    const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
+    // F.grid_sample(align_corners=True): pixel = (n + 1) * ((size - 1) / 2)
+    const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(Ws - 1), 2.0f));
+    const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(Hs - 1), 2.0f));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = __fsub_rn(fx, x0f), wy = __fsub_rn(fy, y0f);
+    const float ex = __fsub_rn(1.0f, wx), ey = __fsub_rn(1.0f, wy);
+    const float w_nw = __fmul_rn(ex, ey), w_ne = __fmul_rn(wx, ey), w_sw = __fmul_rn(ex, wy), w_se = __fmul_rn(wx, wy);
+    // float -> int with saturation so that far-away samples stay out of range instead of wrapping
+    const float lim = 1.0e9f;
+    const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Ws, vx1 = x1 >= 0 && x1 < Ws;
+    const bool vy0 = y0 >= 0 && y0 < Hs, vy1 = y1 >= 0 && y1 < Hs;
+    const bool finite = (fx == fx) && (fy == fy);
+    const size_t splane = (size_t)Hs * Ws, dplane = (size_t)Hd * Wd;
+    float* d = dst + ((size_t)b * out_ctot + out_coff) * dplane + pix;
+    if (src == nullptr) {   // warp of an all-ones image (MASIC.py:636-638): the sum of the in-range weights
+        float v = 0.0f;
+        if (finite) {
+            v = (vx0 && vy0) ? w_nw : 0.0f;
+            v = __fadd_rn(v, (vx1 && vy0) ? w_ne : 0.0f);
+            v = __fadd_rn(v, (vx0 && vy1) ? w_sw : 0.0f);
+            v = __fadd_rn(v, (vx1 && vy1) ? w_se : 0.0f);
+        }
+        d[0] = v;
+        return;
+    }
+    const float* s = src + (size_t)b * C * splane;
+    for (int c = 0; c < C; ++c) {
+        const float* sc = s + (size_t)c * splane;
+        float v = 0.0f;
+        if (finite) {
+            const float nw = (vx0 && vy0) ? sc[(size_t)y0 * Ws + x0] : 0.0f;
+            const float ne = (vx1 && vy0) ? sc[(size_t)y0 * Ws + x1] : 0.0f;
+            const float sw = (vx0 && vy1) ? sc[(size_t)y1 * Ws + x0] : 0.0f;
+            const float se = (vx1 && vy1) ? sc[(size_t)y1 * Ws + x1] : 0.0f;
+            v = __fmul_rn(nw, w_nw);
+            v = __fadd_rn(v, __fmul_rn(ne, w_ne));
+            v = __fadd_rn(v, __fmul_rn(sw, w_sw));
+            v = __fadd_rn(v, __fmul_rn(se, w_se));
+        }
+        d[(size_t)c * dplane] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int masic_warp_matrix(const float* M, float* minv_norm, int B, int Hs, int Ws, int Hd, int Wd,
+                                 int invert_first, void* stream) {
+    MASIC_REQUIRE(M && minv_norm, MASIC_ERR_ARG, "warp_matrix: null pointer");
+    MASIC_REQUIRE(B > 0, MASIC_ERR_SHAPE, "warp_matrix: B=%d", B);
+    hipLaunchKernelGGL(warp_matrix_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, M, minv_norm, B,
+                       Hs, Ws, Hd, Wd, invert_first);
+    return masic_launch_status("warp_matrix");
+}
+
+extern "C" int masic_warp_perspective_fwd(const float* src, const float* minv_norm, float* dst,
+                                          int B, int C, int Hs, int Ws, int Hd, int Wd,
+                                          int out_ctot, int out_coff, void* stream) {
+    MASIC_REQUIRE(minv_norm && dst, MASIC_ERR_ARG, "warp_perspective_fwd: null pointer");
+    MASIC_REQUIRE(B > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, MASIC_ERR_SHAPE, "warp_perspective_fwd: bad shape");
+    MASIC_REQUIRE(src != nullptr || C == 1, MASIC_ERR_ARG, "warp_perspective_fwd: ones-source needs C == 1");
+    MASIC_REQUIRE(out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "warp_perspective_fwd: output view out of range");
+    hipLaunchKernelGGL(warp_kernel, dim3(ceil_div(Hd * Wd, 256), B), dim3(256), 0, (hipStream_t)stream, src, minv_norm,
+                       dst, C, Hs, Ws, Hd, Wd, out_ctot, out_coff);
+    return masic_launch_status("warp_perspective_fwd");
+}

@@ -1,0 +1,37 @@
+"""Stereo rate-distortion criterion on the HIP reductions.
+
+Reference: coremasic/mywork/newtrain_codec_real.py:66-87 (`RateDistortionLoss.forward(output, target1, target2)`):
+  bpp_loss = sum_{y1,y2,z1,z2} sum(log(lik)) / (-ln2 * B*H*W);  mse_loss = MSE(x1_hat,x1) + MSE(x2_hat,x2);
+  loss = lmbda * 255^2 * mse_loss + bpp_loss;  psnr_i = 10*log10(1/mse_i).
+The four log-sums and two squared-error sums run as deterministic two-stage device reductions
+(masic_amd/csrc/misc.hip) with a float64 final stage; the scalars stay on the device until asked for.
+"""
+import math
+
+from . import ops
+
+
+class RateDistortionLoss:
+    """Callable with the reference's signature: criterion(out_net, d1, d2) -> dict."""
+
+    def __init__(self, lmbda=1e-2):
+        self.lmbda = lmbda
+
+    def __call__(self, output, target1, target2):
+        return rate_distortion(output, target1, target2, self.lmbda)
+
+
+def rate_distortion(output, target1, target2, lmbda):
+    B, _, H, W = target1.shape
+    num_pixels = B * H * W
+    per = {k: ops.sum_log(v.contiguous()) / (-math.log(2) * num_pixels) for k, v in output["likelihoods"].items()}
+    bpp = sum(per.values())
+    mse1 = ops.sse(output["x1_hat"].contiguous(), target1.contiguous()) / target1.numel()
+    mse2 = ops.sse(output["x2_hat"].contiguous(), target2.contiguous()) / target2.numel()
+    mse = mse1 + mse2
+    out = {"bpp_loss": bpp.float(), "mse_loss": mse.float(), "loss": (lmbda * 255 ** 2 * mse + bpp).float(),
+           "mse1": mse1, "mse2": mse2}
+    out.update({"bpp_" + k: v for k, v in per.items()})
+    out["psnr1"] = 10 * math.log10(1 / float(mse1))
+    out["psnr2"] = 10 * math.log10(1 / float(mse2))
+    return out

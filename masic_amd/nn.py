@@ -1,0 +1,80 @@
+"""HIP-backed drop-ins for the nn.Conv2d / nn.ConvTranspose2d modules the reference's factories
+return (compressai/models/utils.py:128-146).  They subclass the torch modules so parameter names,
+initialisation (`isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))`, MASIC.py:67-72), state dicts and
+optimizers are unchanged; only `forward` is replaced by the implicit-GEMM kernels of
+masic_amd/csrc/conv.hip.
+
+Weights are re-laid out ("packed") for the kernel once per weight version: the cache key is the
+parameter's autograd version counter + storage pointer, so optimizer steps and load_state_dict
+trigger a re-pack and eval loops do not.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import PREC_F32
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class _PackedWeightMixin:
+    transposed_conv = False
+    masked_conv = False
+
+    def _geometry(self):
+        kh, kw = _pair(self.kernel_size)
+        sh, sw = _pair(self.stride)
+        ph, pw = _pair(self.padding)
+        if sh != sw or ph != pw or _pair(self.dilation) != (1, 1) or self.groups != 1:
+            raise RuntimeError("masic_amd: only square stride/padding, dilation 1, groups 1 convolutions are built")
+        if self.transposed_conv and _pair(self.output_padding) != (sh - 1, sh - 1):
+            raise RuntimeError("masic_amd: ConvTranspose2d needs output_padding = stride - 1 (compressai deconv())")
+        return kh, kw, sh, ph
+
+    def _desc(self, x_shape, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, in_op=ops.INOP_NONE,
+              act=ops.ACT_NONE, gate_ctot=0, gate_c=0):
+        kh, kw, s, p = self._geometry()
+        B, _, Hi, Wi = x_shape
+        return ops.make_conv_desc(B, self.in_channels, Hi, Wi, self.out_channels, kh, kw, s, p,
+                                  transposed=self.transposed_conv, masked=self.masked_conv,
+                                  in_ctot=in_ctot, in_coff=in_coff, out_ctot=out_ctot, out_coff=out_coff,
+                                  in_op=in_op, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=PREC_F32)
+
+    def packed_weight(self, desc):
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi)
+        cache = self.__dict__.get("_packed_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.pack_conv_weight(w.detach().contiguous(), desc))
+            self.__dict__["_packed_cache"] = cache
+        return cache[1]
+
+    def invalidate_packed_weight(self):
+        self.__dict__.pop("_packed_cache", None)
+
+    def run(self, x, in_coff=0, out=None, out_coff=0, in_op=ops.INOP_NONE, act=ops.ACT_NONE, gate=None, gate_c=0):
+        """Fused form: y = act(conv(in_op(x[:, in_coff:in_coff+Cin])) + bias) [* gate[:, gate_c]],
+        optionally written into channels [out_coff, out_coff+Cout) of `out` (a torch.cat target)."""
+        desc = self._desc(x.shape, in_ctot=x.shape[1], in_coff=in_coff,
+                          out_ctot=None if out is None else out.shape[1], out_coff=out_coff,
+                          in_op=in_op, act=act, gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
+        bias = None if self.bias is None else self.bias.detach()
+        return ops.conv2d(x, self.packed_weight(desc), bias, desc, out=out, gate=gate)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Conv2d(_PackedWeightMixin, nn.Conv2d):
+    pass
+
+
+class ConvTranspose2d(_PackedWeightMixin, nn.ConvTranspose2d):
+    transposed_conv = True
+
+    def forward(self, x, output_size=None):
+        if output_size is not None:
+            raise RuntimeError("masic_amd: ConvTranspose2d(output_size=...) is not supported")
+        return self.run(x)

@@ -1,0 +1,284 @@
+"""Tensor-level entry points of the HIP path: each function checks shapes on the host, allocates
+its outputs with torch (device memory is torch's; the library never allocates) and launches the
+C-ABI kernel on torch's current HIP stream.  No function here computes on the CPU and none falls
+back to ATen ops: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SOFTMAX_C, INOP_ABS, INOP_NONE, INOP_ROUND,  # noqa: F401
+                   ConvDesc, check, lib)
+
+LIK_BOUND = 1e-9
+SCALE_BOUND = 0.11
+
+
+def _dev(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"masic_amd: {name} must be a CUDA (HIP) tensor -- the MI355X path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"masic_amd: {name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"masic_amd: {name} must be contiguous (NCHW)")
+    return t
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------------------------- conv
+def conv_out_hw(Hi, Wi, KH, KW, stride, pad, transposed):
+    if transposed:
+        return ((Hi - 1) * stride - 2 * pad + KH + stride - 1, (Wi - 1) * stride - 2 * pad + KW + stride - 1)
+    return ((Hi + 2 * pad - KH) // stride + 1, (Wi + 2 * pad - KW) // stride + 1)
+
+
+def make_conv_desc(B, Cin, Hi, Wi, Cout, KH, KW, stride, pad, transposed=False, masked=False,
+                   in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, in_op=INOP_NONE, act=ACT_NONE,
+                   gate_ctot=0, gate_c=0, prec=_lib.PREC_F32):
+    Ho, Wo = conv_out_hw(Hi, Wi, KH, KW, stride, pad, transposed)
+    return ConvDesc(B=B, Cin=Cin, Hi=Hi, Wi=Wi, in_ctot=in_ctot if in_ctot is not None else Cin, in_coff=in_coff,
+                    Cout=Cout, Ho=Ho, Wo=Wo, out_ctot=out_ctot if out_ctot is not None else Cout, out_coff=out_coff,
+                    KH=KH, KW=KW, stride=stride, pad=pad, transposed=int(transposed), masked=int(masked),
+                    in_op=in_op, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=prec)
+
+
+def pack_conv_weight(weight, desc):
+    """Re-lays a Conv2d / ConvTranspose2d weight out as [phase-tap][ci][co] (include/masic_hip.h)."""
+    _dev(weight, "weight")
+    nbytes = lib.masic_conv_packed_bytes(ctypes.byref(desc))
+    if nbytes == 0:
+        check(-1, "conv_packed_bytes")
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    check(lib.masic_conv_pack_weight(_p(weight), _p(packed), ctypes.byref(desc), _stream()), "conv_pack_weight")
+    return packed
+
+
+def conv2d(x, packed, bias, desc, out=None, gate=None):
+    _dev(x, "conv input")
+    if x.dim() != 4 or x.shape[0] != desc.B or x.shape[1] != desc.in_ctot or x.shape[2] != desc.Hi or x.shape[3] != desc.Wi:
+        raise RuntimeError(f"masic_amd.conv2d: input {tuple(x.shape)} does not match descriptor "
+                           f"[{desc.B},{desc.in_ctot},{desc.Hi},{desc.Wi}]")
+    if out is None:
+        out = torch.empty((desc.B, desc.out_ctot, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, "conv output")
+        if tuple(out.shape) != (desc.B, desc.out_ctot, desc.Ho, desc.Wo):
+            raise RuntimeError(f"masic_amd.conv2d: output buffer {tuple(out.shape)} does not match descriptor")
+    if gate is not None:
+        _dev(gate, "gate")
+        if tuple(gate.shape) != (desc.B, desc.gate_ctot, desc.Ho, desc.Wo):
+            raise RuntimeError(f"masic_amd.conv2d: gate {tuple(gate.shape)} does not match descriptor")
+    if bias is not None:
+        _dev(bias, "bias")
+    check(lib.masic_conv2d_fwd(_p(x), _p(packed), _p(bias), _p(gate), _p(out), ctypes.byref(desc), _stream()), "conv2d_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- GDN
+def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+    _dev(x, "gdn input"); _dev(beta, "beta"); _dev(gamma, "gamma")
+    B, C, H, W = x.shape
+    if beta.numel() != C or tuple(gamma.shape) != (C, C):
+        raise RuntimeError("masic_amd.gdn: parameter shapes do not match the input channels")
+    y = torch.empty_like(x)
+    check(lib.masic_gdn_fwd(_p(x), _p(beta), _p(gamma), _p(y), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------------------------- entropy
+def quantize(x, mode, noise=None, out=None, out_coff=0, gate=None, gate_c=0):
+    """mode: 'dequantize' (round) or 'noise' (x + noise)."""
+    _dev(x, "quantize input")
+    B, C, H, W = x.shape
+    m = {"dequantize": 0, "noise": 1}[mode]
+    if m == 1:
+        _dev(noise, "noise")
+        if noise.numel() != x.numel():
+            raise RuntimeError("masic_amd.quantize: noise size mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _dev(out, "quantize output")
+        if out.shape[0] != B or out.shape[2] != H or out.shape[3] != W:
+            raise RuntimeError("masic_amd.quantize: output buffer shape mismatch")
+    gate_ctot = 0
+    if gate is not None:
+        _dev(gate, "gate")
+        if gate.shape[0] != B or gate.shape[2] != H or gate.shape[3] != W:
+            raise RuntimeError("masic_amd.quantize: gate shape mismatch")
+        gate_ctot = gate.shape[1]
+    check(lib.masic_quantize_fwd(_p(x), _p(noise), _p(gate), _p(out), B, C, H, W, out.shape[1], out_coff,
+                                 gate_ctot, gate_c, m, _stream()), "quantize_fwd")
+    return out
+
+
+def symbols(x, medians=None):
+    _dev(x, "symbols input")
+    B, C, H, W = x.shape
+    if medians is not None:
+        _dev(medians, "medians")
+        if medians.numel() != C:
+            raise RuntimeError("masic_amd.symbols: medians size mismatch")
+    sym = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    check(lib.masic_symbols_fwd(_p(x), _p(medians), _p(sym), B, C, H, W, _stream()), "symbols_fwd")
+    return sym
+
+
+def eb_param_table(matrices, biases, factors):
+    """[C,58] table: matrices (3,9,9,9,3) | biases (3,3,3,3,1) | factors (3,3,3,3) per channel."""
+    C = matrices[0].shape[0]
+    parts = [m.reshape(C, -1) for m in matrices] + [b.reshape(C, -1) for b in biases] + [f.reshape(C, -1) for f in factors]
+    table = torch.cat(parts, dim=1).contiguous()
+    if table.shape[1] != _lib.EB_PARAMS_PER_CHANNEL:
+        raise RuntimeError("masic_amd: EntropyBottleneck filters must be (3,3,3,3)")
+    return table
+
+
+def entropy_bottleneck(z, table, medians, training=False, noise=None, lik_bound=LIK_BOUND):
+    _dev(z, "z"); _dev(table, "EB table"); _dev(medians, "medians")
+    B, C, H, W = z.shape
+    if tuple(table.shape) != (C, _lib.EB_PARAMS_PER_CHANNEL) or medians.numel() != C:
+        raise RuntimeError("masic_amd.entropy_bottleneck: parameter table does not match channels")
+    if training:
+        _dev(noise, "noise")
+        if noise.numel() != z.numel():
+            raise RuntimeError("masic_amd.entropy_bottleneck: noise size mismatch")
+    z_hat = torch.empty_like(z)
+    lik = torch.empty_like(z)
+    check(lib.masic_entropy_bottleneck_fwd(_p(z), _p(table), _p(medians), _p(noise), _p(z_hat), _p(lik),
+                                           B, C, H, W, int(training), float(lik_bound), _stream()), "entropy_bottleneck_fwd")
+    return z_hat, lik
+
+
+def entropy_bottleneck_auxloss(table, quantiles, tail_mass=1e-9):
+    _dev(table, "EB table"); _dev(quantiles, "quantiles")
+    C = table.shape[0]
+    out = torch.empty(1, dtype=torch.float32, device=table.device)
+    check(lib.masic_entropy_bottleneck_auxloss(_p(table), _p(quantiles), _p(out), C, float(tail_mass), _stream()), "eb_auxloss")
+    return out[0]
+
+
+def gmm_likelihood(y, sigma, mu, wts, K, training=False, noise=None, weights_are_logits=False,
+                   want_weights=False, scale_bound=SCALE_BOUND, lik_bound=LIK_BOUND):
+    _dev(y, "y"); _dev(sigma, "sigma"); _dev(mu, "mu"); _dev(wts, "weights")
+    B, M, H, W = y.shape
+    for t, n in ((sigma, "sigma"), (mu, "mu"), (wts, "weights")):
+        if tuple(t.shape) != (B, K * M, H, W):
+            raise RuntimeError(f"masic_amd.gmm_likelihood: {n} {tuple(t.shape)} != {(B, K * M, H, W)}")
+    if training:
+        _dev(noise, "noise")
+        if noise.numel() != y.numel():
+            raise RuntimeError("masic_amd.gmm_likelihood: noise size mismatch")
+    y_hat = torch.empty_like(y)
+    lik = torch.empty_like(y)
+    wout = torch.empty_like(wts) if (weights_are_logits and want_weights) else None
+    check(lib.masic_gmm_likelihood_fwd(_p(y), _p(noise), _p(sigma), _p(mu), _p(wts), _p(y_hat), _p(lik), _p(wout),
+                                       B, M, K, H, W, int(training), int(weights_are_logits),
+                                       float(scale_bound), float(lik_bound), _stream()), "gmm_likelihood_fwd")
+    return (y_hat, lik, wout) if want_weights else (y_hat, lik)
+
+
+def softmax_k(x, K):
+    _dev(x, "softmax input")
+    B, KM, H, W = x.shape
+    y = torch.empty_like(x)
+    check(lib.masic_softmax_k_fwd(_p(x), _p(y), B, KM // K, K, H * W, _stream()), "softmax_k_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------------------------- warp
+def warp_matrix(M, src_hw, dst_hw, invert_first=False):
+    _dev(M, "homography")
+    B = M.shape[0]
+    if tuple(M.shape) != (B, 3, 3):
+        raise RuntimeError("masic_amd.warp_matrix: homography must be [B,3,3]")
+    out = torch.empty_like(M)
+    check(lib.masic_warp_matrix(_p(M), _p(out), B, src_hw[0], src_hw[1], dst_hw[0], dst_hw[1], int(invert_first), _stream()), "warp_matrix")
+    return out
+
+
+def warp_perspective(src, minv_norm, dsize, ones_like=None, out=None, out_coff=0):
+    """src None: warp an all-ones [B,1,H,W] image whose size is given by ones_like=(B,H,W)."""
+    _dev(minv_norm, "warp matrix")
+    if src is not None:
+        _dev(src, "warp source")
+        B, C, Hs, Ws = src.shape
+    else:
+        B, Hs, Ws = ones_like
+        C = 1
+    if tuple(minv_norm.shape) != (B, 3, 3):
+        raise RuntimeError("masic_amd.warp_perspective: matrix batch mismatch")
+    Hd, Wd = dsize
+    if out is None:
+        out = torch.empty((B, C, Hd, Wd), dtype=torch.float32, device=minv_norm.device)
+    else:
+        _dev(out, "warp output")
+    check(lib.masic_warp_perspective_fwd(_p(src), _p(minv_norm), _p(out), B, C, Hs, Ws, Hd, Wd, out.shape[1], out_coff, _stream()),
+          "warp_perspective_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- misc
+def mul_inplace(x, m):
+    _dev(x, "x"); _dev(m, "mask")
+    if x.numel() != m.numel():
+        raise RuntimeError("masic_amd.mul_inplace: size mismatch")
+    check(lib.masic_mul_inplace(_p(x), _p(m), x.numel(), _stream()), "mul_inplace")
+    return x
+
+
+def lower_bound(x, bound):
+    _dev(x, "x")
+    y = torch.empty_like(x)
+    check(lib.masic_lower_bound_fwd(_p(x), _p(y), float(bound), x.numel(), _stream()), "lower_bound_fwd")
+    return y
+
+
+def lower_bound_bwd(x, g, bound):
+    _dev(x, "x"); _dev(g, "grad")
+    gx = torch.empty_like(x)
+    check(lib.masic_lower_bound_bwd(_p(x), _p(g), _p(gx), float(bound), x.numel(), _stream()), "lower_bound_bwd")
+    return gx
+
+
+def copy_view(x, out, out_coff):
+    _dev(x, "x"); _dev(out, "out")
+    B, C, H, W = x.shape
+    check(lib.masic_copy_view(_p(x), _p(out), B, C, H * W, out.shape[1], out_coff, _stream()), "copy_view")
+    return out
+
+
+_ws = {}
+
+
+def _workspace(device):
+    key = (device.type, device.index)
+    if key not in _ws:
+        _ws[key] = torch.empty(lib.masic_reduce_workspace_bytes() // 8, dtype=torch.float64, device=device)
+    return _ws[key]
+
+
+def sum_log(x):
+    """float64 device scalar: sum(log(x))."""
+    _dev(x, "x")
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    check(lib.masic_sum_log(_p(x), x.numel(), _p(out), _p(_workspace(x.device)), _stream()), "sum_log")
+    return out[0]
+
+
+def sse(a, b):
+    """float64 device scalar: sum((a-b)^2)."""
+    _dev(a, "a"); _dev(b, "b")
+    if a.numel() != b.numel():
+        raise RuntimeError("masic_amd.sse: size mismatch")
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    check(lib.masic_sse(_p(a), _p(b), a.numel(), _p(out), _p(_workspace(a.device)), _stream()), "sse")
+    return out[0]

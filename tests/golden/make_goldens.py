@@ -1,0 +1,227 @@
+"""Generates tests/golden/*.npz from the REFERENCE implementation (run in the build container only).
+
+    python tests/golden/make_goldens.py
+
+The reference's own coremasic/mywork/MASIC.py + compressai/* are imported on CPU through
+oracle/ref_import.py (third-party stubs, kornia warp restated -- see that file), loaded with the
+deterministic synthetic weights of masic_amd/synth.py, and run; inputs, weights and every output are
+stored as plain arrays.  The fixtures are data only: no reference source text is written anywhere.
+
+Files
+  hsic_tiny.npz       HSIC(N=16,M=24,K=3), 1x3x64x64: inputs, all parameters, eval outputs, symbols,
+                      RD-loss scalars, train-mode outputs with the 7 recorded noise draws, and
+                      d(loss)/d(parameter) for every parameter (train mode) + aux-loss value/grads.
+  hsic_small.npz      HSIC(N=32,M=48,K=3), 2x3x128x192 (ragged 8x12 latent): inputs by seed, eval
+                      outputs (weights regenerated from the seed by masic_amd.synth).
+  hsic_c1_digest.json BASELINE config 1 (1x3x256x256, N=128,M=192,K=5): scalar goldens, symbol SHA-256,
+                      64 sampled values per output (weights/inputs regenerated from the seed).
+  state_keys.json     names/shapes/dtypes of the reference's HSIC(128,192,5).state_dict() (248 tensors)
+                      and Independent_EN().state_dict() (86).
+  pin_report.json     max |oracle - reference| per tensor for every case above.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import hsic_oracle as O  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+R = ref_import.load()
+# masic_amd.synth is pure numpy/torch; import it without pulling the product's `compressai`
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("masic_synth", os.path.join(ROOT, "masic_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+torch.set_num_threads(8)
+LMBDA = 0.01
+
+
+def build_ref(N, M, K, seed):
+    net = R.HSIC(N=N, M=M, K=K)
+    sd = synth.synth_state_dict(net.state_dict(), seed=seed)
+    net.load_state_dict(sd)
+    return net, {k: v.clone() for k, v in net.state_dict().items()}
+
+
+def ref_symbols(net, x1, x2, H):
+    """What reference compress() quantises (MASIC.py:859-868, 1013): symbols of y1,y2,z1,z2."""
+    import importlib
+    with torch.no_grad():
+        y1 = net.encoder1(x1)[0]
+        z1 = net._h_a1(y1)
+        # the reference calls kornia.warp_perspective through its module global (our restated warp)
+        x1_warp = O.warp_perspective(x1, H, x1.shape[-2:])
+        y2 = net.encoder2(x1_warp, x2)
+        z2 = net._h_a2(y2)
+        med1 = net.entropy_bottleneck1._medians().detach().view(1, -1, 1, 1)
+        med2 = net.entropy_bottleneck2._medians().detach().view(1, -1, 1, 1)
+        return {"y1": net.gaussian1._quantize(y1, "symbols"), "y2": net.gaussian2._quantize(y2, "symbols"),
+                "z1": net.entropy_bottleneck1._quantize(z1, "symbols", med1),
+                "z2": net.entropy_bottleneck2._quantize(z2, "symbols", med2)}
+
+
+def ref_loss(out, x1, x2):
+    """newtrain_codec_real.py:66-87 restated on the reference's outputs (the driver file imports cv2)."""
+    return O.rd_loss(out, x1, x2, LMBDA)
+
+
+def flat_outputs(out, prefix):
+    d = {prefix + k: out[k].detach().numpy() for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat", "x1_mask_R", "x1_mask_L")}
+    for k, v in out["likelihoods"].items():
+        d[prefix + "lik_" + k] = v.detach().numpy()
+    return d
+
+
+def record_noise(net):
+    """Wrap every entropy model's cached-noise method to log the draws in order."""
+    log = []
+    EM = type(net.gaussian1).__mro__[1]
+    orig = EM._get_noise_cached
+
+    def logged(self, x):
+        n = orig(self, x)
+        log.append(n.clone())
+        return n
+
+    EM._get_noise_cached = logged
+    return log, lambda: setattr(EM, "_get_noise_cached", orig)
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def pin(case, ref_out, ora_out, report):
+    r = {}
+    for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat", "x1_mask_R", "x1_mask_L"):
+        r[k] = maxdiff(ref_out[k], ora_out[k])
+    for k in ref_out["likelihoods"]:
+        r["lik_" + k] = maxdiff(ref_out["likelihoods"][k], ora_out["likelihoods"][k])
+    report[case] = r
+
+
+def main():
+    report = {}
+    # ------------------------------------------------------------------ tiny: full tensors + grads
+    N, M, K = 16, 24, 3
+    net, sd = build_ref(N, M, K, seed=1)
+    x1, x2, H = synth.synth_inputs(1, 64, 64, seed=1)
+    fx = {"x1": x1.numpy(), "x2": x2.numpy(), "h_matrix": H.numpy(), "NMK": np.array([N, M, K]), "lmbda": np.array(LMBDA)}
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and v.numel() > 0:
+            fx["sd/" + k] = v.numpy()
+    net.eval()
+    with torch.no_grad():
+        out = net(x1, x2, H)
+        ora = O.hsic_forward(sd, x1, x2, H, K=K)
+    pin("tiny_eval", out, ora, report)
+    fx.update(flat_outputs(out, "eval/"))
+    for k, v in ref_loss(out, x1, x2).items():
+        fx["eval/loss_" + k] = np.array(float(v))
+    for k, v in ref_symbols(net, x1, x2, H).items():
+        fx["eval/sym_" + k] = v.numpy().astype(np.int32)
+    # train mode with recorded noise + gradients
+    net.train()
+    log, restore = record_noise(net)
+    torch.manual_seed(11)
+    net.zero_grad()
+    out_t = net(x1, x2, H)
+    restore()
+    assert len(log) == 7, len(log)
+    noise = dict(zip(O.NOISE_KEYS, log))
+    for k, v in noise.items():
+        fx["train/noise_" + k] = v.numpy()
+    loss_t = ref_loss(out_t, x1, x2)
+    loss_t["loss"].backward()
+    fx.update(flat_outputs(out_t, "train/"))
+    for k, v in loss_t.items():
+        fx["train/loss_" + k] = np.array(float(v))
+    ref_grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for n, g in ref_grads.items():
+        fx["train/grad/" + n] = g.numpy()
+    aux = net.aux_loss()
+    net.zero_grad()
+    aux.backward()
+    fx["train/aux_loss"] = np.array(float(aux))
+    for n, p in net.named_parameters():
+        if p.grad is not None and n.endswith("quantiles"):
+            fx["train/auxgrad/" + n] = p.grad.numpy().copy()
+    # oracle in train mode with the same noise, incl. gradients
+    sd_g = {k: (v.clone().requires_grad_(True) if (v.dtype == torch.float32 and k in dict(net.named_parameters())) else v)
+            for k, v in sd.items()}
+    ora_t = O.hsic_forward(sd_g, x1, x2, H, K=K, training=True, noise=noise)
+    pin("tiny_train", out_t, ora_t, report)
+    O.rd_loss(ora_t, x1, x2, LMBDA)["loss"].backward()
+    gd = {}
+    for n, g in ref_grads.items():
+        og = sd_g[n].grad
+        gd[n] = maxdiff(g, og if og is not None else torch.zeros_like(g)) / (float(g.abs().max()) + 1e-30)
+    report["tiny_train_grad_maxrel"] = max(gd.values())
+    report["tiny_train_grad_worst"] = max(gd, key=gd.get)
+    report["tiny_aux_loss"] = abs(float(aux) - float(O.eb_aux_loss(sd, "entropy_bottleneck1") + O.eb_aux_loss(sd, "entropy_bottleneck2")))
+    np.savez_compressed(os.path.join(HERE, "hsic_tiny.npz"), **fx)
+
+    # ------------------------------------------------------------------ small ragged: outputs only
+    N, M, K = 32, 48, 3
+    net, sd = build_ref(N, M, K, seed=2)
+    x1, x2, H = synth.synth_inputs(2, 128, 192, seed=2)
+    net.eval()
+    with torch.no_grad():
+        out = net(x1, x2, H)
+        ora = O.hsic_forward(sd, x1, x2, H, K=K)
+    pin("small_eval", out, ora, report)
+    fs = {"NMK": np.array([N, M, K]), "BHW": np.array([2, 128, 192]), "seed": np.array(2), "lmbda": np.array(LMBDA)}
+    fs.update(flat_outputs(out, "eval/"))
+    for k, v in ref_loss(out, x1, x2).items():
+        fs["eval/loss_" + k] = np.array(float(v))
+    for k, v in ref_symbols(net, x1, x2, H).items():
+        fs["eval/sym_" + k] = v.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "hsic_small.npz"), **fs)
+
+    # ------------------------------------------------------------------ BASELINE config 1 digest
+    N, M, K = 128, 192, 5
+    net, sd = build_ref(N, M, K, seed=3)
+    x1, x2, H = synth.synth_inputs(1, 256, 256, seed=3)
+    net.eval()
+    with torch.no_grad():
+        out = net(x1, x2, H)
+        ora = O.hsic_forward(sd, x1, x2, H, K=K)
+    pin("c1_eval", out, ora, report)
+    dg = {"NMK": [N, M, K], "BHW": [1, 256, 256], "seed": 3, "lmbda": LMBDA, "loss": {}, "sym_sha256": {}, "samples": {}}
+    for k, v in ref_loss(out, x1, x2).items():
+        dg["loss"][k] = float(v)
+    for k, v in ref_symbols(net, x1, x2, H).items():
+        dg["sym_sha256"][k] = hashlib.sha256(v.numpy().astype(np.int32).tobytes()).hexdigest()
+    rs = np.random.RandomState(99)
+    for k, v in flat_outputs(out, "").items():
+        idx = rs.randint(0, v.size, size=64)
+        dg["samples"][k] = {"index": idx.tolist(), "value": [float(t) for t in v.reshape(-1)[idx]],
+                            "absmax": float(np.abs(v).max())}
+    y1 = net.encoder1(x1)[0].detach()
+    fr = (y1 - torch.floor(y1) - 0.5).abs()
+    dg["y1_tie_margin_min"] = float(fr.min())
+    dg["y1_within_1e-4_of_tie"] = int((fr < 1e-4).sum())
+    json.dump(dg, open(os.path.join(HERE, "hsic_c1_digest.json"), "w"), indent=1)
+
+    # ------------------------------------------------------------------ state-dict key tables
+    keys = {"HSIC_128_192_5": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()],
+            "Independent_EN": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in R.Independent_EN().state_dict().items()],
+            "HSIC_parameters_count": len(list(net.parameters())),
+            "HSIC_aux_parameters_count": len(list(net.aux_parameters()))}
+    json.dump(keys, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0)
+    json.dump(report, open(os.path.join(HERE, "pin_report.json"), "w"), indent=1)
+    print(json.dumps(report, indent=1))
+
+
+if __name__ == "__main__":
+    main()

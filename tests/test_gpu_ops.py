@@ -1,0 +1,234 @@
+"""GPU parity tests (-m gpu): every HIP kernel, called through the C ABI (ctypes, masic_amd/ops.py),
+against the CPU oracle on the same seeded inputs.  Tolerance: 1e-4 relative (north_star) on float32
+outputs; integer symbols bit-exact outside the declared tie zone."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hsic_oracle as O
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from masic_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(size=shape) * scale).astype(np.float32))
+
+
+CONV_CASES = [
+    # name,            B, Cin, H,  W,  Cout, k, s, transposed, masked, in_op, act
+    ("g_a_conv1",      2, 3,   64, 96, 128,  5, 2, False, False, 0, 0),
+    ("g_a_conv2",      2, 128, 48, 64, 128,  5, 2, False, False, 0, 0),
+    ("g_a_conv4_rag",  1, 128, 24, 56, 192,  5, 2, False, False, 0, 0),
+    ("h_a0_abs_relu",  2, 192, 16, 24, 128,  5, 1, False, False, 1, 1),
+    ("h_a2_small",     2, 128, 16, 8,  128,  5, 2, False, False, 0, 1),
+    ("h_a4_tiny",      2, 128, 8,  4,  128,  5, 2, False, False, 0, 0),
+    ("h_s_up0",        2, 128, 4,  6,  192,  5, 2, True,  False, 0, 2),
+    ("h_s_up2",        1, 192, 8,  12, 288,  5, 2, True,  False, 0, 2),
+    ("h_s_up4_3x3",    2, 288, 16, 24, 384,  3, 1, False, False, 0, 0),
+    ("ctx_masked_rnd", 2, 192, 16, 24, 384,  5, 1, False, True,  2, 0),
+    ("g_s_conv1",      2, 192, 8,  12, 128,  5, 2, True,  False, 0, 0),
+    ("g_s_conv3",      1, 128, 32, 48, 128,  5, 2, True,  False, 0, 0),
+    ("g_s_conv4_to3",  2, 128, 32, 48, 3,    5, 2, True,  False, 0, 0),
+    ("pre_conv_6to3",  2, 6,   64, 96, 3,    5, 1, False, False, 0, 0),
+    ("after_conv",     2, 6,   64, 96, 3,    5, 1, True,  False, 0, 0),
+    ("gmm_1x1_conv",   2, 768, 16, 24, 960,  1, 1, False, False, 0, 1),
+    ("gmm_1x1_deconv", 2, 768, 16, 24, 1152, 1, 1, True,  False, 0, 2),
+    ("m2w_1to3",       2, 1,   64, 96, 3,    3, 2, False, False, 0, 1),
+    ("m2w_6to6",       2, 6,   16, 24, 6,    3, 2, False, False, 0, 1),
+    ("odd_sizes",      1, 20,  19, 37, 72,   5, 2, False, False, 0, 2),
+    ("cqe_3x3_32",     1, 32,  40, 72, 32,   3, 1, False, False, 0, 2),
+]
+
+
+def _oracle_conv(x, w, b, k, s, transposed, masked, in_op, act):
+    if in_op == 1:
+        x = x.abs()
+    elif in_op == 2:
+        x = torch.round(x)
+    if masked:
+        w = O.masked_weight(w)
+    if transposed:
+        y = F.conv_transpose2d(x, w, b, stride=s, padding=k // 2, output_padding=s - 1)
+    else:
+        y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+    return {0: lambda t: t, 1: F.relu, 2: F.leaky_relu}[act](y)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_variants(case):
+    ops = _ops()
+    name, B, Cin, H, W, Cout, k, s, tr, masked, in_op, act = case
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w = _rand(*wshape, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    ref = _oracle_conv(x, w, b, k, s, tr, masked, in_op, act)
+    desc = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, k // 2, transposed=tr, masked=masked, in_op=in_op, act=act)
+    packed = ops.pack_conv_weight(w.to(DEV), desc)
+    y = ops.conv2d(x.to(DEV), packed, b.to(DEV), desc)
+    assert_close(y, ref, name)
+
+
+def test_conv_views_and_gate():
+    """Input read from a channel slice, output written into a slice of a wider buffer, gated."""
+    ops = _ops()
+    B, H, W = 2, 16, 24
+    xbig = _rand(B, 40, H, W, seed=4)
+    w = _rand(64, 24, 3, 3, seed=5, scale=0.1)
+    b = _rand(64, seed=6, scale=0.1)
+    gate = torch.rand(B, 3, H, W)
+    ref = F.conv2d(xbig[:, 8:32], w, b, padding=1) * gate[:, 1:2]
+    out = torch.full((B, 100, H, W), 7.0, device=DEV)
+    desc = ops.make_conv_desc(B, 24, H, W, 64, 3, 3, 1, 1, in_ctot=40, in_coff=8, out_ctot=100, out_coff=20, gate_ctot=3, gate_c=1)
+    ops.conv2d(xbig.to(DEV), ops.pack_conv_weight(w.to(DEV), desc), b.to(DEV), desc, out=out, gate=gate.to(DEV))
+    assert_close(out[:, 20:84], ref, "view+gate")
+    assert float((out[:, :20] - 7).abs().max()) == 0 and float((out[:, 84:] - 7).abs().max()) == 0
+
+
+def test_conv_channel_softmax_epilogue():
+    ops = _ops()
+    x = _rand(2, 6, 16, 24, seed=7)
+    w = _rand(3, 6, 3, 3, seed=8, scale=0.3)
+    b = _rand(3, seed=9, scale=0.1)
+    ref = F.softmax(F.conv2d(x, w, b, stride=2, padding=1), dim=1)
+    desc = ops.make_conv_desc(2, 6, 16, 24, 3, 3, 3, 2, 1, act=ops.ACT_SOFTMAX_C)
+    y = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV), desc), b.to(DEV), desc)
+    assert_close(y, ref, "softmax_c")
+
+
+@pytest.mark.parametrize("C,H,W,inverse", [(128, 32, 48, False), (128, 16, 24, True), (128, 8, 8, False),
+                                           (3, 64, 96, False), (3, 40, 56, True), (16, 12, 20, False)])
+def test_gdn(C, H, W, inverse):
+    ops = _ops()
+    rs = np.random.RandomState(C + H)
+    x = _rand(2, C, H, W, seed=10, scale=3.0)
+    from masic_amd import synth
+    beta = synth.synth_tensor("g.beta", (C,), rs)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs)
+    gamma[0, 1] = 1e-7      # below the 2^-18 reparametrisation bound
+    beta[0] = 1e-5          # below sqrt(beta_min + 2^-36)
+    ref = O.gdn(x, beta, gamma, inverse=inverse)
+    y = ops.gdn(x.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse)
+    assert_close(y, ref, f"gdn C={C}")
+
+
+def _eb_sd(C, seed):
+    from masic_amd import synth
+    import MASIC
+    from compressai.entropy_models import EntropyBottleneck
+    eb = EntropyBottleneck(C)
+    sd = synth.synth_state_dict({"eb." + k: v for k, v in eb.state_dict().items()}, seed=seed)
+    return sd
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_entropy_bottleneck(training):
+    ops = _ops()
+    C, B, H, W = 24, 3, 4, 6
+    sd = _eb_sd(C, 5)
+    z = _rand(B, C, H, W, seed=11, scale=4.0)
+    noise = torch.from_numpy(np.random.RandomState(12).uniform(-0.5, 0.5, size=(C, 1, H * W * B)).astype(np.float32))
+    ref_hat, ref_lik = O.entropy_bottleneck(z, sd, "eb", training=training, noise=noise)
+    table = ops.eb_param_table([sd[f"eb._matrices.{i}"].to(DEV) for i in range(5)], [sd[f"eb._biases.{i}"].to(DEV) for i in range(5)],
+                               [sd[f"eb._factors.{i}"].to(DEV) for i in range(4)])
+    med = sd["eb.quantiles"][:, 0, 1].contiguous().to(DEV)
+    z_hat, lik = ops.entropy_bottleneck(z.to(DEV), table, med, training=training, noise=noise.to(DEV))
+    assert_close(z_hat, ref_hat, "z_hat", rtol=1e-6)
+    assert_close(lik, ref_lik, "z_lik")
+    # elementwise relative check on the likelihoods (they span orders of magnitude)
+    rel = ((lik.cpu() - ref_lik).abs() / ref_lik).max()
+    assert float(rel) < 1e-3, float(rel)
+    aux = ops.entropy_bottleneck_auxloss(table, sd["eb.quantiles"].to(DEV))
+    assert abs(float(aux) - float(O.eb_aux_loss(sd, "eb"))) <= 1e-5 * float(O.eb_aux_loss(sd, "eb"))
+
+
+@pytest.mark.parametrize("training,logits", [(False, False), (True, False), (False, True)])
+def test_gmm_likelihood(training, logits):
+    ops = _ops()
+    B, M, K, H, W = 2, 24, 5, 6, 10
+    y = _rand(B, M, H, W, seed=13, scale=6.0)
+    sigma = F.relu(_rand(B, K * M, H, W, seed=14, scale=2.0))       # zeros -> 0.11 bound active
+    mu = _rand(B, K * M, H, W, seed=15, scale=5.0)
+    raw = _rand(B, K * M, H, W, seed=16, scale=2.0)
+    y[0, 0, 0, :4] = torch.tensor([40.0, -35.0, 0.5, 2.5])          # far tails -> 1e-9 bound; exact ties of round()
+    wts = O._softmax_over_k(raw, K)
+    noise = torch.from_numpy(np.random.RandomState(17).uniform(-0.5, 0.5, size=y.shape).astype(np.float32))
+    y_hat_ref = O.quantize(y, training, noise)
+    lik_ref = O.gmm_likelihood(y_hat_ref, sigma, mu, wts, K)
+    d = lambda t: t.to(DEV)
+    if logits:
+        y_hat, lik, wout = ops.gmm_likelihood(d(y), d(sigma), d(mu), d(raw), K, training=training, noise=d(noise),
+                                              weights_are_logits=True, want_weights=True)
+        assert_close(wout, wts, "softmax_k in-kernel", rtol=1e-5)
+    else:
+        y_hat, lik = ops.gmm_likelihood(d(y), d(sigma), d(mu), d(wts), K, training=training, noise=d(noise))
+    assert torch.equal(y_hat.cpu(), y_hat_ref), "quantised latents must be identical"
+    assert_close(lik, lik_ref, "gmm lik")
+    big = lik_ref > 1e-6
+    assert float(((lik.cpu() - lik_ref).abs() / lik_ref)[big].max()) < 2e-3
+    assert float(lik.min()) >= 1e-9 * 0.999 and int((lik_ref <= 1e-9).sum()) > 0
+    assert_close(ops.softmax_k(d(raw), K), wts, "softmax_k", rtol=1e-5)
+
+
+def test_quantize_symbols_views():
+    ops = _ops()
+    B, C, H, W = 2, 12, 5, 7
+    x = _rand(B, C, H, W, seed=18, scale=5.0)
+    x[0, 0, 0, :6] = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 1e-8])
+    gate = torch.rand(B, 3, H, W)
+    out = torch.zeros(B, 30, H, W, device=DEV)
+    ops.quantize(x.to(DEV), "dequantize", out=out, out_coff=10, gate=gate.to(DEV), gate_c=2)
+    assert torch.equal(out[:, 10:22].cpu(), torch.round(x) * gate[:, 2:3])
+    med = _rand(C, seed=19)
+    sym = ops.symbols(x.to(DEV), med.to(DEV))
+    assert sym.dtype == torch.int32
+    assert torch.equal(sym.cpu(), torch.round(x - med.view(1, -1, 1, 1)).int())
+    assert torch.equal(ops.symbols(x.to(DEV)).cpu(), torch.round(x).int())
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (40, 56)])
+def test_warp_and_masks(H, W):
+    ops = _ops()
+    from masic_amd import synth
+    x, _, hm = synth.synth_inputs(2, H, W, seed=4)
+    ref = O.warp_perspective(x, hm, (H, W))
+    m = ops.warp_matrix(hm.to(DEV), (H, W), (H, W))
+    assert_close(m, O.warp_matrix(hm, (H, W), (H, W)), "warp matrix", rtol=1e-5)
+    y = ops.warp_perspective(x.to(DEV), m, (H, W))
+    assert_close(y, ref, "warp")
+    mr_ref, ml_ref = O.mask(x, hm)
+    mr = ops.warp_perspective(None, m, (H, W), ones_like=(2, H, W))
+    mb = ops.warp_matrix(hm.to(DEV), (H, W), (H, W), invert_first=True)
+    ml = ops.warp_perspective(mr, mb, (H, W))
+    assert_close(mr, mr_ref, "mask_R")
+    assert_close(ml, ml_ref, "mask_L")
+    assert int(((mr_ref > 0) & (mr_ref < 1)).sum()) > 0     # non-binarised border is exercised
+
+
+def test_reductions_and_small_helpers():
+    ops = _ops()
+    lik = torch.rand(3, 50, 17, 11) * 0.9 + 1e-6
+    a, b = _rand(2, 3, 64, 96, seed=20), _rand(2, 3, 64, 96, seed=21)
+    s = ops.sum_log(lik.to(DEV))
+    assert abs(float(s) - float(torch.log(lik.double()).sum())) <= 1e-5 * abs(float(torch.log(lik.double()).sum()))
+    e = ops.sse(a.to(DEV), b.to(DEV))
+    assert abs(float(e) - float(((a.double() - b.double()) ** 2).sum())) <= 1e-6 * float(((a.double() - b.double()) ** 2).sum())
+    x = _rand(1000, seed=22)
+    m = (torch.rand(1000) > 0.5).float()
+    xd = x.to(DEV)
+    ops.mul_inplace(xd, m.to(DEV))
+    assert torch.equal(xd.cpu(), x * m)
+    assert torch.equal(ops.lower_bound(x.to(DEV), 0.11).cpu(), torch.clamp(x, min=0.11))
+    g = _rand(1000, seed=23)
+    ref = torch.where((x >= 0.11) | (g < 0), g, torch.zeros_like(g))
+    assert torch.equal(ops.lower_bound_bwd(x.to(DEV), g.to(DEV), 0.11).cpu(), ref)
