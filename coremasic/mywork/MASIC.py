@@ -25,6 +25,7 @@ from compressai.entropy_models import (EntropyBottleneck, GaussianConditional, G
 from compressai.layers import GDN, MaskedConv2d, ResidualBlock, conv3x3  # noqa: F401
 from compressai.models.utils import conv, deconv, update_registered_buffers  # noqa: F401
 from masic_amd import ops as _hip
+from masic_amd.homography import warp_matrices as _warp_matrices
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
 
@@ -294,8 +295,7 @@ def mask(im1, H_inv):
     """Validity masks of the left->right->left warp (reference :627-649). As there, the masks are NOT
     binarised (the reference discards its torch.where results) and keep bilinear border values."""
     B, _, h, w = im1.shape
-    m_fwd = _hip.warp_matrix(H_inv.contiguous(), (h, w), (h, w))
-    m_back = _hip.warp_matrix(H_inv.contiguous(), (h, w), (h, w), invert_first=True)
+    m_fwd, m_back = _warp_matrices(H_inv, (h, w), (h, w), want_inverse=True)
     mask_r = _hip.warp_perspective(None, m_fwd, (h, w), ones_like=(B, h, w))
     mask_l = _hip.warp_perspective(mask_r, m_back, (h, w))
     return mask_r, mask_l
@@ -353,6 +353,8 @@ class HSIC(CompressionModel):
         train = self.training
         mode = "noise" if train else "dequantize"
 
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+
         # ---- left view
         y1 = self.encoder1(x1)[0]
         z1 = self._h_a1(y1)
@@ -370,7 +372,6 @@ class HSIC(CompressionModel):
         x1_hat = self.decoder1(y1_hat)[0]
 
         # ---- right view
-        m_fwd = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W))
         pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
         _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
         _hip.copy_view(x2, pair, 3)
@@ -378,7 +379,6 @@ class HSIC(CompressionModel):
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
 
-        m_back = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W), invert_first=True)
         x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
         x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
         gates = self.mask2weights_unit(x1_mask_R)                                    # [B,3,h,w]
@@ -413,7 +413,7 @@ class HSIC(CompressionModel):
         B, _, H, W = x1.shape
         y1 = self.encoder1(x1)[0]
         z1 = self._h_a1(y1)
-        m_fwd = _hip.warp_matrix(h_matrix.contiguous(), (H, W), (H, W))
+        m_fwd, _ = _warp_matrices(h_matrix, (H, W), (H, W))
         x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
         y2 = self.encoder2(x1_warp, x2.contiguous())
         z2 = self._h_a2(y2)

@@ -202,16 +202,20 @@ def test_warp_and_masks(H, W):
     from masic_amd import synth
     x, _, hm = synth.synth_inputs(2, H, W, seed=4)
     ref = O.warp_perspective(x, hm, (H, W))
-    m = ops.warp_matrix(hm.to(DEV), (H, W), (H, W))
-    assert_close(m, O.warp_matrix(hm, (H, W), (H, W)), "warp matrix", rtol=1e-5)
+    from masic_amd.homography import warp_matrices
+    m, mb = warp_matrices(hm.to(DEV), (H, W), (H, W), want_inverse=True)
+    assert torch.equal(m.cpu(), O.warp_matrix(hm, (H, W), (H, W))), "host float32 chain must equal the oracle's bitwise"
     y = ops.warp_perspective(x.to(DEV), m, (H, W))
     assert_close(y, ref, "warp")
     mr_ref, ml_ref = O.mask(x, hm)
     mr = ops.warp_perspective(None, m, (H, W), ones_like=(2, H, W))
-    mb = ops.warp_matrix(hm.to(DEV), (H, W), (H, W), invert_first=True)
     ml = ops.warp_perspective(mr, mb, (H, W))
     assert_close(mr, mr_ref, "mask_R")
     assert_close(ml, ml_ref, "mask_L")
+    # float64 device kernel: agrees with the float32 chain to the conditioning of that chain
+    md = ops.warp_matrix(hm.to(DEV), (H, W), (H, W))
+    assert_close(md, m, "device f64 warp matrix", rtol=1e-5)
+    assert_close(ops.warp_perspective(x.to(DEV), md, (H, W)), ref, "warp (device matrix)", rtol=1e-3)
     assert int(((mr_ref > 0) & (mr_ref < 1)).sum()) > 0     # non-binarised border is exercised
 
 
