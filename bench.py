@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s (enc+dec = one HSIC.forward) of the MI355X-native MASIC codec.
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch 8 --height 512 --width 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one HSIC(N=128,M=192,K=5) eval forward over a batch of synthetic stereo pairs already resident
+in HBM (BASELINE.json configs[1]: 8 x 512x512 per GPU; weak scaling: every rank runs its own batch, no
+data-path collective).  Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- the dominant kernel symbol (by device time): algorithmic FLOPs per launch / average launch
+                  duration, both measured with HIP events on the launch stream inside the timed region
+  cpu_baseline -- oracle/ (CPU restatement of the reference, kind "port") timed on this box's host cores on a
+                  bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "coremasic", "mywork")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(N, M, K, H, W, seed):
+    """Oracle (CPU float32 restatement pinned to the reference) on the host cores: 1 pair, 1 warm-up + 3 runs."""
+    import MASIC
+    from masic_amd import synth
+    from oracle import hsic_oracle as O
+    # the GPU box gives one GPU's job a 16-core share of its host CPUs; oversubscribing torch's pool
+    # beyond that share (os.cpu_count() reports the whole machine) makes the CPU path slower, not faster
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=seed)
+    x1, x2, hm = synth.synth_inputs(1, H, W, seed=seed)
+    with torch.no_grad():
+        O.hsic_forward(sd, x1, x2, hm, K=K)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.hsic_forward(sd, x1, x2, hm, K=K)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": 1.0 / ts[1], "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/hsic_oracle.py eval forward, 1x3x{H}x{W} pair, median of 3 runs after 1 warm-up, torch CPU float32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    import MASIC
+    from masic_amd import ops, synth
+
+    N, M, K = 128, 192, 5
+    B, H, W = args.batch, args.height, args.width
+    net = MASIC.HSIC(N, M, K)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100))
+    net = net.to(dev).eval()
+    x1, x2, hm = (t.to(dev) for t in synth.synth_inputs(B, H, W, seed=100 + rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x1, x2, hm)
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(x1, x2, hm)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant conv kernel symbol by device time (HIP events on the launch stream, inside the timed region)
+    agg = timer.summary()
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    a = agg[dom]
+    avg_ms = a["ms"] / a["launches"]
+    tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,
+                "flops_per_launch": a["flops"] / a["launches"],
+                "share_of_step_time": a["ms"] / (elapsed * 1e3),
+                "all_conv_kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in agg.items()}}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roofline["traffic"] = json.load(open(pmc)).get(dom)
+        except Exception:
+            pass
+
+    if rank == 0:
+        line = {
+            "metric": "stereo pairs/sec (enc+dec)", "value": world * B * args.steps / elapsed, "unit": "stereo pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HSIC(N=128,M=192,K=5) eval forward (enc+dec both views), {B}x3x{H}x{W} stereo pairs per GPU "
+                                   "(BASELINE.json configs[1] shape), inputs resident in HBM",
+                       "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world} (pairs sharded, no data-path collective)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, M, K, H, W, seed=100)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

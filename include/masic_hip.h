@@ -71,6 +71,11 @@ typedef struct {
  * version into the K-major, Cout-contiguous order the implicit-GEMM kernel stages into LDS) */
 size_t masic_conv_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
+/* which kernel (and how many launches of it) masic_conv2d_fwd issues for this layer -- used by
+ * bench.py to attribute HIP-event timings to kernel symbols:
+ *   variant 0/1: conv_direct_f32<3>/<8>; 2/3/4: conv_igemm_f32<1>/<2>/<4>; launches = phases (1, or
+ *   stride^2 for transposed convs). Returns variant, writes *launches if non-NULL; <0 on bad desc. */
+int masic_conv_variant(const masic_conv_desc_t* d, int* launches);
 /* y = act(conv(in_op(x), w) + bias) [* gate].  bias may be NULL. */
 int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
                      float* y, const masic_conv_desc_t* d, void* stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "masic_version": (c_int, []),
     "masic_last_error": (ctypes.c_char_p, []),
     "masic_conv_packed_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "masic_conv_variant": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "masic_conv_pack_weight": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),

@@ -360,6 +360,17 @@ extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
     return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
 }
 
+extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const ConvCfg c = choose_cfg(*d, g, np);
+    if (launches) *launches = np;
+    if (c.direct) return d->Cout <= 3 ? 0 : 1;
+    return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
+}
+
 extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;

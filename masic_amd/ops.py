@@ -61,7 +61,62 @@ def pack_conv_weight(weight, desc):
     return packed
 
 
+class KernelTimer:
+    """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
+    keyed by kernel symbol; used by bench.py for the live roofline figure."""
+    VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1>", 3: "conv_igemm_f32<2>",
+                4: "conv_igemm_f32<4>"}
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for variant, launches, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(self.VARIANTS[variant], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += launches
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def conv_algorithmic_work(desc):
+    """(flops, bytes) of one conv layer: dense MACs incl. masked taps; activations in + out + weights."""
+    taps = desc.KH * desc.KW
+    if desc.transposed:
+        macs = desc.B * desc.Cin * desc.Cout * taps * desc.Hi * desc.Wi
+    else:
+        macs = desc.B * desc.Cout * desc.Cin * taps * desc.Ho * desc.Wo
+    nbytes = 4 * (desc.B * desc.Cin * desc.Hi * desc.Wi + desc.B * desc.Cout * desc.Ho * desc.Wo + desc.Cin * desc.Cout * taps)
+    return 2.0 * macs, float(nbytes)
+
+
 def conv2d(x, packed, bias, desc, out=None, gate=None):
+    if _timer is not None:
+        n = ctypes.c_int(0)
+        variant = lib.masic_conv_variant(ctypes.byref(desc), ctypes.byref(n))
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = _conv2d(x, packed, bias, desc, out, gate)
+        e1.record()
+        flops, nbytes = conv_algorithmic_work(desc)
+        _timer.records.append((variant, n.value, flops, nbytes, e0, e1))
+        return y
+    return _conv2d(x, packed, bias, desc, out, gate)
+
+
+def _conv2d(x, packed, bias, desc, out=None, gate=None):
     _dev(x, "conv input")
     if x.dim() != 4 or x.shape[0] != desc.B or x.shape[1] != desc.in_ctot or x.shape[2] != desc.Hi or x.shape[3] != desc.Wi:
         raise RuntimeError(f"masic_amd.conv2d: input {tuple(x.shape)} does not match descriptor "
