@@ -76,6 +76,8 @@ int build_geoms(const masic_conv_desc_t& d, ConvGeom* g) {
 struct ConvCfg {
     int direct;         // 1: direct kernel (Cout <= 8)
     int wn;             // pixel sub-tiles (of 32) per wave: 4 -> 64x256 block tile, 1 -> 64x64
+    int buf_sz;         // floats per LDS buffer: patch [KC][PSZ] + weights [round4(taps*KC)][64]
+    int vec4;           // 1x1 layers: the patch is staged with 16-byte DMA pieces
     int KC, KClog;      // input channels per LDS chunk
     int TW, TWlog, SR, TH;
     int Cin_pad, Cout_pad;
@@ -111,17 +113,29 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * mtiles * d.B * nphase;
     };
     c.wn = nblocks(4) >= 768 ? 4 : (nblocks(2) >= 512 ? 2 : 1);
+    // the per-channel patch must fit 24 DMA wave-instructions (MAXE = 6 per wave)
+    while (c.wn > 1 && ((c.SR * 2 * c.wn - 1) * is + span_h) * ((c.TW - 1) * is + span_w) > 24 * 64) c.wn >>= 1;
     c.TH = c.SR * 2 * c.wn;
     c.PH = (c.TH - 1) * is + span_h;
     c.PW = (c.TW - 1) * is + span_w;
-    c.PWp = c.PW | 1;                                   // odd pitch: fewer LDS bank conflicts across rows
-    c.PSZ = round_up(c.PH * c.PWp, 4);
-    const int cin4 = round_up(d.Cin, 4);
+    c.PWp = c.PW;                                       // LDS-DMA writes 64 consecutive floats: no row padding
+    c.PSZ = round_up(c.PH * c.PW, 64);                  // whole wave-instructions per channel
+    const int groups = c.PSZ / 64;                      // DMA wave-instructions per channel
+    const int epw = ceil_div(groups, 4);                // ... per wave
+    const int cin2 = round_up(d.Cin, 2);
+    // 1x1 layers (the GMM heads): rows are contiguous and 16-byte aligned -> dwordx4 DMA, 4x fewer instructions
+    c.vec4 = (max_taps == 1 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Wi % 4 == 0 && d.Cin >= 4) ? 1 : 0;
+    // two LDS buffers (the next chunk lands by DMA while this one is contracted); keep 2 blocks per CU
     int KC = 32;
-    while (KC > 4 && ((size_t)KC * (c.PSZ + max_taps * 64) * 4 > 48 * 1024 || KC > cin4)) KC >>= 1;
+    if (c.vec4) {
+        while (KC > 4 && (KC * c.PSZ > 8192 || KC > round_up(d.Cin, 4))) KC >>= 1;
+    } else {
+        while (KC > 2 && ((size_t)2 * KC * (c.PSZ + max_taps * 64) * 4 > 80 * 1024 || KC > cin2 || KC * epw > 48)) KC >>= 1;
+    }
     c.KC = KC; c.KClog = ilog2(KC);
     c.Cin_pad = round_up(d.Cin, KC);
-    c.lds_bytes = (size_t)KC * (c.PSZ + max_taps * 64) * 4;
+    c.buf_sz = KC * c.PSZ + round_up(max_taps * KC, 4) * 64;
+    c.lds_bytes = (size_t)2 * c.buf_sz * 4;
     return c;
 }
 
@@ -158,16 +172,32 @@ struct IgemmArgs {
     int Cout, Ho, Wo, out_ctot, out_coff;
     int Cin_pad, Cout_pad, KC, KClog;
     int TW, TWlog, SR, TH, tiles_w;
-    int PH, PW, PWp, PSZ;
+    int PH, PW, PWp, PSZ, buf_sz, vec4;
     int in_op, act, gate_ctot, gate_c;
     ConvGeom g;
 };
 
-template <int WN>
+__device__ __attribute__((aligned(16))) float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+// global -> LDS DMA (no VGPR round trip): per-lane source address, LDS destination = wave-uniform base + lane*size
+__device__ __forceinline__ void dma4(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int MAXE = 6;   // DMA wave-instructions per wave per channel plane (patch <= 1536 floats)
+constexpr int MAXQ = 8;   // 16-byte-DMA wave-instructions per wave per chunk (1x1 layers: KC*PSZ <= 8192 floats)
+
+template <int WN, int INOP>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* patch = lds;                        // [KC][PH][PWp] (PSZ floats per channel)
-    float* wts = lds + a.KC * a.PSZ;           // [ntaps][KC][64]
+    // two buffers, each: patch [KC][PSZ] (rows of PW floats, flattened) | weights [ntaps][KC][64]
+    const int wts_off = a.KC * a.PSZ;
+    const int buf_sz = a.buf_sz;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -179,12 +209,78 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
     const int ih0 = r0 * a.g.is + a.g.dh_min, iw0 = c0 * a.g.is + a.g.dw_min;
 
-    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
+    // ---- per-lane source offsets of this wave's DMA groups within one input channel plane (-1: zero fill)
+    const int groups = a.PSZ >> 6;
+    int goff[MAXE];
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int e = (wave + 4 * i) * 64 + lane;
+        const int pr = e / a.PW, pc = e - pr * a.PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        goff[i] = ok ? ih * a.Wi + iw : -1;
+    }
+    // ---- 1x1 layers: 16-byte pieces over the whole [KC][PSZ] chunk; per lane (channel-in-chunk, offset)
+    const int nq = (a.KC * a.PSZ) >> 8;
+    int goff4[MAXQ], gci4[MAXQ];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int off = (wave + 4 * i) * 256 + lane * 4;
+        const int ci = off / a.PSZ, rem = off - ci * a.PSZ;
+        const int pr = rem / a.PW, pc = rem - pr * a.PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw + 3 < a.Wi;
+        gci4[i] = ci;
+        goff4[i] = ok ? ci * (a.Hi * a.Wi) + ih * a.Wi + iw : -1;
+    }
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    // weights: 16-byte pieces, 16 lanes per (tap,ci) row of 64 co -> 4 rows per wave-instruction
+    const int wrows = a.g.ntaps * a.KC;                    // multiple of 2; rows beyond wrows are skipped per lane
+    const int wq = lane & 15, wr = lane >> 4;
+
+    auto issue = [&](int cc, float* buf) {
+        if (a.vec4) {
+            const float* xc = xb + (size_t)cc * plane;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int q = wave + 4 * i;
+                if (q < nq) {
+                    const float* src = (goff4[i] >= 0 && cc + gci4[i] < a.Cin) ? xc + goff4[i] : g_zero_word;
+                    dma16(src, buf + q * 256);
+                }
+            }
+        } else {
+            for (int ci = 0; ci < a.KC; ++ci) {
+                const bool cok = (cc + ci) < a.Cin;
+                const float* xc = xb + (size_t)(cc + ci) * plane;
+                float* dst = buf + ci * a.PSZ;
+#pragma unroll
+                for (int i = 0; i < MAXE; ++i) {
+                    const int g = wave + 4 * i;
+                    if (g < groups) {
+                        const float* src = (cok && goff[i] >= 0) ? xc + goff[i] : g_zero_word;
+                        dma4(src, dst + g * 64);
+                    }
+                }
+            }
+        }
+        float* wdst = buf + wts_off;
+        for (int r4 = wave * 4; r4 < wrows; r4 += 16) {       // this wave-instruction covers rows r4..r4+3
+            int row = r4 + wr;
+            row = row < wrows ? row : wrows - 1;                // tail lanes duplicate the last row into the (unused) pad rows
+            const int t = row >> a.KClog, ci = row & (a.KC - 1);
+            const float* src = a.wp + ((size_t)(a.g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0 + wq * 4;
+            dma16(src, wdst + r4 * 64);
+        }
+    };
+
     int pixoff[WN];
+    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int r = (wn * WN + n) * a.SR + jr;
-        pixoff[n] = (r * a.g.is) * a.PWp + jc * a.g.is;
+        pixoff[n] = (r * a.g.is) * a.PW + jc * a.g.is;
     }
     f32x16 acc[WN];
 #pragma unroll
@@ -192,56 +288,59 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
 
-    const size_t plane = (size_t)a.Hi * a.Wi;
-    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
-
-    for (int cc = 0; cc < a.Cin_pad; cc += a.KC) {
-        // ---- stage the input patch: coalesced NCHW row segments -> LDS [ci][row][col]
-        for (int ci = 0; ci < a.KC; ++ci) {
-            const int cg = cc + ci;
-            const float* xc = xb + (size_t)cg * plane;
-            float* pc = patch + ci * a.PSZ;
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int ih = ih0 + pr;
-                const bool rowok = (cg < a.Cin) && (ih >= 0) && (ih < a.Hi);
-                const float* src = xc + (size_t)ih * a.Wi;
-                float* dst = pc + pr * a.PWp;
-                for (int pcx = lane; pcx < a.PW; pcx += 64) {
-                    const int iw = iw0 + pcx;
-                    float v = 0.0f;
-                    if (rowok && iw >= 0 && iw < a.Wi) v = apply_inop(src[iw], a.in_op);
-                    dst[pcx] = v;
-                }
-            }
-        }
-        // ---- stage the packed weights [tap][ci][64 co] (straight 16-byte copies)
-        {
-            const int nvec = a.g.ntaps * a.KC * 16;
-            for (int idx = tid; idx < nvec; idx += 256) {
-                const int row = idx >> 4, q = idx & 15;
-                const int t = row >> a.KClog, ci = row & (a.KC - 1);
-                const float4* src = reinterpret_cast<const float4*>(
-                    a.wp + ((size_t)(a.g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0) + q;
-                reinterpret_cast<float4*>(wts)[idx] = *src;
-            }
-        }
-        __syncthreads();
-        // ---- contraction over (tap, ci) for this chunk
-        for (int t = 0; t < a.g.ntaps; ++t) {
-            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
-            const int toff = (a.g.dh0 + ta * a.g.dsh - a.g.dh_min) * a.PWp + (a.g.dw0 + tb * a.g.dsw - a.g.dw_min);
-            const float* wrow = wts + (t * a.KC + h) * 64 + wm * 32 + j;
-            const float* prow = patch + h * a.PSZ + toff;
-            for (int kk = 0; kk < a.KC; kk += 2) {
-                const float av = wrow[kk * 64];
+    const int lane_w = h * 64 + wm * 32 + j;
+    int lane_p[WN];
 #pragma unroll
-                for (int n = 0; n < WN; ++n) {
-                    const float bv = prow[kk * a.PSZ + pixoff[n]];
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
-                }
-            }
-        }
+    for (int n = 0; n < WN; ++n) lane_p[n] = h * a.PSZ + pixoff[n];
+    const int kh = a.KC >> 1, khlog = a.KClog - 1;
+    const int nsteps = a.g.ntaps << khlog;
+    const int tap0_off = (a.g.dh0 - a.g.dh_min) * a.PW + (a.g.dw0 - a.g.dw_min);
+    const int chan_span = 2 * a.PSZ * (kh - 1);                       // back to channel pair 0 of the chunk
+    const int row_step = a.g.dsh * a.PW - a.g.dsw * (a.g.ntw - 1);   // first tap of the next kernel row
+
+    const int nchunks = a.Cin_pad >> a.KClog;
+    issue(0, lds);
+    for (int c = 0; c < nchunks; ++c) {
+        float* cur = lds + (c & 1) * buf_sz;
+        // own DMAs landed (vmcnt(0)) + everyone finished reading the other buffer -> barrier
         __syncthreads();
+        if (c + 1 < nchunks) issue((c + 1) << a.KClog, lds + ((c + 1) & 1) * buf_sz);
+        const float* patch = cur;
+        const float* wts = cur + wts_off;
+        // k-steps s = (tap, channel pair) of this chunk, software-pipelined: the LDS reads of step s+1 are
+        // issued before the MFMAs of step s
+        // offsets advance incrementally (a handful of scalar ops per step): weights are contiguous in step
+        // order; the patch offset moves by two channels inside a tap, else to the next tap (row-major taps)
+        int sw = 0, sp = tap0_off, kk2 = 0, tb = 0;
+        float av = wts[lane_w];
+        float bv[WN];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) bv[n] = patch[sp + lane_p[n]];
+        for (int st = 0; st < nsteps; ++st) {
+            float av1 = 0.0f, bv1[WN];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv1[n] = 0.0f;
+            if (st + 1 < nsteps) {
+                sw += 128;
+                if (++kk2 < kh) {
+                    sp += 2 * a.PSZ;
+                } else {
+                    kk2 = 0;
+                    sp -= chan_span;
+                    if (++tb < a.g.ntw) sp += a.g.dsw;
+                    else { tb = 0; sp += row_step; }
+                }
+                av1 = wts[sw + lane_w];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) bv1[n] = patch[sp + lane_p[n]];
+            }
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, apply_inop(bv[n], INOP), acc[n], 0, 0, 0);
+            av = av1;
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv[n] = bv1[n];
+        }
     }
 
     // ---- epilogue: bias, activation, gate, NCHW store (32 consecutive pixels per half-wave)
@@ -329,7 +428,7 @@ int check_desc(const masic_conv_desc_t* d) {
     MASIC_REQUIRE(d != nullptr, MASIC_ERR_ARG, "conv: null descriptor");
     MASIC_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Hi > 0 && d->Wi > 0, MASIC_ERR_SHAPE,
                   "conv: non-positive dimension");
-    MASIC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7, MASIC_ERR_UNSUPPORTED, "conv: kernel size %dx%d", d->KH, d->KW);
+    MASIC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 5 && d->KW <= 5, MASIC_ERR_UNSUPPORTED, "conv: kernel size %dx%d", d->KH, d->KW);
     MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv: stride %d", d->stride);
     MASIC_REQUIRE(d->in_coff >= 0 && d->in_coff + d->Cin <= d->in_ctot, MASIC_ERR_SHAPE, "conv: input channel view out of range");
     MASIC_REQUIRE(d->out_coff >= 0 && d->out_coff + d->Cout <= d->out_ctot, MASIC_ERR_SHAPE, "conv: output channel view out of range");
@@ -414,12 +513,21 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
                     d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                     c.Cin_pad, c.Cout_pad, c.KC, c.KClog,
                     c.TW, c.TWlog, c.SR, c.TH, ceil_div(g[p].Wp, c.TW),
-                    c.PH, c.PW, c.PWp, c.PSZ,
+                    c.PH, c.PW, c.PWp, c.PSZ, c.buf_sz, c.vec4,
                     d->in_op, d->act, d->gate_ctot, d->gate_c, g[p]};
         dim3 grid(ceil_div(g[p].Wp, c.TW) * ceil_div(g[p].Hp, c.TH), c.Cout_pad / 64, d->B);
-        if (c.wn == 4) hipLaunchKernelGGL(conv_igemm_f32<4>, grid, dim3(256), c.lds_bytes, st, a);
-        else if (c.wn == 2) hipLaunchKernelGGL(conv_igemm_f32<2>, grid, dim3(256), c.lds_bytes, st, a);
-        else hipLaunchKernelGGL(conv_igemm_f32<1>, grid, dim3(256), c.lds_bytes, st, a);
+#define IGEMM_LAUNCH(WNV, OPV) hipLaunchKernelGGL((conv_igemm_f32<WNV, OPV>), grid, dim3(256), c.lds_bytes, st, a)
+#define IGEMM_BY_OP(WNV)                                             \
+    do {                                                             \
+        if (d->in_op == MASIC_INOP_ABS) IGEMM_LAUNCH(WNV, MASIC_INOP_ABS);         \
+        else if (d->in_op == MASIC_INOP_ROUND) IGEMM_LAUNCH(WNV, MASIC_INOP_ROUND); \
+        else IGEMM_LAUNCH(WNV, MASIC_INOP_NONE);                     \
+    } while (0)
+        if (c.wn == 4) IGEMM_BY_OP(4);
+        else if (c.wn == 2) IGEMM_BY_OP(2);
+        else IGEMM_BY_OP(1);
+#undef IGEMM_BY_OP
+#undef IGEMM_LAUNCH
     }
     return masic_launch_status("conv2d_fwd");
 }
