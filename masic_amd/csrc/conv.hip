@@ -37,45 +37,70 @@ struct ConvGeom {
     int dh_min, dw_min;       // smallest tap offsets (patch origin)
 };
 
+// What is needed to derive a phase's geometry; small enough to ride in the kernel arguments so that one launch
+// covers every phase (blockIdx.x % nphase) and the phases of a tile run next to each other (their interleaved
+// output columns merge in L2).
+struct GeomParams {
+    int transposed, masked, KH, KW, stride, pad, Ho, Wo;
+};
+
+__host__ __device__ inline void phase_axis(int p, int K, int s, int pad, int& k0, int& nt, int& d0) {
+    k0 = (p + pad) % s;              // first kernel index of this output parity
+    nt = (K - k0 + s - 1) / s;       // taps along this axis
+    d0 = (p + pad - k0) / s;         // input offset of tap 0 (then -1 per tap)
+}
+
+__host__ __device__ inline ConvGeom make_geom(const GeomParams& q, int phase) {
+    ConvGeom g;
+    if (!q.transposed) {
+        g.nth = q.KH; g.ntw = q.KW; g.ntaps = q.KH * q.KW;
+        if (q.masked) {                                   // layers.py:69-75, mask type 'A'
+            g.ntaps = (q.KH / 2) * q.KW + q.KW / 2;
+            g.nth = q.KH / 2 + 1;
+        }
+        g.dh0 = -q.pad; g.dsh = 1; g.dw0 = -q.pad; g.dsw = 1;
+        g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1;
+        g.is = q.stride; g.os = 1; g.oph = 0; g.opw = 0;
+        g.Hp = q.Ho; g.Wp = q.Wo; g.tap_base = 0;
+        g.dh_min = -q.pad; g.dw_min = -q.pad;
+        return g;
+    }
+    const int s = q.stride;
+    const int ph = phase / s, pw = phase - ph * s;
+    phase_axis(ph, q.KH, s, q.pad, g.kh0, g.nth, g.dh0);
+    phase_axis(pw, q.KW, s, q.pad, g.kw0, g.ntw, g.dw0);
+    g.khs = s; g.kws = s; g.dsh = -1; g.dsw = -1;
+    g.ntaps = g.nth * g.ntw;
+    g.is = 1; g.os = s; g.oph = ph; g.opw = pw;
+    g.Hp = (q.Ho - ph + s - 1) / s; g.Wp = (q.Wo - pw + s - 1) / s;
+    g.dh_min = g.dh0 - (g.nth - 1); g.dw_min = g.dw0 - (g.ntw - 1);
+    int base = 0;
+    for (int p = 0; p < phase; ++p) {
+        int k0, nh, nw, d0;
+        phase_axis(p / s, q.KH, s, q.pad, k0, nh, d0);
+        phase_axis(p % s, q.KW, s, q.pad, k0, nw, d0);
+        base += nh * nw;
+    }
+    g.tap_base = base;
+    return g;
+}
+
+GeomParams geom_params(const masic_conv_desc_t& d) {
+    return GeomParams{d.transposed, d.masked, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo};
+}
+
 // Phases of a layer (host side). Returns the number of phases (1 for Conv2d, s*s for transposed).
 int build_geoms(const masic_conv_desc_t& d, ConvGeom* g) {
-    int n = 0, tap_base = 0;
-    if (!d.transposed) {
-        ConvGeom& q = g[n++];
-        q.nth = d.KH; q.ntw = d.KW; q.ntaps = d.KH * d.KW;
-        if (d.masked) {                                   // layers.py:69-75, mask type 'A'
-            q.ntaps = (d.KH / 2) * d.KW + d.KW / 2;
-            q.nth = d.KH / 2 + 1;
-        }
-        q.dh0 = -d.pad; q.dsh = 1; q.dw0 = -d.pad; q.dsw = 1;
-        q.kh0 = 0; q.khs = 1; q.kw0 = 0; q.kws = 1;
-        q.is = d.stride; q.os = 1; q.oph = 0; q.opw = 0;
-        q.Hp = d.Ho; q.Wp = d.Wo; q.tap_base = 0;
-        q.dh_min = -d.pad; q.dw_min = -d.pad;
-        return 1;
-    }
-    const int s = d.stride;
-    for (int ph = 0; ph < s; ++ph)
-        for (int pw = 0; pw < s; ++pw) {
-            ConvGeom& q = g[n++];
-            q.kh0 = (ph + d.pad) % s; q.khs = s;
-            q.kw0 = (pw + d.pad) % s; q.kws = s;
-            q.nth = (d.KH - q.kh0 + s - 1) / s;
-            q.ntw = (d.KW - q.kw0 + s - 1) / s;
-            q.ntaps = q.nth * q.ntw;
-            q.dh0 = (ph + d.pad - q.kh0) / s; q.dsh = -1;
-            q.dw0 = (pw + d.pad - q.kw0) / s; q.dsw = -1;
-            q.is = 1; q.os = s; q.oph = ph; q.opw = pw;
-            q.Hp = (d.Ho - ph + s - 1) / s; q.Wp = (d.Wo - pw + s - 1) / s;
-            q.tap_base = tap_base; tap_base += q.ntaps;
-            q.dh_min = q.dh0 - (q.nth - 1); q.dw_min = q.dw0 - (q.ntw - 1);
-        }
+    const GeomParams q = geom_params(d);
+    const int n = d.transposed ? d.stride * d.stride : 1;
+    for (int p = 0; p < n; ++p) g[p] = make_geom(q, p);
     return n;
 }
 
 struct ConvCfg {
-    int direct;         // 1: direct kernel (Cout <= 8)
-    int wn;             // pixel sub-tiles (of 32) per wave: 4 -> 64x256 block tile, 1 -> 64x64
+    int direct;         // 1: direct kernel (Cout <= 8); 2: LDS-tiled 5x5 stride-2 transposed conv to <= 4 channels
+    int wm;             // 32-channel sub-tiles per wave: block covers BM = 64*wm output channels
+    int wn;             // pixel sub-tiles (of 32) per wave: 4 -> BM x 256 block tile, 1 -> BM x 64
     int buf_sz;         // floats per LDS buffer: patch [KC][PSZ] + weights [round4(taps*KC)][64]
     int vec4;           // 1x1 layers: the patch is staged with 16-byte DMA pieces
     int KC, KClog;      // input channels per LDS chunk
@@ -90,6 +115,11 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     ConvCfg c{};
+    if (d.Cout <= 4 && d.transposed && d.stride == 2 && d.KH == 5 && d.KW == 5 && d.pad == 2 && d.Cin >= 16 &&
+        d.in_op == MASIC_INOP_NONE) {
+        c.direct = 2; c.Cin_pad = round_up(d.Cin, 8); c.Cout_pad = 4;      // packed [ci][5][5][4]
+        return c;
+    }
     if (d.Cout <= 8) {
         c.direct = 1; c.Cin_pad = d.Cin; c.Cout_pad = 8;
         return c;
@@ -105,14 +135,16 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
     c.TWlog = ilog2(c.TW);
     c.SR = 32 / c.TW;
-    c.Cout_pad = round_up(d.Cout, 64);
-    const int mtiles = c.Cout_pad / 64;
-    // large tile only when it still fills the 256 CUs a few times over
-    auto nblocks = [&](int wn) {
+    // 128-channel blocks (2x4 MFMA tiles per wave: 0.75 LDS reads per MFMA) when Cout is a multiple of 128 and the
+    // layer is big enough to still fill the chip; 64-channel blocks otherwise
+    auto nblocks = [&](int wm, int wn) {
         int TH = c.SR * 2 * wn;
-        return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * mtiles * d.B * nphase;
+        return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * (round_up(d.Cout, 64 * wm) / (64 * wm)) * d.B * nphase;
     };
-    c.wn = nblocks(4) >= 768 ? 4 : (nblocks(2) >= 512 ? 2 : 1);
+    c.wm = (d.Cout % 128 == 0 && nblocks(2, 4) >= 512) ? 2 : 1;
+    c.wn = c.wm == 2 ? 4 : (nblocks(1, 4) >= 768 ? 4 : (nblocks(1, 2) >= 512 ? 2 : 1));
+    const int BM = 64 * c.wm;
+    c.Cout_pad = round_up(d.Cout, BM);
     // the per-channel patch must fit 24 DMA wave-instructions (MAXE = 6 per wave)
     while (c.wn > 1 && ((c.SR * 2 * c.wn - 1) * is + span_h) * ((c.TW - 1) * is + span_w) > 24 * 64) c.wn >>= 1;
     c.TH = c.SR * 2 * c.wn;
@@ -124,17 +156,18 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     const int epw = ceil_div(groups, 4);                // ... per wave
     const int cin2 = round_up(d.Cin, 2);
     // 1x1 layers (the GMM heads): rows are contiguous and 16-byte aligned -> dwordx4 DMA, 4x fewer instructions
-    c.vec4 = (max_taps == 1 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Wi % 4 == 0 && d.Cin >= 4) ? 1 : 0;
+    c.vec4 = (max_taps == 1 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Wi % 4 == 0 && d.Cin >= 4 &&
+              d.in_op == MASIC_INOP_NONE) ? 1 : 0;
     // two LDS buffers (the next chunk lands by DMA while this one is contracted); keep 2 blocks per CU
     int KC = 32;
     if (c.vec4) {
         while (KC > 4 && (KC * c.PSZ > 8192 || KC > round_up(d.Cin, 4))) KC >>= 1;
     } else {
-        while (KC > 2 && ((size_t)2 * KC * (c.PSZ + max_taps * 64) * 4 > 80 * 1024 || KC > cin2 || KC * epw > 48)) KC >>= 1;
+        while (KC > 2 && ((size_t)2 * KC * (c.PSZ + max_taps * BM) * 4 > 80 * 1024 || KC > cin2 || KC * epw > 48)) KC >>= 1;
     }
     c.KC = KC; c.KClog = ilog2(KC);
     c.Cin_pad = round_up(d.Cin, KC);
-    c.buf_sz = KC * c.PSZ + round_up(max_taps * KC, 4) * 64;
+    c.buf_sz = KC * c.PSZ + round_up(max_taps * KC, 256 / BM) * BM;
     c.lds_bytes = (size_t)2 * c.buf_sz * 4;
     return c;
 }
@@ -174,7 +207,8 @@ struct IgemmArgs {
     int TW, TWlog, SR, TH, tiles_w;
     int PH, PW, PWp, PSZ, buf_sz, vec4;
     int in_op, act, gate_ctot, gate_c;
-    ConvGeom g;
+    GeomParams q;
+    int nphase;
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -192,10 +226,11 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
 constexpr int MAXE = 6;   // DMA wave-instructions per wave per channel plane (patch <= 1536 floats)
 constexpr int MAXQ = 8;   // 16-byte-DMA wave-instructions per wave per chunk (1x1 layers: KC*PSZ <= 8192 floats)
 
-template <int WN, int INOP>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
+template <int WM, int WN, int INOP, bool VEC4>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
+    constexpr int BM = 64 * WM;                 // output channels per block: 2 waves x WM x 32
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // two buffers, each: patch [KC][PSZ] (rows of PW floats, flattened) | weights [ntaps][KC][64]
+    // two buffers, each: patch [KC][PSZ] (rows of PW floats, flattened) | weights [ntaps][KC][BM]
     const int wts_off = a.KC * a.PSZ;
     const int buf_sz = a.buf_sz;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -203,50 +238,54 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
     const int wm = wave & 1, wn = wave >> 1;
     const int j = lane & 31, h = lane >> 5;
 
-    const int tw_i = blockIdx.x % a.tiles_w, th_i = blockIdx.x / a.tiles_w;
-    const int m0 = blockIdx.y * 64;
+    const int phase = blockIdx.x % a.nphase, tile = blockIdx.x / a.nphase;
+    const ConvGeom g = make_geom(a.q, phase);
+    const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
+    const int m0 = blockIdx.y * BM;
     const int b = blockIdx.z;
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
-    const int ih0 = r0 * a.g.is + a.g.dh_min, iw0 = c0 * a.g.is + a.g.dw_min;
+    const int ih0 = r0 * g.is + g.dh_min, iw0 = c0 * g.is + g.dw_min;
 
-    // ---- per-lane source offsets of this wave's DMA groups within one input channel plane (-1: zero fill)
+    // ---- per-lane DMA source offsets, fixed for the whole K loop (-1: zero fill).
+    //  dword mode : this wave's groups of 64 consecutive patch floats within one input channel plane
+    //  VEC4 (1x1) : 16-byte pieces over the whole [KC][PSZ] chunk; per lane (channel-in-chunk, offset)
+    constexpr int NOFF = VEC4 ? MAXQ : MAXE;
     const int groups = a.PSZ >> 6;
-    int goff[MAXE];
-#pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-        const int e = (wave + 4 * i) * 64 + lane;
-        const int pr = e / a.PW, pc = e - pr * a.PW;
-        const int ih = ih0 + pr, iw = iw0 + pc;
-        const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-        goff[i] = ok ? ih * a.Wi + iw : -1;
-    }
-    // ---- 1x1 layers: 16-byte pieces over the whole [KC][PSZ] chunk; per lane (channel-in-chunk, offset)
     const int nq = (a.KC * a.PSZ) >> 8;
-    int goff4[MAXQ], gci4[MAXQ];
+    int goff[NOFF], gci[VEC4 ? MAXQ : 1];
 #pragma unroll
-    for (int i = 0; i < MAXQ; ++i) {
-        const int off = (wave + 4 * i) * 256 + lane * 4;
-        const int ci = off / a.PSZ, rem = off - ci * a.PSZ;
-        const int pr = rem / a.PW, pc = rem - pr * a.PW;
-        const int ih = ih0 + pr, iw = iw0 + pc;
-        const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw + 3 < a.Wi;
-        gci4[i] = ci;
-        goff4[i] = ok ? ci * (a.Hi * a.Wi) + ih * a.Wi + iw : -1;
+    for (int i = 0; i < NOFF; ++i) {
+        if (VEC4) {
+            const int off = (wave + 4 * i) * 256 + lane * 4;
+            const int ci = off / a.PSZ, rem = off - ci * a.PSZ;
+            const int pr = rem / a.PW, pc = rem - pr * a.PW;
+            const int ih = ih0 + pr, iw = iw0 + pc;
+            const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw + 3 < a.Wi;
+            gci[i] = ci;
+            goff[i] = ok ? ci * (a.Hi * a.Wi) + ih * a.Wi + iw : -1;
+        } else {
+            const int e = (wave + 4 * i) * 64 + lane;
+            const int pr = e / a.PW, pc = e - pr * a.PW;
+            const int ih = ih0 + pr, iw = iw0 + pc;
+            const bool ok = (pr < a.PH) && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+            goff[i] = ok ? ih * a.Wi + iw : -1;
+        }
     }
     const size_t plane = (size_t)a.Hi * a.Wi;
     const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
-    // weights: 16-byte pieces, 16 lanes per (tap,ci) row of 64 co -> 4 rows per wave-instruction
-    const int wrows = a.g.ntaps * a.KC;                    // multiple of 2; rows beyond wrows are skipped per lane
-    const int wq = lane & 15, wr = lane >> 4;
+    // weights: 16-byte pieces, BM/4 lanes per (tap,ci) row of BM co -> 256/BM rows per wave-instruction
+    constexpr int LPR = BM / 4, RPI = 64 / LPR;
+    const int wrows = g.ntaps * a.KC;
+    const int wq = lane % LPR, wr = lane / LPR;
 
     auto issue = [&](int cc, float* buf) {
-        if (a.vec4) {
+        if (VEC4) {
             const float* xc = xb + (size_t)cc * plane;
 #pragma unroll
-            for (int i = 0; i < MAXQ; ++i) {
+            for (int i = 0; i < NOFF; ++i) {
                 const int q = wave + 4 * i;
                 if (q < nq) {
-                    const float* src = (goff4[i] >= 0 && cc + gci4[i] < a.Cin) ? xc + goff4[i] : g_zero_word;
+                    const float* src = (goff[i] >= 0 && cc + gci[VEC4 ? i : 0] < a.Cin) ? xc + goff[i] : g_zero_word;
                     dma16(src, buf + q * 256);
                 }
             }
@@ -256,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
                 const float* xc = xb + (size_t)(cc + ci) * plane;
                 float* dst = buf + ci * a.PSZ;
 #pragma unroll
-                for (int i = 0; i < MAXE; ++i) {
+                for (int i = 0; i < NOFF; ++i) {
                     const int g = wave + 4 * i;
                     if (g < groups) {
                         const float* src = (cok && goff[i] >= 0) ? xc + goff[i] : g_zero_word;
@@ -266,37 +305,37 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
             }
         }
         float* wdst = buf + wts_off;
-        for (int r4 = wave * 4; r4 < wrows; r4 += 16) {       // this wave-instruction covers rows r4..r4+3
-            int row = r4 + wr;
-            row = row < wrows ? row : wrows - 1;                // tail lanes duplicate the last row into the (unused) pad rows
+        for (int r = wave * RPI; r < wrows; r += 4 * RPI) {   // this wave-instruction covers rows r..r+RPI-1
+            int row = r + wr;
+            row = row < wrows ? row : wrows - 1;                // tail lanes duplicate the last row into the pad rows
             const int t = row >> a.KClog, ci = row & (a.KC - 1);
-            const float* src = a.wp + ((size_t)(a.g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0 + wq * 4;
-            dma16(src, wdst + r4 * 64);
+            const float* src = a.wp + ((size_t)(g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0 + wq * 4;
+            dma16(src, wdst + r * BM);
         }
     };
 
-    int pixoff[WN];
     const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
+    // per-lane LDS offsets: A fragment (co = wm*32*WM + mi*32 + j of k-row h), B fragment (pixel j of sub-tile n, channel h)
+    const int lane_w = h * BM + wm * (32 * WM) + j;
+    int lane_p[WN];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int r = (wn * WN + n) * a.SR + jr;
-        pixoff[n] = (r * a.g.is) * a.PW + jc * a.g.is;
+        lane_p[n] = h * a.PSZ + (r * g.is) * a.PW + jc * g.is;
     }
-    f32x16 acc[WN];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int n = 0; n < WN; ++n)
+    for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
 
-    const int lane_w = h * 64 + wm * 32 + j;
-    int lane_p[WN];
-#pragma unroll
-    for (int n = 0; n < WN; ++n) lane_p[n] = h * a.PSZ + pixoff[n];
     const int kh = a.KC >> 1, khlog = a.KClog - 1;
-    const int nsteps = a.g.ntaps << khlog;
-    const int tap0_off = (a.g.dh0 - a.g.dh_min) * a.PW + (a.g.dw0 - a.g.dw_min);
+    const int nsteps = g.ntaps << khlog;
+    const int tap0_off = (g.dh0 - g.dh_min) * a.PW + (g.dw0 - g.dw_min);
     const int chan_span = 2 * a.PSZ * (kh - 1);                       // back to channel pair 0 of the chunk
-    const int row_step = a.g.dsh * a.PW - a.g.dsw * (a.g.ntw - 1);   // first tap of the next kernel row
+    const int row_step = g.dsh * a.PW - g.dsw * (g.ntw - 1);   // first tap of the next kernel row
 
     const int nchunks = a.Cin_pad >> a.KClog;
     issue(0, lds);
@@ -307,39 +346,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
         if (c + 1 < nchunks) issue((c + 1) << a.KClog, lds + ((c + 1) & 1) * buf_sz);
         const float* patch = cur;
         const float* wts = cur + wts_off;
-        // k-steps s = (tap, channel pair) of this chunk, software-pipelined: the LDS reads of step s+1 are
-        // issued before the MFMAs of step s
-        // offsets advance incrementally (a handful of scalar ops per step): weights are contiguous in step
-        // order; the patch offset moves by two channels inside a tap, else to the next tap (row-major taps)
+        // k-steps (tap, channel pair) of this chunk, software-pipelined with two fragment sets: the LDS reads of
+        // step s+1 are issued before the MFMAs of step s.  Offsets advance incrementally: weights are contiguous
+        // in step order; the patch offset moves by two channels inside a tap, else to the next (row-major) tap.
         int sw = 0, sp = tap0_off, kk2 = 0, tb = 0;
-        float av = wts[lane_w];
-        float bv[WN];
+        auto advance = [&]() {
+            sw += 2 * BM;
+            if (++kk2 < kh) {
+                sp += 2 * a.PSZ;
+            } else {
+                kk2 = 0;
+                sp -= chan_span;
+                if (++tb < g.ntw) sp += g.dsw;
+                else { tb = 0; sp += row_step; }
+            }
+        };
+        float a0[WM], b0[WN], a1[WM], b1[WN];
 #pragma unroll
-        for (int n = 0; n < WN; ++n) bv[n] = patch[sp + lane_p[n]];
-        for (int st = 0; st < nsteps; ++st) {
-            float av1 = 0.0f, bv1[WN];
+        for (int m = 0; m < WM; ++m) a0[m] = wts[lane_w + m * 32];
 #pragma unroll
-            for (int n = 0; n < WN; ++n) bv1[n] = 0.0f;
-            if (st + 1 < nsteps) {
-                sw += 128;
-                if (++kk2 < kh) {
-                    sp += 2 * a.PSZ;
-                } else {
-                    kk2 = 0;
-                    sp -= chan_span;
-                    if (++tb < a.g.ntw) sp += a.g.dsw;
-                    else { tb = 0; sp += row_step; }
-                }
-                av1 = wts[sw + lane_w];
+        for (int n = 0; n < WN; ++n) b0[n] = patch[sp + lane_p[n]];
+        for (int st = 0; st < nsteps; st += 2) {
+            const bool more1 = st + 1 < nsteps;
+            if (more1) {
+                advance();
 #pragma unroll
-                for (int n = 0; n < WN; ++n) bv1[n] = patch[sp + lane_p[n]];
+                for (int m = 0; m < WM; ++m) a1[m] = wts[sw + lane_w + m * 32];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) b1[n] = patch[sp + lane_p[n]];
             }
 #pragma unroll
-            for (int n = 0; n < WN; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, apply_inop(bv[n], INOP), acc[n], 0, 0, 0);
-            av = av1;
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) bv[n] = bv1[n];
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], apply_inop(b0[n], INOP), acc[m][n], 0, 0, 0);
+            if (!more1) break;
+            if (st + 2 < nsteps) {
+                advance();
+#pragma unroll
+                for (int m = 0; m < WM; ++m) a0[m] = wts[sw + lane_w + m * 32];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) b0[n] = patch[sp + lane_p[n]];
+            }
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], apply_inop(b1[n], INOP), acc[m][n], 0, 0, 0);
         }
     }
 
@@ -348,21 +401,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmArgs a) {
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
-        if (r >= a.g.Hp || c >= a.g.Wp) continue;
-        const int oh = r * a.g.os + a.g.oph, ow = c * a.g.os + a.g.opw;
+        if (r >= g.Hp || c >= g.Wp) continue;
+        const int oh = r * g.os + g.oph, ow = c * g.os + g.opw;
         const size_t opix = (size_t)oh * a.Wo + ow;
         float gv = 1.0f;
         if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (co < a.Cout) {
-                float v = acc[n][e] + (a.bias ? a.bias[co] : 0.0f);
-                v = apply_act(v, a.act);
-                if (a.gate) v *= gv;
-                a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + wm * (32 * WM) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < a.Cout) {
+                    float v = acc[m][n][e] + (a.bias ? a.bias[co] : 0.0f);
+                    v = apply_act(v, a.act);
+                    if (a.gate) v *= gv;
+                    a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+                }
             }
-        }
     }
 }
 
@@ -372,28 +427,31 @@ struct DirectArgs {
     int Cin, Hi, Wi, in_ctot, in_coff;
     int Cout, Ho, Wo, out_ctot, out_coff;
     int in_op, act, gate_ctot, gate_c;
-    ConvGeom g;
+    GeomParams q;
+    int nphase;
 };
 
 template <int CO>
 __global__ __launch_bounds__(256) void conv_direct_f32(const DirectArgs a) {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int phase = blockIdx.x % a.nphase;
+    const ConvGeom g = make_geom(a.q, phase);
+    const int pix = (blockIdx.x / a.nphase) * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    const int npix = a.g.Hp * a.g.Wp;
+    const int npix = g.Hp * g.Wp;
     const bool live = pix < npix;
-    const int r = live ? pix / a.g.Wp : 0, c = live ? pix - r * a.g.Wp : 0;
+    const int r = live ? pix / g.Wp : 0, c = live ? pix - r * g.Wp : 0;
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = 0.0f;
     const size_t plane = (size_t)a.Hi * a.Wi;
     const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
-    for (int t = 0; t < a.g.ntaps; ++t) {
-        const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
-        const int ih = r * a.g.is + a.g.dh0 + ta * a.g.dsh;
-        const int iw = c * a.g.is + a.g.dw0 + tb * a.g.dsw;
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int ta = t / g.ntw, tb = t - ta * g.ntw;
+        const int ih = r * g.is + g.dh0 + ta * g.dsh;
+        const int iw = c * g.is + g.dw0 + tb * g.dsw;
         const bool ok = live && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
         const float* xp = xb + (size_t)ih * a.Wi + iw;
-        const float* wt = a.wp + (size_t)(a.g.tap_base + t) * a.Cin * 8;
+        const float* wt = a.wp + (size_t)(g.tap_base + t) * a.Cin * 8;
         for (int ci = 0; ci < a.Cin; ++ci) {
             const float v = ok ? apply_inop(xp[(size_t)ci * plane], a.in_op) : 0.0f;
 #pragma unroll
@@ -401,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectArgs a) {
         }
     }
     if (!live) return;
-    const int oh = r * a.g.os + a.g.oph, ow = c * a.g.os + a.g.opw;
+    const int oh = r * g.os + g.oph, ow = c * g.os + g.opw;
     const size_t oplane = (size_t)a.Ho * a.Wo, opix = (size_t)oh * a.Wo + ow;
     float gv = 1.0f;
     if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
@@ -422,6 +480,114 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectArgs a) {
 #pragma unroll
     for (int o = 0; o < CO; ++o)
         if (o < a.Cout) a.y[((size_t)b * a.out_ctot + a.out_coff + o) * oplane + opix] = a.gate ? acc[o] * gv : acc[o];
+}
+
+// ------------------------------------------------------------------------------------------ deconv to <=4 channels
+// ConvTranspose2d(Cin -> Cout<=4, k=5, s=2, p=2, op=1): the last layer of both synthesis transforms
+// (decoder{1,2}.g_s_conv4, MASIC.py:542,596).  Cout = 3 cannot feed a 32x32 MFMA tile, and the layer is bound by
+// reading its 128-channel input once, so it runs on the VALU: a 16x16 tile of INPUT pixels per workgroup, the
+// input staged through LDS by DMA (8 channels per chunk, halo 1), each thread producing the 2x2 output pixels of
+// its input pixel for all output channels (25 taps x Cout FMAs per input channel, weights as scalar operands).
+struct Deconv4Args {
+    const float* x; const float* wp; const float* bias; float* y;
+    int Cin, Cin_pad, Hi, Wi, in_ctot, in_coff;
+    int Cout, Ho, Wo, out_ctot, out_coff;
+    int act, tiles_w;
+};
+
+__global__ __launch_bounds__(256) void deconv5s2_small_cout(const Deconv4Args a, const float* __restrict__ wpk) {
+    constexpr int T = 16, LW = T + 2, PLANE = LW * LW, PSZ = 384, KC = 8;   // 324 floats per channel -> 6 DMA groups
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * PSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = tid & 15, ty = tid >> 4;
+    const int tile_x = blockIdx.x % a.tiles_w, tile_y = blockIdx.x / a.tiles_w;
+    const int b = blockIdx.y;
+    const int r = tile_y * T + ty, c = tile_x * T + tx;
+    const int ih0 = tile_y * T - 1, iw0 = tile_x * T - 1;
+
+    int goff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = (wave + 4 * i) * 64 + lane;
+        const int pr = e / LW, pc = e - pr * LW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        const bool ok = e < PLANE && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        goff[i] = ok ? ih * a.Wi + iw : -1;
+    }
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    auto issue = [&](int cc, float* buf) {
+#pragma unroll
+        for (int ci = 0; ci < KC; ++ci) {
+            const bool cok = (cc + ci) < a.Cin;
+            const float* xc = xb + (size_t)(cc + ci) * plane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int g = wave + 4 * i;
+                if (g < 6) dma4((cok && goff[i] >= 0) ? xc + goff[i] : g_zero_word, buf + ci * PSZ + g * 64);
+            }
+        }
+    };
+
+    float acc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (&acc[0][0][0])[i] = 0.0f;
+    const int lbase = (ty + 1) * LW + tx + 1;
+    const int nchunks = a.Cin_pad / KC;
+    issue(0, lds);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* cur = lds + (ch & 1) * (KC * PSZ);
+        __syncthreads();
+        if (ch + 1 < nchunks) issue((ch + 1) * KC, lds + ((ch + 1) & 1) * (KC * PSZ));
+#pragma unroll 1
+        for (int ci = 0; ci < KC; ++ci) {
+            const float* pl = cur + ci * PSZ + lbase;
+            float v[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v[dy][dx] = pl[(dy - 1) * LW + dx - 1];
+            const float* w = wpk + (ch * KC + ci) * 100;       // [kh][kw][4]; const __restrict__ + uniform -> s_load
+            // out(2r+ph, 2c+pw) += in(r+1-a, c+1-b) * W[ph+2a][pw+2b]
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                    for (int ta = 0; ta < 3 - ph; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 3 - pw; ++tb) {
+                            const float xv = v[2 - ta][2 - tb];
+                            const float* wt = w + ((ph + 2 * ta) * 5 + (pw + 2 * tb)) * 4;
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[ph][pw][o] = fmaf(xv, wt[o], acc[ph][pw][o]);
+                        }
+        }
+    }
+    if (r >= a.Hi || c >= a.Wi) return;
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o >= a.Cout) break;
+        const float bv = a.bias ? a.bias[o] : 0.0f;
+        float* yo = a.y + ((size_t)b * a.out_ctot + a.out_coff + o) * oplane;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float2 st;
+            st.x = apply_act(acc[ph][0][o] + bv, a.act);
+            st.y = apply_act(acc[ph][1][o] + bv, a.act);
+            *reinterpret_cast<float2*>(yo + (size_t)(2 * r + ph) * a.Wo + 2 * c) = st;
+        }
+    }
+}
+
+// packed layout for deconv5s2_small_cout: [ci (padded to 8)][kh][kw][4]
+__global__ void pack_deconv4_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cin_pad, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin_pad * 100) return;
+    const int ci = i / 100, rem = i - ci * 100, tap = rem >> 2, o = rem & 3;
+    wp[i] = (ci < Cin && o < Cout) ? w[((size_t)ci * Cout + o) * 25 + tap] : 0.0f;
 }
 
 int check_desc(const masic_conv_desc_t* d) {
@@ -456,6 +622,7 @@ extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
     const ConvCfg c = choose_cfg(*d, g, np);
     int taps = 0;
     for (int p = 0; p < np; ++p) taps += g[p].ntaps;
+    if (c.direct == 2) return (size_t)c.Cin_pad * 100 * sizeof(float);
     return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
 }
 
@@ -465,9 +632,10 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     ConvGeom g[4];
     const int np = build_geoms(*d, g);
     const ConvCfg c = choose_cfg(*d, g, np);
-    if (launches) *launches = np;
+    if (launches) *launches = 1;   // all phases ride in one launch
+    if (c.direct == 2) return 6;
     if (c.direct) return d->Cout <= 3 ? 0 : 1;
-    return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
+    return c.wm == 2 ? 5 : (c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2));
 }
 
 extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
@@ -477,6 +645,11 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
     ConvGeom g[4];
     const int np = build_geoms(*d, g);
     const ConvCfg c = choose_cfg(*d, g, np);
+    if (c.direct == 2) {
+        hipLaunchKernelGGL(pack_deconv4_kernel, dim3(ceil_div(c.Cin_pad * 100, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, (float*)w_packed, d->Cin, c.Cin_pad, d->Cout);
+        return masic_launch_status("conv_pack_weight");
+    }
     for (int p = 0; p < np; ++p) {
         PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, g[p]};
         const size_t total = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
@@ -496,36 +669,48 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
     const int np = build_geoms(*d, g);
     const ConvCfg c = choose_cfg(*d, g, np);
     hipStream_t st = (hipStream_t)stream;
-    for (int p = 0; p < np; ++p) {
-        if (g[p].Hp <= 0 || g[p].Wp <= 0) continue;
-        if (c.direct) {
-            DirectArgs a{x, (const float*)w_packed, bias, gate, y,
-                         d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
-                         d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
-                         d->in_op, d->act, d->gate_ctot, d->gate_c, g[p]};
-            dim3 grid(ceil_div(g[p].Hp * g[p].Wp, 256), d->B);
-            if (d->Cout <= 3) hipLaunchKernelGGL(conv_direct_f32<3>, grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(conv_direct_f32<8>, grid, dim3(256), 0, st, a);
-            continue;
-        }
+    const GeomParams q = geom_params(*d);
+    if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
+    if (c.direct == 2) {
+        MASIC_REQUIRE(gate == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: gate on the small-Cout deconv path");
+        MASIC_REQUIRE(d->Wo % 2 == 0, MASIC_ERR_SHAPE, "conv2d_fwd: odd output width");
+        Deconv4Args a{x, (const float*)w_packed, bias, y, d->Cin, c.Cin_pad, d->Hi, d->Wi, d->in_ctot, d->in_coff,
+                      d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff, d->act, ceil_div(d->Wi, 16)};
+        hipLaunchKernelGGL(deconv5s2_small_cout, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
+                           (const float*)w_packed);
+        return masic_launch_status("conv2d_fwd");
+    }
+    if (c.direct) {
+        DirectArgs a{x, (const float*)w_packed, bias, gate, y,
+                     d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
+                     d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+                     d->in_op, d->act, d->gate_ctot, d->gate_c, q, np};
+        dim3 grid(ceil_div(g[0].Hp * g[0].Wp, 256) * np, d->B);
+        if (d->Cout <= 3) hipLaunchKernelGGL(conv_direct_f32<3>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(conv_direct_f32<8>, grid, dim3(256), 0, st, a);
+        return masic_launch_status("conv2d_fwd");
+    }
+    {
         IgemmArgs a{x, (const float*)w_packed, bias, gate, y,
                     d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
                     d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                     c.Cin_pad, c.Cout_pad, c.KC, c.KClog,
-                    c.TW, c.TWlog, c.SR, c.TH, ceil_div(g[p].Wp, c.TW),
+                    c.TW, c.TWlog, c.SR, c.TH, ceil_div(g[0].Wp, c.TW),
                     c.PH, c.PW, c.PWp, c.PSZ, c.buf_sz, c.vec4,
-                    d->in_op, d->act, d->gate_ctot, d->gate_c, g[p]};
-        dim3 grid(ceil_div(g[p].Wp, c.TW) * ceil_div(g[p].Hp, c.TH), c.Cout_pad / 64, d->B);
-#define IGEMM_LAUNCH(WNV, OPV) hipLaunchKernelGGL((conv_igemm_f32<WNV, OPV>), grid, dim3(256), c.lds_bytes, st, a)
-#define IGEMM_BY_OP(WNV)                                             \
-    do {                                                             \
-        if (d->in_op == MASIC_INOP_ABS) IGEMM_LAUNCH(WNV, MASIC_INOP_ABS);         \
-        else if (d->in_op == MASIC_INOP_ROUND) IGEMM_LAUNCH(WNV, MASIC_INOP_ROUND); \
-        else IGEMM_LAUNCH(WNV, MASIC_INOP_NONE);                     \
+                    d->in_op, d->act, d->gate_ctot, d->gate_c, q, np};
+        dim3 grid(ceil_div(g[0].Wp, c.TW) * ceil_div(g[0].Hp, c.TH) * np, c.Cout_pad / (64 * c.wm), d->B);
+#define IGEMM_LAUNCH(WMV, WNV, OPV, V4) hipLaunchKernelGGL((conv_igemm_f32<WMV, WNV, OPV, V4>), grid, dim3(256), c.lds_bytes, st, a)
+#define IGEMM_BY_OP(WMV, WNV)                                                               \
+    do {                                                                                    \
+        if (d->in_op == MASIC_INOP_ABS) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_ABS, false);      \
+        else if (d->in_op == MASIC_INOP_ROUND) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_ROUND, false); \
+        else if (c.vec4) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, true);                     \
+        else IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, false);                                \
     } while (0)
-        if (c.wn == 4) IGEMM_BY_OP(4);
-        else if (c.wn == 2) IGEMM_BY_OP(2);
-        else IGEMM_BY_OP(1);
+        if (c.wm == 2) IGEMM_BY_OP(2, 4);
+        else if (c.wn == 4) IGEMM_BY_OP(1, 4);
+        else if (c.wn == 2) IGEMM_BY_OP(1, 2);
+        else IGEMM_BY_OP(1, 1);
 #undef IGEMM_BY_OP
 #undef IGEMM_LAUNCH
     }

@@ -64,8 +64,8 @@ def pack_conv_weight(weight, desc):
 class KernelTimer:
     """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
-    VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1>", 3: "conv_igemm_f32<2>",
-                4: "conv_igemm_f32<4>"}
+    VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1,1>", 3: "conv_igemm_f32<1,2>",
+                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout"}
 
     def __init__(self):
         self.records = []
