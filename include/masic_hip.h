@@ -73,7 +73,7 @@ size_t masic_conv_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
 /* which kernel (and how many launches of it) masic_conv2d_fwd issues for this layer -- used by
  * bench.py to attribute HIP-event timings to kernel symbols:
- *   variant 0/1: conv_direct_f32<3>/<8>; 2/3/4/5: conv_igemm_f32<1,1>/<1,2>/<1,4>/<2,4>; launches = phases (1, or
+ *   variant 0/1: conv_direct_f32<3>/<8>; 2/3/4/5/7: conv_igemm_f32<1,1>/<1,2>/<1,4>/<2,4>/<2,2>; 6: deconv5s2_small_cout; launches = phases (1, or
  *   stride^2 for transposed convs). Returns variant, writes *launches if non-NULL; <0 on bad desc. */
 int masic_conv_variant(const masic_conv_desc_t* d, int* launches);
 /* y = act(conv(in_op(x), w) + bias) [* gate].  bias may be NULL. */

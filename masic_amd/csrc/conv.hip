@@ -141,8 +141,10 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         int TH = c.SR * 2 * wn;
         return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * (round_up(d.Cout, 64 * wm) / (64 * wm)) * d.B * nphase;
     };
-    c.wm = (d.Cout % 128 == 0 && nblocks(2, 4) >= 512) ? 2 : 1;
-    c.wn = c.wm == 2 ? 4 : (nblocks(1, 4) >= 768 ? 4 : (nblocks(1, 2) >= 512 ? 2 : 1));
+    const bool m128 = round_up(d.Cout, 128) * 10 <= d.Cout * 11;          // <= 10 % padding waste with 128-wide blocks
+    if (m128 && nblocks(2, 4) >= 512) { c.wm = 2; c.wn = 4; }
+    else if (m128 && nblocks(2, 2) >= 512) { c.wm = 2; c.wn = 2; }
+    else { c.wm = 1; c.wn = nblocks(1, 4) >= 768 ? 4 : (nblocks(1, 2) >= 512 ? 2 : 1); }
     const int BM = 64 * c.wm;
     c.Cout_pad = round_up(d.Cout, BM);
     // the per-channel patch must fit 24 DMA wave-instructions (MAXE = 6 per wave)
@@ -161,7 +163,7 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     // two LDS buffers (the next chunk lands by DMA while this one is contracted); keep 2 blocks per CU
     int KC = 32;
     if (c.vec4) {
-        while (KC > 4 && (KC * c.PSZ > 8192 || KC > round_up(d.Cin, 4))) KC >>= 1;
+        while (KC > 4 && (KC * c.PSZ > 8192 || (size_t)2 * KC * (c.PSZ + BM) * 4 > 48 * 1024 || KC > round_up(d.Cin, 4))) KC >>= 1;
     } else {
         while (KC > 2 && ((size_t)2 * KC * (c.PSZ + max_taps * BM) * 4 > 80 * 1024 || KC > cin2 || KC * epw > 48)) KC >>= 1;
     }
@@ -635,7 +637,8 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     if (launches) *launches = 1;   // all phases ride in one launch
     if (c.direct == 2) return 6;
     if (c.direct) return d->Cout <= 3 ? 0 : 1;
-    return c.wm == 2 ? 5 : (c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2));
+    if (c.wm == 2) return c.wn == 4 ? 5 : 7;
+    return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
 }
 
 extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
@@ -707,7 +710,8 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
         else if (c.vec4) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, true);                     \
         else IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, false);                                \
     } while (0)
-        if (c.wm == 2) IGEMM_BY_OP(2, 4);
+        if (c.wm == 2 && c.wn == 4) IGEMM_BY_OP(2, 4);
+        else if (c.wm == 2) IGEMM_BY_OP(2, 2);
         else if (c.wn == 4) IGEMM_BY_OP(1, 4);
         else if (c.wn == 2) IGEMM_BY_OP(1, 2);
         else IGEMM_BY_OP(1, 1);

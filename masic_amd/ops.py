@@ -65,7 +65,7 @@ class KernelTimer:
     """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
     VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1,1>", 3: "conv_igemm_f32<1,2>",
-                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout"}
+                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout", 7: "conv_igemm_f32<2,2>"}
 
     def __init__(self):
         self.records = []
