@@ -57,5 +57,9 @@ class ResidualBlock(nn.Module):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def forward(self, x):
-        raise NotImplementedError("ResidualBlock (CQE network) is scheduled after the HSIC path; see DESIGN.md")
+    def forward(self, x, extra_identity=None):
+        """out = leaky(conv2(leaky(conv1(x)))) + identity [+ extra_identity]; activations and both adds run in the
+        conv epilogues (`extra_identity` lets Enhancement_Block fold its own skip into the last block)."""
+        identity = x if self.skip is None else self.skip.run(x)
+        t = self.conv1.run(x, act=_hip.ACT_LEAKY)
+        return self.conv2.run(t, act=_hip.ACT_LEAKY, res1=identity, res2=extra_identity)

@@ -435,6 +435,8 @@ class HSIC(CompressionModel):
 
 # ------------------------------------------------------------------------------------------ CQE network
 class Enhancement_Block(nn.Module):
+    """Three residual blocks plus a skip over all of them (reference :149-164)."""
+
     def __init__(self, shape):
         super().__init__()
         self.RB1 = ResidualBlock(shape, shape)
@@ -442,10 +444,13 @@ class Enhancement_Block(nn.Module):
         self.RB3 = ResidualBlock(shape, shape)
 
     def forward(self, x):
-        raise NotImplementedError("Independent_EN is scheduled after the HSIC path; see DESIGN.md")
+        t = self.RB2(self.RB1(x))
+        return self.RB3(t, extra_identity=x)        # (RB3(t)) + x, the outer add fused into RB3's last conv
 
 
 class mask2weights_EN(nn.Module):
+    """mask -> Kw softmax-normalised gate maps at full resolution (reference :1411-1434)."""
+
     def __init__(self, Kw=2):
         super().__init__()
         self.maskconv = nn.Sequential(
@@ -463,7 +468,9 @@ class mask2weights_EN(nn.Module):
 
 
 class Independent_EN(nn.Module):
-    """Cross quality-enhancement network (reference :1436-1501): module tree / state dict only for now."""
+    """Cross quality-enhancement network (reference :1436-1501): each view is refined with features of the other
+    view warped by the homography, mixed through mask-derived 2-way gates.  Warps, gate products and concats are
+    fused (gated writes straight into the concat buffers); residual adds run in conv epilogues."""
 
     def __init__(self):
         super().__init__()
@@ -479,7 +486,49 @@ class Independent_EN(nn.Module):
         self.mask2weights_unit = mask2weights_EN()
 
     def forward(self, x1_hat, x2_hat, h_matrix):
-        raise NotImplementedError("Independent_EN.forward: SURVEY.md section 8(a) row 15, scheduled after the HSIC path")
+        x1_hat = x1_hat.contiguous()
+        x2_hat = x2_hat.contiguous()
+        B, _, H, W = x1_hat.shape
+        dev, dt = x1_hat.device, x1_hat.dtype
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        mask_L = _hip.warp_perspective(mask_R, m_back, (H, W))
+        w_R = self.mask2weights_unit(mask_R)        # [B,2,H,W]
+        w_L = self.mask2weights_unit(mask_L)
+        x1_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))
+        x2_warp = _hip.warp_perspective(x2_hat, m_back, (H, W))
+        x1c = self.conv0(x1_hat)
+        x2c = self.conv0(x2_hat)
+
+        in1 = torch.empty((B, 6, H, W), dtype=dt, device=dev)       # x2_warp*wL0 | x1*wL1   (:1470)
+        _hip.quantize(x2_warp, "copy", out=in1, out_coff=0, gate=w_L, gate_c=0)
+        _hip.quantize(x1_hat, "copy", out=in1, out_coff=3, gate=w_L, gate_c=1)
+        in2 = torch.empty((B, 6, H, W), dtype=dt, device=dev)       # x1_warp*wR0 | x2*wR1   (:1471)
+        _hip.quantize(x1_warp, "copy", out=in2, out_coff=0, gate=w_R, gate_c=0)
+        _hip.quantize(x2_hat, "copy", out=in2, out_coff=3, gate=w_R, gate_c=1)
+        out1 = self.EBl1(self.conv1(in1))
+        out2 = self.EBr1(self.conv1(in2))
+
+        out1_warp = _hip.warp_perspective(out1, m_fwd, (H, W))
+        out2_warp = _hip.warp_perspective(out2, m_back, (H, W))
+        c1 = torch.empty((B, 64, H, W), dtype=dt, device=dev)       # out1*wL1 | out2_warp*wL0   (:1481)
+        _hip.quantize(out1, "copy", out=c1, out_coff=0, gate=w_L, gate_c=1)
+        _hip.quantize(out2_warp, "copy", out=c1, out_coff=32, gate=w_L, gate_c=0)
+        c2 = torch.empty((B, 64, H, W), dtype=dt, device=dev)       # out2*wR1 | out1_warp*wR0   (:1482)
+        _hip.quantize(out2, "copy", out=c2, out_coff=0, gate=w_R, gate_c=1)
+        _hip.quantize(out1_warp, "copy", out=c2, out_coff=32, gate=w_R, gate_c=0)
+        out1 = self.EBl2(c1)
+        out2 = self.EBr2(c2)
+
+        d1 = torch.empty((B, 96, H, W), dtype=dt, device=dev)       # out1 | conv0(x1_hat)   (:1486)
+        _hip.copy_view(out1, d1, 0)
+        _hip.copy_view(x1c, d1, 64)
+        d2 = torch.empty((B, 96, H, W), dtype=dt, device=dev)
+        _hip.copy_view(out2, d2, 0)
+        _hip.copy_view(x2c, d2, 64)
+        out1 = self.EBl3(d1)
+        out2 = self.EBr3(d2)
+        return {"x1_hat": self.conv2.run(out1, res1=x1_hat), "x2_hat": self.conv2.run(out2, res1=x2_hat)}
 
 
 class GMM_together(nn.Module):

@@ -73,12 +73,17 @@ size_t masic_conv_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
 /* which kernel (and how many launches of it) masic_conv2d_fwd issues for this layer -- used by
  * bench.py to attribute HIP-event timings to kernel symbols:
- *   variant 0/1: conv_direct_f32<3>/<8>; 2/3/4/5/7: conv_igemm_f32<1,1>/<1,2>/<1,4>/<2,4>/<2,2>; 6: deconv5s2_small_cout; launches = phases (1, or
+ *   variant 0/1: conv_direct_f32<3>/<8>; 2/3/4/5/7: conv_igemm_f32<2 waves x {1x1,1x2,1x4,2x4,2x2} tiles>; 8/9: conv_igemm_f32<1 wave x {1x2,3x2}>;
+ *   6: deconv5s2_small_cout; launches = phases (1, or
  *   stride^2 for transposed convs). Returns variant, writes *launches if non-NULL; <0 on bad desc. */
 int masic_conv_variant(const masic_conv_desc_t* d, int* launches);
 /* y = act(conv(in_op(x), w) + bias) [* gate].  bias may be NULL. */
 int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
                      float* y, const masic_conv_desc_t* d, void* stream);
+/* same, plus up to two residual tensors [B,Cout,Ho,Wo] added after the activation: the `out + identity` of
+ * ResidualBlock (compressai/layers/layers.py:189), Enhancement_Block (MASIC.py:163) and Independent_EN (:1495-1496) */
+int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias, const float* gate,
+                        const float* res1, const float* res2, float* y, const masic_conv_desc_t* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of
@@ -90,6 +95,7 @@ int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* 
 
 /* ------------------------------------------------------------------------------------------
  * Quantisation: compressai/entropy_models/entropy_models.py:98-125 with means=None.
+ *   mode 3 'copy'      : y = x             (used with the gate / output view: x*w into a torch.cat slice, MASIC.py:1470-1482)
  *   mode 0 'dequantize': y = round(x)      (torch.round: half to even)
  *   mode 1 'noise'     : y = x + noise     (noise drawn by the caller, same shape)
  *   mode 2 'symbols'   : sym = (int32) round(x - median[c])   (median may be NULL -> 0)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "masic_conv_variant": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "masic_conv_pack_weight": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_quantize_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     "masic_symbols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -99,7 +99,8 @@ int build_geoms(const masic_conv_desc_t& d, ConvGeom* g) {
 
 struct ConvCfg {
     int direct;         // 1: direct kernel (Cout <= 8); 2: LDS-tiled 5x5 stride-2 transposed conv to <= 4 channels
-    int wm;             // 32-channel sub-tiles per wave: block covers BM = 64*wm output channels
+    int wvm;            // waves along the channel dimension (2, or 1 for narrow layers); 4/wvm along pixels
+    int wm;             // 32-channel sub-tiles per wave: block covers BM = 32*wm*wvm output channels
     int wn;             // pixel sub-tiles (of 32) per wave: 4 -> BM x 256 block tile, 1 -> BM x 64
     int buf_sz;         // floats per LDS buffer: patch [KC][PSZ] + weights [round4(taps*KC)][64]
     int vec4;           // 1x1 layers: the patch is staged with 16-byte DMA pieces
@@ -142,14 +143,18 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         return (long)ceil_div(Hp, TH) * ceil_div(Wp, c.TW) * (round_up(d.Cout, 64 * wm) / (64 * wm)) * d.B * nphase;
     };
     const bool m128 = round_up(d.Cout, 128) * 10 <= d.Cout * 11;          // <= 10 % padding waste with 128-wide blocks
-    if (m128 && nblocks(2, 4) >= 512) { c.wm = 2; c.wn = 4; }
+    c.wvm = 2;
+    if (d.Cout <= 32) { c.wvm = 1; c.wm = 1; c.wn = 2; }                    // 32 x 256 tile (CQE 32-channel layers)
+    else if (d.Cout > 64 && d.Cout <= 96) { c.wvm = 1; c.wm = 3; c.wn = 2; } // 96 x 256 tile (CQE 96-channel layers)
+    else if (m128 && nblocks(2, 4) >= 512) { c.wm = 2; c.wn = 4; }
     else if (m128 && nblocks(2, 2) >= 512) { c.wm = 2; c.wn = 2; }
     else { c.wm = 1; c.wn = nblocks(1, 4) >= 768 ? 4 : (nblocks(1, 2) >= 512 ? 2 : 1); }
-    const int BM = 64 * c.wm;
+    const int wvn = 4 / c.wvm;
+    const int BM = 32 * c.wm * c.wvm;
     c.Cout_pad = round_up(d.Cout, BM);
     // the per-channel patch must fit 24 DMA wave-instructions (MAXE = 6 per wave)
-    while (c.wn > 1 && ((c.SR * 2 * c.wn - 1) * is + span_h) * ((c.TW - 1) * is + span_w) > 24 * 64) c.wn >>= 1;
-    c.TH = c.SR * 2 * c.wn;
+    while (c.wvm == 2 && c.wn > 1 && ((c.SR * wvn * c.wn - 1) * is + span_h) * ((c.TW - 1) * is + span_w) > 24 * 64) c.wn >>= 1;
+    c.TH = c.SR * wvn * c.wn;
     c.PH = (c.TH - 1) * is + span_h;
     c.PW = (c.TW - 1) * is + span_w;
     c.PWp = c.PW;                                       // LDS-DMA writes 64 consecutive floats: no row padding
@@ -202,7 +207,7 @@ __global__ void pack_weight_kernel(const PackArgs a) {
 
 // ------------------------------------------------------------------------------------------ igemm
 struct IgemmArgs {
-    const float* x; const float* wp; const float* bias; const float* gate; float* y;
+    const float* x; const float* wp; const float* bias; const float* gate; const float* res1; const float* res2; float* y;
     int Cin, Hi, Wi, in_ctot, in_coff;
     int Cout, Ho, Wo, out_ctot, out_coff;
     int Cin_pad, Cout_pad, KC, KClog;
@@ -228,16 +233,16 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
 constexpr int MAXE = 6;   // DMA wave-instructions per wave per channel plane (patch <= 1536 floats)
 constexpr int MAXQ = 8;   // 16-byte-DMA wave-instructions per wave per chunk (1x1 layers: KC*PSZ <= 8192 floats)
 
-template <int WM, int WN, int INOP, bool VEC4>
+template <int WVM, int WM, int WN, int INOP, bool VEC4>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
-    constexpr int BM = 64 * WM;                 // output channels per block: 2 waves x WM x 32
+    constexpr int BM = 32 * WM * WVM;           // output channels per block: WVM waves x WM x 32
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // two buffers, each: patch [KC][PSZ] (rows of PW floats, flattened) | weights [ntaps][KC][BM]
     const int wts_off = a.KC * a.PSZ;
     const int buf_sz = a.buf_sz;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WVM, wn = wave / WVM;
     const int j = lane & 31, h = lane >> 5;
 
     const int phase = blockIdx.x % a.nphase, tile = blockIdx.x / a.nphase;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
     const size_t plane = (size_t)a.Hi * a.Wi;
     const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
     // weights: 16-byte pieces, BM/4 lanes per (tap,ci) row of BM co -> 256/BM rows per wave-instruction
-    constexpr int LPR = BM / 4, RPI = 64 / LPR;
+    constexpr int LPR = BM / 4, RPI = 64 / LPR;     // BM = 96: 24 lanes per row, 2 rows + 16 idle lanes per instruction
     const int wrows = g.ntaps * a.KC;
     const int wq = lane % LPR, wr = lane / LPR;
 
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
             row = row < wrows ? row : wrows - 1;                // tail lanes duplicate the last row into the pad rows
             const int t = row >> a.KClog, ci = row & (a.KC - 1);
             const float* src = a.wp + ((size_t)(g.tap_base + t) * a.Cin_pad + cc + ci) * a.Cout_pad + m0 + wq * 4;
-            dma16(src, wdst + r * BM);
+            if (RPI * LPR == 64 || lane < RPI * LPR) dma16(src, wdst + r * BM);
         }
     };
 
@@ -417,6 +422,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
                     float v = acc[m][n][e] + (a.bias ? a.bias[co] : 0.0f);
                     v = apply_act(v, a.act);
                     if (a.gate) v *= gv;
+                    if (a.res1) v += a.res1[((size_t)b * a.Cout + co) * oplane + opix];
+                    if (a.res2) v += a.res2[((size_t)b * a.Cout + co) * oplane + opix];
                     a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
                 }
             }
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
 
 // ------------------------------------------------------------------------------------------ direct
 struct DirectArgs {
-    const float* x; const float* wp; const float* bias; const float* gate; float* y;
+    const float* x; const float* wp; const float* bias; const float* gate; const float* res1; const float* res2; float* y;
     int Cin, Hi, Wi, in_ctot, in_coff;
     int Cout, Ho, Wo, out_ctot, out_coff;
     int in_op, act, gate_ctot, gate_c;
@@ -481,7 +488,12 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectArgs a) {
     }
 #pragma unroll
     for (int o = 0; o < CO; ++o)
-        if (o < a.Cout) a.y[((size_t)b * a.out_ctot + a.out_coff + o) * oplane + opix] = a.gate ? acc[o] * gv : acc[o];
+        if (o < a.Cout) {
+            float v = a.gate ? acc[o] * gv : acc[o];
+            if (a.res1) v += a.res1[((size_t)b * a.Cout + o) * oplane + opix];
+            if (a.res2) v += a.res2[((size_t)b * a.Cout + o) * oplane + opix];
+            a.y[((size_t)b * a.out_ctot + a.out_coff + o) * oplane + opix] = v;
+        }
 }
 
 // ------------------------------------------------------------------------------------------ deconv to <=4 channels
@@ -637,6 +649,7 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     if (launches) *launches = 1;   // all phases ride in one launch
     if (c.direct == 2) return 6;
     if (c.direct) return d->Cout <= 3 ? 0 : 1;
+    if (c.wvm == 1) return c.wm == 1 ? 8 : 9;
     if (c.wm == 2) return c.wn == 4 ? 5 : 7;
     return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
 }
@@ -663,8 +676,16 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
     return masic_launch_status("conv_pack_weight");
 }
 
+extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias, const float* gate,
+                                   const float* res1, const float* res2, float* y, const masic_conv_desc_t* d, void* stream);
+
 extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
                                 float* y, const masic_conv_desc_t* d, void* stream) {
+    return masic_conv2d_fwd_ex(x, w_packed, bias, gate, nullptr, nullptr, y, d, stream);
+}
+
+extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias, const float* gate,
+                                   const float* res1, const float* res2, float* y, const masic_conv_desc_t* d, void* stream) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     MASIC_REQUIRE(x && w_packed && y, MASIC_ERR_ARG, "conv2d_fwd: null pointer");
@@ -675,7 +696,7 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
     const GeomParams q = geom_params(*d);
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     if (c.direct == 2) {
-        MASIC_REQUIRE(gate == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: gate on the small-Cout deconv path");
+        MASIC_REQUIRE(gate == nullptr && res1 == nullptr && res2 == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: gate/residual on the small-Cout deconv path");
         MASIC_REQUIRE(d->Wo % 2 == 0, MASIC_ERR_SHAPE, "conv2d_fwd: odd output width");
         Deconv4Args a{x, (const float*)w_packed, bias, y, d->Cin, c.Cin_pad, d->Hi, d->Wi, d->in_ctot, d->in_coff,
                       d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff, d->act, ceil_div(d->Wi, 16)};
@@ -684,7 +705,7 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
         return masic_launch_status("conv2d_fwd");
     }
     if (c.direct) {
-        DirectArgs a{x, (const float*)w_packed, bias, gate, y,
+        DirectArgs a{x, (const float*)w_packed, bias, gate, res1, res2, y,
                      d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
                      d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                      d->in_op, d->act, d->gate_ctot, d->gate_c, q, np};
@@ -694,27 +715,30 @@ extern "C" int masic_conv2d_fwd(const float* x, const void* w_packed, const floa
         return masic_launch_status("conv2d_fwd");
     }
     {
-        IgemmArgs a{x, (const float*)w_packed, bias, gate, y,
+        IgemmArgs a{x, (const float*)w_packed, bias, gate, res1, res2, y,
                     d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff,
                     d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                     c.Cin_pad, c.Cout_pad, c.KC, c.KClog,
                     c.TW, c.TWlog, c.SR, c.TH, ceil_div(g[0].Wp, c.TW),
                     c.PH, c.PW, c.PWp, c.PSZ, c.buf_sz, c.vec4,
                     d->in_op, d->act, d->gate_ctot, d->gate_c, q, np};
-        dim3 grid(ceil_div(g[0].Wp, c.TW) * ceil_div(g[0].Hp, c.TH) * np, c.Cout_pad / (64 * c.wm), d->B);
-#define IGEMM_LAUNCH(WMV, WNV, OPV, V4) hipLaunchKernelGGL((conv_igemm_f32<WMV, WNV, OPV, V4>), grid, dim3(256), c.lds_bytes, st, a)
-#define IGEMM_BY_OP(WMV, WNV)                                                               \
-    do {                                                                                    \
-        if (d->in_op == MASIC_INOP_ABS) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_ABS, false);      \
-        else if (d->in_op == MASIC_INOP_ROUND) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_ROUND, false); \
-        else if (c.vec4) IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, true);                     \
-        else IGEMM_LAUNCH(WMV, WNV, MASIC_INOP_NONE, false);                                \
+        dim3 grid(ceil_div(g[0].Wp, c.TW) * ceil_div(g[0].Hp, c.TH) * np, c.Cout_pad / (32 * c.wm * c.wvm), d->B);
+#define IGEMM_LAUNCH(WV, WMV, WNV, OPV, V4) \
+    hipLaunchKernelGGL((conv_igemm_f32<WV, WMV, WNV, OPV, V4>), grid, dim3(256), c.lds_bytes, st, a)
+#define IGEMM_BY_OP(WV, WMV, WNV)                                                               \
+    do {                                                                                        \
+        if (d->in_op == MASIC_INOP_ABS) IGEMM_LAUNCH(WV, WMV, WNV, MASIC_INOP_ABS, false);      \
+        else if (d->in_op == MASIC_INOP_ROUND) IGEMM_LAUNCH(WV, WMV, WNV, MASIC_INOP_ROUND, false); \
+        else if (c.vec4) IGEMM_LAUNCH(WV, WMV, WNV, MASIC_INOP_NONE, true);                     \
+        else IGEMM_LAUNCH(WV, WMV, WNV, MASIC_INOP_NONE, false);                                \
     } while (0)
-        if (c.wm == 2 && c.wn == 4) IGEMM_BY_OP(2, 4);
-        else if (c.wm == 2) IGEMM_BY_OP(2, 2);
-        else if (c.wn == 4) IGEMM_BY_OP(1, 4);
-        else if (c.wn == 2) IGEMM_BY_OP(1, 2);
-        else IGEMM_BY_OP(1, 1);
+        if (c.wvm == 1 && c.wm == 1) IGEMM_BY_OP(1, 1, 2);
+        else if (c.wvm == 1) IGEMM_BY_OP(1, 3, 2);
+        else if (c.wm == 2 && c.wn == 4) IGEMM_BY_OP(2, 2, 4);
+        else if (c.wm == 2) IGEMM_BY_OP(2, 2, 2);
+        else if (c.wn == 4) IGEMM_BY_OP(2, 1, 4);
+        else if (c.wn == 2) IGEMM_BY_OP(2, 1, 2);
+        else IGEMM_BY_OP(2, 1, 1);
 #undef IGEMM_BY_OP
 #undef IGEMM_LAUNCH
     }

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
         const int p = (int)(i - bc * HW);
         const int b = (int)(bc / C), c = (int)(bc - (size_t)b * C);
         float v = x[i];
-        v = (mode == 1) ? v + noise[i] : rintf(v);
+        v = (mode == 1) ? v + noise[i] : (mode == 3 ? v : rintf(v));
         if (gate) v *= gate[((size_t)b * gate_ctot + gate_c) * HW + p];
         y[((size_t)b * out_ctot + out_coff + c) * HW + p] = v;
     }
@@ -215,7 +215,7 @@ extern "C" int masic_quantize_fwd(const float* x, const float* noise, const floa
                                   int B, int C, int H, int W, int out_ctot, int out_coff,
                                   int gate_ctot, int gate_c, int mode, void* stream) {
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "quantize_fwd: null pointer");
-    MASIC_REQUIRE(mode == 0 || mode == 1, MASIC_ERR_ARG, "quantize_fwd: mode %d (symbols: use masic_symbols_fwd)", mode);
+    MASIC_REQUIRE(mode == 0 || mode == 1 || mode == 3, MASIC_ERR_ARG, "quantize_fwd: mode %d (symbols: use masic_symbols_fwd)", mode);
     MASIC_REQUIRE(mode != 1 || noise, MASIC_ERR_ARG, "quantize_fwd: noise mode without a noise tensor");
     MASIC_REQUIRE(out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "quantize_fwd: output view out of range");
     const size_t total = (size_t)B * C * H * W;

@@ -54,14 +54,15 @@ class _PackedWeightMixin:
     def invalidate_packed_weight(self):
         self.__dict__.pop("_packed_cache", None)
 
-    def run(self, x, in_coff=0, out=None, out_coff=0, in_op=ops.INOP_NONE, act=ops.ACT_NONE, gate=None, gate_c=0):
+    def run(self, x, in_coff=0, out=None, out_coff=0, in_op=ops.INOP_NONE, act=ops.ACT_NONE, gate=None, gate_c=0,
+            res1=None, res2=None):
         """Fused form: y = act(conv(in_op(x[:, in_coff:in_coff+Cin])) + bias) [* gate[:, gate_c]],
         optionally written into channels [out_coff, out_coff+Cout) of `out` (a torch.cat target)."""
         desc = self._desc(x.shape, in_ctot=x.shape[1], in_coff=in_coff,
                           out_ctot=None if out is None else out.shape[1], out_coff=out_coff,
                           in_op=in_op, act=act, gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
         bias = None if self.bias is None else self.bias.detach()
-        return ops.conv2d(x, self.packed_weight(desc), bias, desc, out=out, gate=gate)
+        return ops.conv2d(x, self.packed_weight(desc), bias, desc, out=out, gate=gate, res1=res1, res2=res2)
 
     def forward(self, x):
         return self.run(x)

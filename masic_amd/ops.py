@@ -65,7 +65,8 @@ class KernelTimer:
     """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
     VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1,1>", 3: "conv_igemm_f32<1,2>",
-                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout", 7: "conv_igemm_f32<2,2>"}
+                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout", 7: "conv_igemm_f32<2,2>",
+                8: "conv_igemm_f32<1w,1,2>", 9: "conv_igemm_f32<1w,3,2>"}
 
     def __init__(self):
         self.records = []
@@ -101,22 +102,22 @@ def conv_algorithmic_work(desc):
     return 2.0 * macs, float(nbytes)
 
 
-def conv2d(x, packed, bias, desc, out=None, gate=None):
+def conv2d(x, packed, bias, desc, out=None, gate=None, res1=None, res2=None):
     if _timer is not None:
         n = ctypes.c_int(0)
         variant = lib.masic_conv_variant(ctypes.byref(desc), ctypes.byref(n))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = _conv2d(x, packed, bias, desc, out, gate)
+        y = _conv2d(x, packed, bias, desc, out, gate, res1, res2)
         e1.record()
         flops, nbytes = conv_algorithmic_work(desc)
         _timer.records.append((variant, n.value, flops, nbytes, e0, e1))
         return y
-    return _conv2d(x, packed, bias, desc, out, gate)
+    return _conv2d(x, packed, bias, desc, out, gate, res1, res2)
 
 
-def _conv2d(x, packed, bias, desc, out=None, gate=None):
+def _conv2d(x, packed, bias, desc, out=None, gate=None, res1=None, res2=None):
     _dev(x, "conv input")
     if x.dim() != 4 or x.shape[0] != desc.B or x.shape[1] != desc.in_ctot or x.shape[2] != desc.Hi or x.shape[3] != desc.Wi:
         raise RuntimeError(f"masic_amd.conv2d: input {tuple(x.shape)} does not match descriptor "
@@ -133,7 +134,13 @@ def _conv2d(x, packed, bias, desc, out=None, gate=None):
             raise RuntimeError(f"masic_amd.conv2d: gate {tuple(gate.shape)} does not match descriptor")
     if bias is not None:
         _dev(bias, "bias")
-    check(lib.masic_conv2d_fwd(_p(x), _p(packed), _p(bias), _p(gate), _p(out), ctypes.byref(desc), _stream()), "conv2d_fwd")
+    for r in (res1, res2):
+        if r is not None:
+            _dev(r, "residual")
+            if tuple(r.shape) != (desc.B, desc.Cout, desc.Ho, desc.Wo):
+                raise RuntimeError(f"masic_amd.conv2d: residual {tuple(r.shape)} does not match the output")
+    check(lib.masic_conv2d_fwd_ex(_p(x), _p(packed), _p(bias), _p(gate), _p(res1), _p(res2), _p(out), ctypes.byref(desc), _stream()),
+          "conv2d_fwd")
     return out
 
 
@@ -150,10 +157,10 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
 
 # --------------------------------------------------------------------------------------------- entropy
 def quantize(x, mode, noise=None, out=None, out_coff=0, gate=None, gate_c=0):
-    """mode: 'dequantize' (round) or 'noise' (x + noise)."""
+    """mode: 'dequantize' (round), 'noise' (x + noise) or 'copy' (identity; for gated writes into a concat slice)."""
     _dev(x, "quantize input")
     B, C, H, W = x.shape
-    m = {"dequantize": 0, "noise": 1}[mode]
+    m = {"dequantize": 0, "noise": 1, "copy": 3}[mode]
     if m == 1:
         _dev(noise, "noise")
         if noise.numel() != x.numel():

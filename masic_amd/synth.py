@@ -26,6 +26,7 @@ _GAINS = {
     "gmm_means.4": 0.5,
     "gmm_weights.4": 1.5,
     "maskconv": 1.5,
+    ".RB": 0.35,                 # CQE residual blocks: keep 9 stacked blocks per view at O(1)
 }
 
 

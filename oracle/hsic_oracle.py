@@ -415,3 +415,53 @@ def rd_loss(out, x1, x2, lmbda):
         "bpp_z1": torch.log(out["likelihoods"]["z1"]).sum() / (-math.log(2) * n),
         "bpp_z2": torch.log(out["likelihoods"]["z2"]).sum() / (-math.log(2) * n),
     }
+
+
+# --------------------------------------------------------------------------- CQE network
+def _residual_block(x, sd, p):
+    """compressai/layers/layers.py:160-190 (in_ch == out_ch: no 1x1 skip)."""
+    t = F.leaky_relu(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1))
+    t = F.leaky_relu(F.conv2d(t, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1))
+    return t + x
+
+
+def _enhancement_block(x, sd, p):
+    """coremasic/mywork/MASIC.py:149-164."""
+    t = _residual_block(x, sd, p + ".RB1")
+    t = _residual_block(t, sd, p + ".RB2")
+    t = _residual_block(t, sd, p + ".RB3")
+    return t + x
+
+
+def mask2weights_en(m, sd, p="mask2weights_unit"):
+    """MASIC.py:1411-1434: four 3x3 s1 convs 1->2->4->4->2, softmax over the 2 gates."""
+    t = F.relu(conv(m, sd, p + ".maskconv.0", k=3, s=1))
+    t = F.relu(conv(t, sd, p + ".maskconv.2", k=3, s=1))
+    t = F.relu(conv(t, sd, p + ".maskconv.4", k=3, s=1))
+    return F.softmax(conv(t, sd, p + ".maskconv.6", k=3, s=1), dim=1)
+
+
+def independent_en_forward(sd, x1_hat, x2_hat, H):
+    """coremasic/mywork/MASIC.py:1456-1501."""
+    h, w = x1_hat.shape[-2:]
+    H_inv = torch.inverse(H)
+    mask_r, mask_l = mask(x1_hat, H)
+    w_r = mask2weights_en(mask_r, sd)
+    w_l = mask2weights_en(mask_l, sd)
+    x1_warp = warp_perspective(x1_hat, H, (h, w))
+    x2_warp = warp_perspective(x2_hat, H_inv, (h, w))
+    c3 = lambda t, n: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], padding=1)
+    x1c, x2c = c3(x1_hat, "conv0"), c3(x2_hat, "conv0")
+    o1 = torch.cat((x2_warp * w_l[:, 0:1], x1_hat * w_l[:, 1:2]), dim=1)
+    o2 = torch.cat((x1_warp * w_r[:, 0:1], x2_hat * w_r[:, 1:2]), dim=1)
+    o1 = _enhancement_block(c3(o1, "conv1"), sd, "EBl1")
+    o2 = _enhancement_block(c3(o2, "conv1"), sd, "EBr1")
+    o1w = warp_perspective(o1, H, (h, w))
+    o2w = warp_perspective(o2, H_inv, (h, w))
+    n1 = torch.cat((o1 * w_l[:, 1:2], o2w * w_l[:, 0:1]), dim=1)
+    n2 = torch.cat((o2 * w_r[:, 1:2], o1w * w_r[:, 0:1]), dim=1)
+    o1 = _enhancement_block(n1, sd, "EBl2")
+    o2 = _enhancement_block(n2, sd, "EBr2")
+    o1 = _enhancement_block(torch.cat((o1, x1c), dim=1), sd, "EBl3")
+    o2 = _enhancement_block(torch.cat((o2, x2c), dim=1), sd, "EBr3")
+    return {"x1_hat": c3(o1, "conv2") + x1_hat, "x2_hat": c3(o2, "conv2") + x2_hat}

@@ -15,6 +15,7 @@ Files
                       outputs (weights regenerated from the seed by masic_amd.synth).
   hsic_c1_digest.json BASELINE config 1 (1x3x256x256, N=128,M=192,K=5): scalar goldens, symbol SHA-256,
                       64 sampled values per output (weights/inputs regenerated from the seed).
+  cqe_small.npz       Independent_EN(), 1x3x64x96: outputs (weights/inputs regenerated from the seed).
   state_keys.json     names/shapes/dtypes of the reference's HSIC(128,192,5).state_dict() (248 tensors)
                       and Independent_EN().state_dict() (86).
   pin_report.json     max |oracle - reference| per tensor for every case above.
@@ -212,6 +213,19 @@ def main():
     dg["y1_tie_margin_min"] = float(fr.min())
     dg["y1_within_1e-4_of_tie"] = int((fr < 1e-4).sum())
     json.dump(dg, open(os.path.join(HERE, "hsic_c1_digest.json"), "w"), indent=1)
+
+    # ------------------------------------------------------------------ Independent_EN (CQE), 1x3x64x96
+    en = R.Independent_EN()
+    en_sd = synth.synth_state_dict(en.state_dict(), seed=5)
+    en.load_state_dict(en_sd)
+    en.eval()
+    xa, xb, Hc = synth.synth_inputs(1, 64, 96, seed=5)
+    with torch.no_grad():
+        eo = en(xa, xb, Hc)
+        oo = O.independent_en_forward(en_sd, xa, xb, Hc)
+    report["cqe_eval"] = {k: maxdiff(eo[k], oo[k]) for k in ("x1_hat", "x2_hat")}
+    np.savez_compressed(os.path.join(HERE, "cqe_small.npz"), seed=np.array(5), BHW=np.array([1, 64, 96]),
+                        x1_hat=eo["x1_hat"].numpy(), x2_hat=eo["x2_hat"].numpy())
 
     # ------------------------------------------------------------------ state-dict key tables
     keys = {"HSIC_128_192_5": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()],

@@ -201,3 +201,16 @@ def test_c_abi_argument_errors_are_reported_not_thrown():
     assert b"output size" in _lib.lib.masic_last_error()
     rc = _lib.lib.masic_gdn_fwd(None, None, None, None, 1, 3, 4, 4, 0, 1e-6, None)
     assert rc == -1 and b"null pointer" in _lib.lib.masic_last_error()
+
+
+def test_oracle_cqe_vs_golden():
+    """Independent_EN (CQE): oracle against the reference's outputs (tests/golden/cqe_small.npz)."""
+    fx = load_npz("cqe_small.npz")
+    B, H, W = (int(v) for v in fx["BHW"])
+    seed = int(fx["seed"])
+    sd = synth.synth_state_dict(MASIC.Independent_EN().state_dict(), seed=seed)
+    xa, xb, hm = synth.synth_inputs(B, H, W, seed=seed)
+    with torch.no_grad():
+        out = O.independent_en_forward(sd, xa, xb, hm)
+    for k in ("x1_hat", "x2_hat"):
+        assert float((out[k] - torch.from_numpy(fx[k])).abs().max()) <= 1e-6 * float(np.abs(fx[k]).max()), k

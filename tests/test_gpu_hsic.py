@@ -258,3 +258,36 @@ def test_batch_independence_and_determinism():
         assert_close(full[k][1:2], one[k], k, rtol=2e-5)     # tile/chunk choice may differ with B: not bitwise
     for k in full["likelihoods"]:
         assert_close(full["likelihoods"][k][1:2], one["likelihoods"][k], k, rtol=2e-5)
+
+
+def test_independent_en_vs_reference_golden():
+    """CQE network: product forward vs the reference's outputs, 1x3x64x96."""
+    import MASIC
+    from masic_amd import synth
+    fx = load_npz("cqe_small.npz")
+    B, H, W = (int(v) for v in fx["BHW"])
+    seed = int(fx["seed"])
+    net = MASIC.Independent_EN()
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=seed))
+    net = net.to(DEV).eval()
+    xa, xb, hm = (t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=seed))
+    with torch.no_grad():
+        out = net(xa, xb, hm)
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], torch.from_numpy(fx[k]), "cqe:" + k)
+
+
+def test_independent_en_batch_and_ragged_vs_oracle():
+    """Two pairs, 96x160 (ragged against the 8x32 pixel tiles), against the CPU oracle."""
+    import MASIC
+    from masic_amd import synth
+    net = MASIC.Independent_EN()
+    sd = synth.synth_state_dict(net.state_dict(), seed=6)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    xa, xb, hm = synth.synth_inputs(2, 96, 160, seed=6)
+    with torch.no_grad():
+        ref = O.independent_en_forward(sd, xa, xb, hm)
+        out = net(xa.to(DEV), xb.to(DEV), hm.to(DEV))
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], ref[k], "cqe2:" + k)
