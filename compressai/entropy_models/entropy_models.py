@@ -50,7 +50,11 @@ class EntropyModel(nn.Module):
         if mode not in ("noise", "dequantize", "symbols"):
             raise ValueError(f'Invalid quantization mode: "{mode}"')
         if mode == "noise":
-            return _hip.quantize(inputs.contiguous(), "noise", noise=self._get_noise_cached(inputs))
+            noise = self._get_noise_cached(inputs)
+            if torch.is_grad_enabled() and inputs.requires_grad:
+                from masic_amd.autograd import AddNoiseFn
+                return AddNoiseFn.apply(inputs, noise)
+            return _hip.quantize(inputs.contiguous(), "noise", noise=noise)
         if mode == "symbols":
             med = None if means is None else means.reshape(-1).contiguous()
             if med is not None and med.numel() != inputs.shape[1]:
@@ -102,12 +106,17 @@ class EntropyBottleneck(EntropyModel):
     def _medians(self):
         return self.quantiles[:, :, 1:2]
 
-    def _table(self):
+    def _table(self, differentiable=False):
+        if differentiable:      # torch.cat is tracked: autograd routes the table gradient back to the 14 parameters
+            return _hip.eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
         return _hip.eb_param_table([m.detach() for m in self._matrices], [b.detach() for b in self._biases],
                                    [f.detach() for f in self._factors])
 
     def loss(self):
         """sum |logits(quantiles) - target| with all density parameters detached (reference :345-348)."""
+        if torch.is_grad_enabled() and self.quantiles.requires_grad:
+            from masic_amd.autograd import AuxLossFn
+            return AuxLossFn.apply(self.quantiles, self._table(), self.tail_mass)
         return _hip.entropy_bottleneck_auxloss(self._table(), self.quantiles.detach().contiguous(), self.tail_mass)
 
     def forward(self, x):
@@ -117,6 +126,10 @@ class EntropyBottleneck(EntropyModel):
             # drawn in the reference's (C, 1, H*W*B) layout (reference :386-394)
             noise = self._get_noise_cached(x.new_empty((C, 1, H * W * B)))
         medians = self.quantiles.detach()[:, 0, 1].contiguous()
+        lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        if self.training and torch.is_grad_enabled() and (x.requires_grad or self._matrices[0].requires_grad):
+            from masic_amd.autograd import EntropyBottleneckFn
+            return EntropyBottleneckFn.apply(x, self._table(differentiable=True), noise, medians, lb)
         return _hip.entropy_bottleneck(x.contiguous(), self._table(), medians, training=self.training, noise=noise,
                                        lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
 
@@ -189,6 +202,12 @@ class GaussianMixtureConditional(_GaussianBase):
 
     def forward(self, inputs, scales, means=None, weights=None, weights_are_logits=False):
         noise = self._get_noise_cached(inputs) if self.training else None
+        lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        if self.training and torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, scales, means, weights)):
+            from masic_amd import autograd as A
+            if not weights_are_logits:
+                raise NotImplementedError("training-mode GMM on pre-normalised weights: pass the head logits (weights_are_logits=True)")
+            return A.GmmFn.apply(inputs, noise, scales, means, weights, self.K, self._scale_bound_value, lb)
         return _hip.gmm_likelihood(inputs.contiguous(), scales.contiguous(), means.contiguous(), weights.contiguous(),
                                    self.K, training=self.training, noise=noise, weights_are_logits=weights_are_logits,
                                    scale_bound=self._scale_bound_value,

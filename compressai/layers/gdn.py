@@ -24,6 +24,9 @@ class GDN(nn.Module):
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.gamma.requires_grad):
+            from masic_amd.autograd import GdnFn
+            return GdnFn.apply(x, self.beta, self.gamma, self.inverse, self.beta_min)
         return _hip.gdn(x, self.beta.detach(), self.gamma.detach(), inverse=self.inverse, beta_min=self.beta_min)
 
 

@@ -26,6 +26,7 @@ from compressai.layers import GDN, MaskedConv2d, ResidualBlock, conv3x3  # noqa:
 from compressai.models.utils import conv, deconv, update_registered_buffers  # noqa: F401
 from masic_amd import ops as _hip
 from masic_amd.homography import warp_matrices as _warp_matrices
+from masic_amd import autograd as _ag
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
 
@@ -250,11 +251,7 @@ class Encoder2(nn.Module):
         self.g_a_conv4 = conv(N, M)
 
     def forward(self, x1_warp, x2):
-        B, _, H, W = x2.shape
-        pair = torch.empty((B, 6, H, W), dtype=x2.dtype, device=x2.device)
-        _hip.copy_view(x1_warp, pair, 0)
-        _hip.copy_view(x2, pair, 3)
-        return self.forward_pair(pair)
+        return self.forward_pair(_ag.cat(x1_warp, x2))
 
     def forward_pair(self, pair):
         t = self.pre_gdn(self.pre_conv(pair))
@@ -284,11 +281,7 @@ class Decoder2(nn.Module):
         t = self.g_s_gdn2(self.g_s_conv2(t))
         t = self.g_s_gdn3(self.g_s_conv3(t))
         t = self.after_gdn(self.g_s_conv4(t))
-        B, _, H, W = t.shape
-        pair = torch.empty((B, 6, H, W), dtype=t.dtype, device=t.device)
-        _hip.copy_view(t, pair, 0)
-        _hip.copy_view(x1_hat_warp, pair, 3)
-        return self.after_conv(pair)
+        return self.after_conv(_ag.cat(t, x1_hat_warp))
 
 
 def mask(im1, H_inv):
@@ -345,7 +338,52 @@ class HSIC(CompressionModel):
         t = seq[2].run(t, act=_LEAKY)
         return seq[4].run(t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
 
+    def _needs_graph(self):
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder1.parameters())
+
+    def _forward_graph(self, x1, x2, h_matrix):
+        """Training-mode forward as a differentiable graph of HIP nodes (masic_amd/autograd.py): same arithmetic and
+        the same 7 noise draws in the same order as the fused path, without the inference-only fusions (writes into
+        concat buffers, gate products in conv epilogues)."""
+        x1 = x1.contiguous()
+        x2 = x2.contiguous()
+        B, _, H, W = x1.shape
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        y1 = self.encoder1(x1)[0]
+        z1 = self._h_a1(y1)
+        z1_hat, z1_lik = self.entropy_bottleneck1(z1)                                   # draw 1
+        params1 = self._hyper_up(self.h_s1_up, z1_hat, None, 0)
+        ctx1 = self.context_prediction1.run(self.gaussian1._quantize(y1, "noise"))     # draw 2
+        s1, m1, l1 = self._h_s1_same_resolution.heads(_ag.cat(params1, ctx1))
+        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)       # draw 3
+        x1_hat = self.decoder1(y1_hat)[0]
+
+        x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
+        y2 = self.encoder2(x1_warp, x2)
+        z2 = self._h_a2(y2)
+        z2_hat, z2_lik = self.entropy_bottleneck2(z2)                                   # draw 4
+        params2 = self._hyper_up(self.h_s2_up, z2_hat, None, 0)
+        ctx2 = self.context_prediction2.run(self.gaussian2._quantize(y2, "noise"))     # draw 5
+        x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
+        gates = self.mask2weights_unit(x1_mask_R)
+        x1_hat_warp = _ag.WarpFn.apply(x1_hat, m_fwd, (H, W))
+        y1_warp = self.encoder1(x1_hat_warp)[0]
+        y1_warp_hat = self.gaussian1._quantize(y1_warp, "noise")                        # draw 6
+        cat2 = _ag.cat(_ag.GateFn.apply(params2, gates, 0), _ag.GateFn.apply(ctx2, gates, 1),
+                       _ag.GateFn.apply(y1_warp_hat, gates, 2))
+        s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
+        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)       # draw 7
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {
+            "x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "z1_hat": z1_hat,
+            "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L,
+            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
+        }
+
     def forward(self, x1, x2, h_matrix):
+        if self._needs_graph():
+            return self._forward_graph(x1, x2, h_matrix)
         M, K = self.M, self.K
         x1 = x1.contiguous()
         x2 = x2.contiguous()

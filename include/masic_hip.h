@@ -171,6 +171,55 @@ size_t masic_reduce_workspace_bytes(void);
 int masic_sum_log(const float* x, size_t n, double* out, void* workspace, void* stream);
 int masic_sse(const float* a, const float* b, size_t n, double* out, void* workspace, void* stream);
 
+/* ==========================================================================================
+ * Backward entry points (what torch autograd derives for the reference graph).
+ * ========================================================================================== */
+
+/* Weight gradient of Conv2d / ConvTranspose2d (same descriptor as the forward layer):
+ *   Conv2d:          dW[co,ci,kh,kw] = sum_{b,oh,ow} dy[b,co,oh,ow] * x[b,ci,oh*s+kh-p,ow*s+kw-p]
+ *   ConvTranspose2d: dW[ci,co,kh,kw] = sum_{b,ih,iw} x[b,ci,ih,iw] * dy[b,co,ih*s+kh-p,iw*s+kw-p]
+ * x is the forward input view (in_ctot/in_coff of desc), dy a contiguous [B,Cout,Ho,Wo] tensor.
+ * Pixel tiles are reduced with float atomics into `workspace` (>= masic_conv2d_wgrad_workspace_bytes(d) bytes,
+ * zero-filled by the call itself with a stream-ordered memset) and then transposed into dw (weight layout).
+ * Input gradients need no entry point of their own: dx of a Conv2d is masic_conv2d_fwd with transposed=1 and
+ * Cin/Cout swapped on the same weight tensor (and vice versa), see masic_amd/autograd.py. */
+size_t masic_conv2d_wgrad_workspace_bytes(const masic_conv_desc_t* d);
+int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, const masic_conv_desc_t* d, void* stream);
+
+/* y = op(a, b) elementwise over n floats; ops (s0,s1 scalars):
+ *   0 act_bwd (a=grad, b=activation output, s0=MASIC_ACT_*)   1 abs_bwd (a=grad, b=x)   2 square   3 abs
+ *   4 axpy s0*a+s1*b (b may be NULL)   5 s0/a   6 s0*(a-b)   7 a*b
+ *   8 reparam max(a,s0)^2-s1 (parametrizers.py:61-64)   9 reparam_bwd (a=grad, b=stored param, s0=bound; incl. LowerBound rule)
+ *   10 a+b */
+int masic_elementwise(const float* a, const float* b, float* y, size_t n, int op, float s0, float s1, void* stream);
+/* out[c] = sum over batch and pixels of channel coff+c of x[B,ctot,HW]  (bias / beta gradients; deterministic) */
+int masic_channel_sum(const float* x, float* out, int B, int C, int HW, int ctot, int coff, void* stream);
+/* y[B,C,HW] = x[B,ctot,HW][:, coff:coff+C]  (backward of copy_view / torch.cat) */
+int masic_slice_copy(const float* x, float* y, int B, int C, int HW, int ctot, int coff, void* stream);
+/* backward of y = x * gate[:,gate_c]: gx = g*gate, ggate[:,gate_c] = sum_c g*x (other gate channels untouched) */
+int masic_gate_bwd(const float* g, const float* x, const float* gate, float* gx, float* ggate,
+                   int B, int C, int HW, int gate_ctot, int gate_c, void* stream);
+int masic_softmax_k_bwd(const float* g, const float* y, float* gx, int B, int M, int K, int HW, void* stream);
+/* GDN backward, elementwise pieces (gdn.py:77-92; the three CxC contractions run on the conv / wgrad kernels):
+ *   pre : s = g*n^(-1/2), t = dL/dn = -1/2 g x n^(-3/2)   (inverse: s = g*n^(1/2), t = +1/2 g x n^(-1/2))
+ *   post: dx = s + 2 x u,  u = gamma^T t */
+int masic_gdn_bwd_pre(const float* x, const float* nrm, const float* g, float* s, float* t, size_t n, int inverse, void* stream);
+int masic_gdn_bwd_post(const float* x, const float* s, const float* u, float* dx, size_t n, void* stream);
+/* GaussianMixtureConditional_gf backward (entropy_models.py:808-858 + both LowerBound rules, bound_ops.py:40-42).
+ * y_hat as returned by the forward; g_yhat may be NULL; weights_are_logits as in the forward. */
+int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,
+                             const float* g_lik, const float* g_yhat, float* g_y, float* g_sigma, float* g_mu,
+                             float* g_w, int B, int M, int K, int H, int W, int weights_are_logits,
+                             float scale_bound, float lik_bound, void* stream);
+/* EntropyBottleneck backward: g_z [B,C,H,W] and g_params [C,58] (same table layout as the forward) */
+int masic_entropy_bottleneck_bwd(const float* z_hat, const float* params, const float* g_lik, const float* g_zhat,
+                                 float* g_z, float* g_params, int B, int C, int H, int W, float lik_bound, void* stream);
+int masic_entropy_bottleneck_auxloss_bwd(const float* params, const float* quantiles, float* g_quantiles,
+                                         int C, double tail_mass, float gout, void* stream);
+/* warp backward w.r.t. the source image; g_src [B,C,Hs,Ws] must be ZERO-FILLED by the caller (float atomics) */
+int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,
+                               int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

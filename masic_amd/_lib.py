@@ -52,6 +52,20 @@ SIGNATURES = {
     "masic_reduce_workspace_bytes": (c_size_t, []),
     "masic_sum_log": (c_int, [_P, c_size_t, _P, _P, _P]),
     "masic_sse": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    # backward
+    "masic_conv2d_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "masic_conv2d_wgrad": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_elementwise": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, c_float, _P]),
+    "masic_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_slice_copy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_gate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_softmax_k_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "masic_gdn_bwd_pre": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, _P]),
+    "masic_gdn_bwd_post": (c_int, [_P, _P, _P, _P, c_size_t, _P]),
+    "masic_gmm_likelihood_bwd": (c_int, [_P] * 10 + [c_int] * 6 + [c_float, c_float, _P]),
+    "masic_entropy_bottleneck_bwd": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
+    "masic_entropy_bottleneck_auxloss_bwd": (c_int, [_P, _P, _P, c_int, c_double, c_float, _P]),
+    "masic_warp_perspective_bwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
 }
 
 

@@ -1,0 +1,307 @@
+"""torch.autograd.Function wrappers: the training-mode graph of the MASIC path, every node a HIP launch.
+
+The reference relies on torch autograd over ATen ops (`loss.backward()` at newtrain_codec_real.py:141).  Here
+each differentiable op of HSIC.forward is a Function whose forward AND backward call the C ABI; torch's autograd
+engine only orders the calls and accumulates parameter gradients (`AccumulateGrad`), so optimizers, DDP hooks and
+`zero_grad` work unchanged.  Formulas: SURVEY.md appendix B (checked there against autograd in float64).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import PREC_F32
+
+PEDESTAL = 2.0 ** -36
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ConvFn(Function):
+    """y = act(conv(x, W) + b) for the module's Conv2d / ConvTranspose2d / MaskedConv2d.
+    dx: the forward kernel run as the opposite layer kind on the same weight tensor (a Conv2d's input gradient is a
+    ConvTranspose2d with Cin/Cout swapped and vice versa); dW: masic_conv2d_wgrad; db: per-channel sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod, act):
+        x = _c(x)
+        y = mod.run(x, act=act)
+        ctx.mod, ctx.act = mod, act
+        ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        mod = ctx.mod
+        g = _c(g)
+        if ctx.act != ops.ACT_NONE:
+            g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=ctx.act)
+        kh, kw, s, p = mod._geometry()
+        B, Cin, Hi, Wi = x.shape
+        Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=PREC_F32)
+            if (d.Ho, d.Wo) != (Hi, Wi):
+                raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
+            gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
+        if ctx.needs_input_grad[1]:
+            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=PREC_F32)
+            gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = ops.channel_sum(g)
+        return gx, gw, gb, None, None
+
+
+def conv(mod, x, act=ops.ACT_NONE):
+    if getattr(mod, "masked_conv", False):
+        mod.zero_masked_taps()
+    return ConvFn.apply(x, mod.weight, mod.bias, mod, act)
+
+
+class GdnFn(Function):
+    """Forward: the fused GDN kernel.  Backward = elementwise pieces + three CxC contractions that
+    reuse the conv kernels: n = gamma^ x^2 + beta^ (1x1 conv), u = gamma^T t (1x1 transposed conv),
+    d gamma^ = t (x^2)^T (1x1 weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_min):
+        x = _c(x)
+        ctx.inverse, ctx.beta_min = inverse, beta_min
+        ctx.save_for_backward(x, beta, gamma)
+        return ops.gdn(x, beta.detach(), gamma.detach(), inverse=inverse, beta_min=beta_min)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, beta, gamma = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = x.shape
+        b_bound = float(torch.tensor((ctx.beta_min + PEDESTAL) ** 0.5, dtype=torch.float32))
+        g_bound = float(torch.tensor(PEDESTAL ** 0.5, dtype=torch.float32))
+        ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))
+        gam = ops.elementwise(ops.EW_REPARAM, gamma.detach().contiguous(), None, g_bound, ped)
+        bet = ops.elementwise(ops.EW_REPARAM, beta.detach().contiguous(), None, b_bound, ped)
+        x2 = ops.elementwise(ops.EW_SQUARE, x)
+        d_f = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0)
+        w4 = gam.view(C, C, 1, 1)
+        nrm = ops.conv2d(x2, ops.pack_conv_weight(w4, d_f), bet, d_f)
+        s, t = ops.gdn_bwd_pre(x, nrm, g, ctx.inverse)
+        d_t = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, transposed=True)
+        u = ops.conv2d(t, ops.pack_conv_weight(w4, d_t), None, d_t)
+        gx = ops.gdn_bwd_post(x, s, u) if ctx.needs_input_grad[0] else None
+        g_gam = ops.conv2d_wgrad(x2, t, d_f, (C, C, 1, 1)).view(C, C)
+        g_bet = ops.channel_sum(t)
+        g_gamma = ops.elementwise(ops.EW_REPARAM_BWD, g_gam, gamma.detach().contiguous(), g_bound)
+        g_beta = ops.elementwise(ops.EW_REPARAM_BWD, g_bet, beta.detach().contiguous(), b_bound)
+        return gx, g_beta, g_gamma, None, None
+
+
+class EntropyBottleneckFn(Function):
+    """training-mode EntropyBottleneck.forward: (z, table[C,58], noise) -> (z + noise, likelihood)."""
+
+    @staticmethod
+    def forward(ctx, z, table, noise, medians, lik_bound):
+        z = _c(z)
+        z_hat, lik = ops.entropy_bottleneck(z, table.detach(), medians, training=True, noise=noise, lik_bound=lik_bound)
+        ctx.lik_bound = lik_bound
+        ctx.save_for_backward(z_hat, table)
+        return z_hat, lik
+
+    @staticmethod
+    def backward(ctx, g_zhat, g_lik):
+        z_hat, table = ctx.saved_tensors
+        g_lik = _c(g_lik) if g_lik is not None else torch.zeros_like(z_hat)
+        g_zhat = _c(g_zhat) if g_zhat is not None else None
+        g_z, g_t = ops.entropy_bottleneck_bwd(z_hat, table.detach(), g_lik, g_zhat, ctx.lik_bound)
+        return g_z, g_t, None, None, None
+
+
+class AuxLossFn(Function):
+    """EntropyBottleneck.loss(): sum |logits(quantiles) - target|, density parameters detached."""
+
+    @staticmethod
+    def forward(ctx, quantiles, table, tail_mass):
+        ctx.tail_mass = tail_mass
+        q = _c(quantiles)
+        ctx.save_for_backward(q, table)
+        return ops.entropy_bottleneck_auxloss(table, q.detach(), tail_mass)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, table = ctx.saved_tensors
+        return ops.entropy_bottleneck_auxloss_bwd(table, q.detach(), float(g), ctx.tail_mass), None, None
+
+
+class GmmFn(Function):
+    """training-mode GaussianMixtureConditional_gf.forward with the softmax over K fused: (y, noise, sigma, mu, logits)."""
+
+    @staticmethod
+    def forward(ctx, y, noise, sigma, mu, logits, K, scale_bound, lik_bound):
+        y, sigma, mu, logits = _c(y), _c(sigma), _c(mu), _c(logits)
+        y_hat, lik = ops.gmm_likelihood(y, sigma, mu, logits, K, training=True, noise=noise, weights_are_logits=True,
+                                        scale_bound=scale_bound, lik_bound=lik_bound)
+        ctx.K, ctx.sb, ctx.lb = K, scale_bound, lik_bound
+        ctx.save_for_backward(y_hat, sigma, mu, logits)
+        return y_hat, lik
+
+    @staticmethod
+    def backward(ctx, g_yhat, g_lik):
+        y_hat, sigma, mu, logits = ctx.saved_tensors
+        g_lik = _c(g_lik) if g_lik is not None else torch.zeros_like(y_hat)
+        g_yhat = _c(g_yhat) if g_yhat is not None else None
+        g_y, g_s, g_m, g_w = ops.gmm_likelihood_bwd(y_hat, sigma, mu, logits, g_lik, g_yhat, ctx.K, True, ctx.sb, ctx.lb)
+        return g_y, None, g_s, g_m, g_w, None, None, None
+
+
+class AddNoiseFn(Function):
+    """_quantize(x, 'noise'): x + U(-1/2,1/2); identity gradient."""
+
+    @staticmethod
+    def forward(ctx, x, noise):
+        return ops.quantize(_c(x), "noise", noise=noise)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class WarpFn(Function):
+    """kornia warp_perspective w.r.t. the source image (h_matrix is detached by every driver)."""
+
+    @staticmethod
+    def forward(ctx, src, minv, dsize):
+        src = _c(src)
+        ctx.src_shape = tuple(src.shape)
+        ctx.save_for_backward(minv)
+        return ops.warp_perspective(src, minv, dsize)
+
+    @staticmethod
+    def backward(ctx, g):
+        (minv,) = ctx.saved_tensors
+        return ops.warp_perspective_bwd(_c(g), minv, ctx.src_shape), None, None
+
+
+class CatFn(Function):
+    """torch.cat along channels: producers' outputs copied into one buffer; backward slices the gradient."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        B, _, H, W = ts[0].shape
+        ctx.sizes = [t.shape[1] for t in ts]
+        out = torch.empty((B, sum(ctx.sizes), H, W), dtype=ts[0].dtype, device=ts[0].device)
+        off = 0
+        for t in ts:
+            ops.copy_view(_c(t), out, off)
+            off += t.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs, off = [], 0
+        for i, c in enumerate(ctx.sizes):
+            outs.append(ops.slice_copy(g, off, c) if ctx.needs_input_grad[i] else None)
+            off += c
+        return tuple(outs)
+
+
+class GateFn(Function):
+    """x * gates[:, c:c+1] (the mask2weights products of MASIC.py:827)."""
+
+    @staticmethod
+    def forward(ctx, x, gates, c):
+        x, gates = _c(x), _c(gates)
+        ctx.c = c
+        ctx.save_for_backward(x, gates)
+        return ops.quantize(x, "copy", gate=gates, gate_c=c)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gates = ctx.saved_tensors
+        gx, gg = ops.gate_bwd(_c(g), x, gates, ctx.c)
+        return gx, gg, None
+
+
+class AbsFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.elementwise(ops.EW_ABS, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.elementwise(ops.EW_ABS_BWD, _c(g), x)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.elementwise(ops.EW_ADD, _c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def cat(*ts):
+    """torch.cat(dim=1) on the HIP path; differentiable when any input needs a gradient."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        return CatFn.apply(*ts)
+    B, _, H, W = ts[0].shape
+    out = torch.empty((B, sum(t.shape[1] for t in ts), H, W), dtype=ts[0].dtype, device=ts[0].device)
+    off = 0
+    for t in ts:
+        ops.copy_view(_c(t), out, off)
+        off += t.shape[1]
+    return out
+
+
+class SoftmaxKFn(Function):
+    """softmax over K on the (B,K,M,H,W) view (MASIC.py:389-393; K=3, M=1 for the mask2weights gates)."""
+
+    @staticmethod
+    def forward(ctx, x, K):
+        y = ops.softmax_k(_c(x), K)
+        ctx.K = K
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_k_bwd(_c(g), y, ctx.K), None
+
+
+class RateDistortionFn(Function):
+    """loss = lmbda*255^2*(MSE(x1_hat,x1)+MSE(x2_hat,x2)) + sum_t sum(log lik_t)/(-ln2*B*H*W)
+    (newtrain_codec_real.py:73-87) as one node: six device reductions forward, six elementwise kernels backward."""
+
+    @staticmethod
+    def forward(ctx, lmbda, x1, x2, x1_hat, x2_hat, *liks):
+        x1, x2, x1_hat, x2_hat = _c(x1), _c(x2), _c(x1_hat), _c(x2_hat)
+        liks = [_c(l) for l in liks]
+        B, _, H, W = x1.shape
+        ctx.cb = 1.0 / (-math.log(2) * B * H * W)
+        ctx.cm = lmbda * 255 ** 2
+        bpp = sum(ops.sum_log(l) for l in liks) * ctx.cb
+        mse1 = ops.sse(x1_hat, x1) / x1.numel()
+        mse2 = ops.sse(x2_hat, x2) / x2.numel()
+        ctx.save_for_backward(x1, x2, x1_hat, x2_hat, *liks)
+        ctx.aux = (bpp, mse1, mse2)
+        return (ctx.cm * (mse1 + mse2) + bpp).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, x1_hat, x2_hat, *liks = ctx.saved_tensors
+        gs = float(g)
+        g1 = ops.elementwise(ops.EW_DIFF_SCALE, x1_hat, x1, s0=gs * ctx.cm * 2.0 / x1.numel())
+        g2 = ops.elementwise(ops.EW_DIFF_SCALE, x2_hat, x2, s0=gs * ctx.cm * 2.0 / x2.numel())
+        gl = [ops.elementwise(ops.EW_RECIP_SCALE, l, None, s0=gs * ctx.cb) for l in liks]
+        return (None, None, None, g1, g2, *gl)

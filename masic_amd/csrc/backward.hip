@@ -1,0 +1,510 @@
+// backward.hip -- backward kernels of the MASIC hot path that are not contractions (gfx950).
+//
+// What torch autograd derives for the reference's graph, written out per op:
+//   * activation / abs / gate / softmax-over-K backward, per-channel sums (bias, beta gradients)
+//   * GDN elementwise pieces (the three 128x128 contractions of its backward reuse the conv / wgrad kernels)
+//   * GaussianMixtureConditional_gf backward incl. both LowerBound rules (compressai/ops/bound_ops.py:40-42) and the
+//     softmax over K (coremasic/mywork/MASIC.py:389-393)
+//   * EntropyBottleneck backward (entropy_models.py:350-411): inputs and all 58 per-channel density parameters
+//   * perspective-warp backward w.r.t. the source image (scatter-add of the 4 bilinear taps)
+// All are HBM-bound elementwise kernels; the two with cross-element sums (channel sums, EB parameter gradients)
+// reduce inside a workgroup and write one result per channel: deterministic, no atomics. The warp backward
+// scatters with float atomics (order-dependent in the last bits, like torch's grid_sample backward on GPUs).
+#include "common.h"
+
+namespace {
+
+int grid_for(size_t total, int cap = 8192) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g == 0 ? 1 : g));
+}
+
+// ---------------------------------------------------------------------------- elementwise
+enum { EW_ACT_BWD = 0, EW_ABS_BWD = 1, EW_SQUARE = 2, EW_ABS = 3, EW_AXPY = 4, EW_RECIP_SCALE = 5, EW_DIFF_SCALE = 6,
+       EW_MUL = 7, EW_REPARAM = 8, EW_REPARAM_BWD = 9, EW_ADD = 10 };
+
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                 size_t n, int op, float s0, float s1) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float r;
+        switch (op) {
+            case EW_ACT_BWD: {      // a = grad wrt activation output, b = activation output, s0 = act code
+                const float yv = b[i];
+                const int act = (int)s0;
+                r = act == MASIC_ACT_RELU ? (yv > 0.0f ? a[i] : 0.0f) : (act == MASIC_ACT_LEAKY ? (yv > 0.0f ? a[i] : 0.01f * a[i]) : a[i]);
+                break;
+            }
+            case EW_ABS_BWD: { const float xv = b[i]; r = xv > 0.0f ? a[i] : (xv < 0.0f ? -a[i] : 0.0f); break; }
+            case EW_SQUARE: r = a[i] * a[i]; break;
+            case EW_ABS: r = fabsf(a[i]); break;
+            case EW_AXPY: r = s0 * a[i] + (b ? s1 * b[i] : 0.0f); break;
+            case EW_RECIP_SCALE: r = s0 / a[i]; break;                     // d (c * sum log x) / dx = c / x
+            case EW_DIFF_SCALE: r = s0 * (a[i] - b[i]); break;             // d sse: 2 c (a - b)
+            case EW_MUL: r = a[i] * b[i]; break;
+            case EW_REPARAM: { const float v = fmaxf(a[i], s0); r = v * v - s1; break; }           // parametrizers.py:61-64
+            case EW_REPARAM_BWD: {  // a = grad wrt reparametrised value, b = stored parameter, s0 = bound
+                const float p = b[i], g = a[i] * 2.0f * fmaxf(p, s0);
+                r = (p >= s0 || g < 0.0f) ? g : 0.0f;
+                break;
+            }
+            default: r = a[i] + b[i]; break;
+        }
+        y[i] = r;
+    }
+}
+
+// per-channel sum over batch and pixels: out[c] = sum_{b,p} x[b,c,p]   (bias / beta gradients); one block per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int B, int C, int HW, int ctot, int coff) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* p = x + ((size_t)b * ctot + coff + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) acc += (double)p[i];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+
+// slice of a wider buffer -> contiguous (the backward of copy_view / torch.cat)
+__global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
+                                                         int ctot, int coff, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t bc = i / HW;
+        const int p = (int)(i - bc * HW);
+        const int b = (int)(bc / C), c = (int)(bc - (size_t)b * C);
+        y[i] = x[((size_t)b * ctot + coff + c) * HW + p];
+    }
+}
+
+// gate product backward: gx = g * gate[b,gc,p];  ggate[b,p] = sum_c g[b,c,p] * x[b,c,p]
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                       const float* __restrict__ gate, float* __restrict__ gx,
+                                                       float* __restrict__ ggate, int B, int C, int HW, int gate_ctot, int gate_c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // over B*HW
+    if (i >= (size_t)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (size_t)b * HW);
+    const float gv = gate[((size_t)b * gate_ctot + gate_c) * HW + p];
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const size_t k = ((size_t)b * C + c) * HW + p;
+        const float gg = g[k];
+        gx[k] = gg * gv;
+        acc = fmaf(gg, x[k], acc);
+    }
+    ggate[((size_t)b * gate_ctot + gate_c) * HW + p] = acc;
+}
+
+// softmax over K on the (B,K,M,HW) view, backward: gx_k = y_k (g_k - sum_j g_j y_j)
+__global__ __launch_bounds__(256) void softmax_k_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            float* __restrict__ gx, int M, int K, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t bm = i / HW;
+    const int p = (int)(i - bm * HW);
+    const int b = (int)(bm / M), m = (int)(bm - (size_t)b * M);
+    const size_t base = ((size_t)b * K * M + m) * HW + p, ks = (size_t)M * HW;
+    float dot = 0.0f;
+    for (int k = 0; k < K; ++k) dot = fmaf(g[base + k * ks], y[base + k * ks], dot);
+    for (int k = 0; k < K; ++k) gx[base + k * ks] = y[base + k * ks] * (g[base + k * ks] - dot);
+}
+
+// ---------------------------------------------------------------------------- GDN pieces
+// given x, n = beta^ + gamma^ x^2 and g = dL/dy:  s = g * n^(-1/2) [inverse: g * n^(1/2)],
+// t = dL/dn = -1/2 g x n^(-3/2)   [inverse: +1/2 g x n^(-1/2)]
+__global__ __launch_bounds__(256) void gdn_bwd_pre_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
+                                                          const float* __restrict__ g, float* __restrict__ s,
+                                                          float* __restrict__ t, size_t n, int inverse) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float nv = nrm[i], r = sqrtf(nv), gv = g[i], xv = x[i];
+        if (inverse) { s[i] = gv * r; t[i] = 0.5f * gv * xv / r; }
+        else { s[i] = gv / r; t[i] = -0.5f * gv * xv / (nv * r); }
+    }
+}
+// dx = s + 2 x u
+__global__ __launch_bounds__(256) void gdn_bwd_post_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                           const float* __restrict__ u, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dx[i] = fmaf(2.0f * x[i], u[i], s[i]);
+}
+
+// ---------------------------------------------------------------------------- Gaussian mixture backward
+__device__ __forceinline__ float norm_pdf(float t) { return 0.3989422804014327f * expf(-0.5f * t * t); }
+
+template <int K>
+__global__ __launch_bounds__(256) void gmm_bwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ sigma,
+                                                      const float* __restrict__ mu, const float* __restrict__ wts,
+                                                      const float* __restrict__ g_lik, const float* __restrict__ g_yhat,
+                                                      float* __restrict__ g_y, float* __restrict__ g_sigma,
+                                                      float* __restrict__ g_mu, float* __restrict__ g_w,
+                                                      int M, int HW, int logits, float scale_bound, float lik_bound, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t bm = i / HW;
+    const int p = (int)(i - bm * HW);
+    const int b = (int)(bm / M), m = (int)(bm - (size_t)b * M);
+    const size_t base = ((size_t)b * K * M + m) * HW + p, ks = (size_t)M * HW;
+    const float yv = y_hat[i];
+    float wk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wk[k] = wts[base + k * ks];
+    if (logits) {
+        float mx = wk[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, wk[k]);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { wk[k] = expf(wk[k] - mx); s += wk[k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k] = wk[k] / s;
+    }
+    const float cst = -0.70710678118654752440f;
+    float lik = 0.0f, dcdf[K], dsig[K], dv[K], sgn[K];
+    bool sig_ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float sraw = sigma[base + k * ks];
+        const float s = fmaxf(sraw, scale_bound);
+        const float d = yv - mu[base + k * ks];
+        const float v = fabsf(d);
+        const float ta = (0.5f - v) / s, tb = (-0.5f - v) / s;
+        const float up = 0.5f * erfcf(cst * ta), lo = 0.5f * erfcf(cst * tb);
+        const float pa = norm_pdf(ta), pb = norm_pdf(tb);
+        dcdf[k] = up - lo;                                  // dL/dw_k
+        dsig[k] = wk[k] * (tb * pb - ta * pa) / s;          // dL/ds_k
+        dv[k] = -wk[k] * (pa - pb) / s;                     // dL/dv_k
+        sgn[k] = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        sig_ok[k] = sraw >= scale_bound;
+        lik += dcdf[k] * wk[k];
+    }
+    // LowerBound(lik, 1e-9): pass if lik >= bound or the gradient is negative
+    float g = g_lik[i];
+    g = (lik >= lik_bound || g < 0.0f) ? g : 0.0f;
+    float gy = 0.0f, gw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float gs = g * dsig[k];
+        g_sigma[base + k * ks] = (sig_ok[k] || gs < 0.0f) ? gs : 0.0f;      // LowerBound(sigma, 0.11)
+        const float gv = g * dv[k] * sgn[k];
+        g_mu[base + k * ks] = -gv;
+        gy += gv;
+        gw[k] = g * dcdf[k];
+    }
+    if (logits) {       // through the softmax over K
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) dot = fmaf(gw[k], wk[k], dot);
+#pragma unroll
+        for (int k = 0; k < K; ++k) gw[k] = wk[k] * (gw[k] - dot);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) g_w[base + k * ks] = gw[k];
+    g_y[i] = gy + (g_yhat ? g_yhat[i] : 0.0f);               // y_hat = y + noise: identity
+}
+
+// ---------------------------------------------------------------------------- EntropyBottleneck backward
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+struct EbRaw { float m[33], b[13], f[12]; };     // raw parameters of one channel (table row)
+
+// forward of the cumulative-logits net at x, keeping what the backward needs; returns logits
+struct EbTape { float pre[4][3], th[4][3], in[5][3]; };   // pre-activation s, tanh(s), layer inputs
+
+__device__ __forceinline__ float eb_forward_tape(const float* M /*softplus*/, const float* Bv, const float* F /*tanh(f)*/,
+                                                 float x, EbTape& tp) {
+    float v[3];
+    tp.in[0][0] = x;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s = M[i] * x + Bv[i];
+        tp.pre[0][i] = s; tp.th[0][i] = tanhf(s);
+        v[i] = s + F[i] * tp.th[0][i];
+    }
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+        float o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tp.in[l][i] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float* mr = M + 3 + 9 * (l - 1) + 3 * i;
+            float s = mr[0] * v[0];
+            s = fmaf(mr[1], v[1], s);
+            s = fmaf(mr[2], v[2], s);
+            s += Bv[3 * l + i];
+            tp.pre[l][i] = s; tp.th[l][i] = tanhf(s);
+            o[i] = s + F[3 * l + i] * tp.th[l][i];
+        }
+        v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tp.in[4][i] = v[i];
+    float s = M[30] * v[0];
+    s = fmaf(M[31], v[1], s);
+    s = fmaf(M[32], v[2], s);
+    return s + Bv[12];
+}
+
+// backward of the net: accumulates d/d(softplus(M)), d/db, d/d(tanh f) into gM,gB,gF scaled by `gout`; returns d/dx
+__device__ __forceinline__ float eb_backward_tape(const float* M, const float* F, const EbTape& tp, float gout,
+                                                  float* gM, float* gB, float* gF) {
+    float gv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { gM[30 + j] += gout * tp.in[4][j]; gv[j] = gout * M[30 + j]; }
+    gB[12] += gout;
+#pragma unroll
+    for (int l = 3; l >= 1; --l) {
+        float gin[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float th = tp.th[l][i];
+            gF[3 * l + i] += gv[i] * th;
+            const float gs = gv[i] * (1.0f + F[3 * l + i] * (1.0f - th * th));
+            gB[3 * l + i] += gs;
+            const float* mr = M + 3 + 9 * (l - 1) + 3 * i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gM[3 + 9 * (l - 1) + 3 * i + j] += gs * tp.in[l][j];
+                gin[j] = fmaf(gs, mr[j], gin[j]);
+            }
+        }
+        gv[0] = gin[0]; gv[1] = gin[1]; gv[2] = gin[2];
+    }
+    float gx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float th = tp.th[0][i];
+        gF[i] += gv[i] * th;
+        const float gs = gv[i] * (1.0f + F[i] * (1.0f - th * th));
+        gB[i] += gs;
+        gM[i] += gs * tp.in[0][0];
+        gx = fmaf(gs, M[i], gx);
+    }
+    return gx;
+}
+
+// one workgroup per channel: every element of the channel, parameter gradients reduced in LDS (deterministic)
+__global__ __launch_bounds__(256) void eb_bwd_kernel(const float* __restrict__ z_hat, const float* __restrict__ params,
+                                                     const float* __restrict__ g_lik, const float* __restrict__ g_zhat,
+                                                     float* __restrict__ g_z, float* __restrict__ g_params,
+                                                     int B, int C, int HW, float lik_bound) {
+    const int c = blockIdx.x;
+    const float* row = params + (size_t)c * MASIC_EB_PARAMS_PER_CHANNEL;
+    float M[33], Bv[13], F[12];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) M[i] = softplusf_(row[i]);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) Bv[i] = row[33 + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) F[i] = tanhf(row[46 + i]);
+    float gM[33], gB[13], gF[12];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) gM[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) gB[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gF[i] = 0.0f;
+
+    const int per = B * HW;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int b = e / HW, p = e - b * HW;
+        const size_t idx = ((size_t)b * C + c) * HW + p;
+        const float v = z_hat[idx];
+        EbTape tl, tu;
+        const float lower = eb_forward_tape(M, Bv, F, v - 0.5f, tl);
+        const float upper = eb_forward_tape(M, Bv, F, v + 0.5f, tu);
+        const float sum = lower + upper;
+        const float sign = sum > 0.0f ? -1.0f : (sum < 0.0f ? 1.0f : 0.0f);
+        const float su = sigmoidf_(sign * upper), sl = sigmoidf_(sign * lower);
+        const float diff = su - sl, lik = fabsf(diff);
+        float g = g_lik[idx];
+        g = (lik >= lik_bound || g < 0.0f) ? g : 0.0f;                       // LowerBound(lik, 1e-9)
+        const float gd = g * (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+        const float gu = gd * su * (1.0f - su) * sign;
+        const float gl = -gd * sl * (1.0f - sl) * sign;
+        float gx = eb_backward_tape(M, F, tu, gu, gM, gB, gF);
+        gx += eb_backward_tape(M, F, tl, gl, gM, gB, gF);
+        g_z[idx] = gx + (g_zhat ? g_zhat[idx] : 0.0f);                       // z_hat = z + noise: identity
+    }
+    // chain to the raw parameters: softplus' = sigmoid(raw), tanh' = 1 - tanh^2
+#pragma unroll
+    for (int i = 0; i < 33; ++i) gM[i] *= sigmoidf_(row[i]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gF[i] *= (1.0f - F[i] * F[i]);
+    __shared__ float red[256];
+    auto reduce_store = [&](float val, int slot) {
+        red[threadIdx.x] = val;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) g_params[(size_t)c * MASIC_EB_PARAMS_PER_CHANNEL + slot] = red[0];
+        __syncthreads();
+    };
+#pragma unroll
+    for (int i = 0; i < 33; ++i) reduce_store(gM[i], i);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) reduce_store(gB[i], 33 + i);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) reduce_store(gF[i], 46 + i);
+}
+
+// aux loss backward: d/d quantiles of sum |logits(q) - target| (all density parameters detached)
+__global__ __launch_bounds__(256) void eb_auxloss_bwd_kernel(const float* __restrict__ params, const float* __restrict__ quantiles,
+                                                             float* __restrict__ g_q, int C, float target, float gout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * 3) return;
+    const int c = i / 3, q = i - 3 * c;
+    const float* row = params + (size_t)c * MASIC_EB_PARAMS_PER_CHANNEL;
+    float M[33], Bv[13], F[12];
+    for (int k = 0; k < 33; ++k) M[k] = softplusf_(row[k]);
+    for (int k = 0; k < 13; ++k) Bv[k] = row[33 + k];
+    for (int k = 0; k < 12; ++k) F[k] = tanhf(row[46 + k]);
+    EbTape tp;
+    const float lg = eb_forward_tape(M, Bv, F, quantiles[i], tp);
+    const float t = q == 0 ? -target : (q == 1 ? 0.0f : target);
+    const float d = lg - t;
+    const float gs = gout * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+    float gM[33] = {0}, gB[13] = {0}, gF[12] = {0};
+    g_q[i] = eb_backward_tape(M, F, tp, gs, gM, gB, gF);
+}
+
+// ---------------------------------------------------------------------------- warp backward (w.r.t. the source)
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ g_dst, const float* __restrict__ minv,
+                                                       float* __restrict__ g_src, int C, int Hs, int Ws, int Hd, int Wd) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hd * Wd) return;
+    const int oy = pix / Wd, ox = pix - oy * Wd;
+    const float* m = minv + b * 9;
+    const float gx = __fmul_rn(__fsub_rn(__fdiv_rn((float)ox, (float)(Wd - 1)), 0.5f), 2.0f);
+    const float gy = __fmul_rn(__fsub_rn(__fdiv_rn((float)oy, (float)(Hd - 1)), 0.5f), 2.0f);
+    const float X = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[0]), __fmul_rn(gy, m[1])), m[2]);
+    const float Y = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[3]), __fmul_rn(gy, m[4])), m[5]);
+    const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
+    const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
+    const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
+    const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(Ws - 1), 2.0f));
+    const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(Hs - 1), 2.0f));
+    if (!(fx == fx) || !(fy == fy)) return;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
+    const float lim = 1.0e9f;
+    const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Ws, vx1 = x1 >= 0 && x1 < Ws, vy0 = y0 >= 0 && y0 < Hs, vy1 = y1 >= 0 && y1 < Hs;
+    const size_t splane = (size_t)Hs * Ws, dplane = (size_t)Hd * Wd;
+    for (int c = 0; c < C; ++c) {
+        const float g = g_dst[((size_t)b * C + c) * dplane + pix];
+        float* s = g_src + ((size_t)b * C + c) * splane;
+        if (vx0 && vy0) atomicAdd(s + (size_t)y0 * Ws + x0, g * ex * ey);
+        if (vx1 && vy0) atomicAdd(s + (size_t)y0 * Ws + x1, g * wx * ey);
+        if (vx0 && vy1) atomicAdd(s + (size_t)y1 * Ws + x0, g * ex * wy);
+        if (vx1 && vy1) atomicAdd(s + (size_t)y1 * Ws + x1, g * wx * wy);
+    }
+}
+
+}  // namespace
+
+extern "C" int masic_elementwise(const float* a, const float* b, float* y, size_t n, int op, float s0, float s1, void* stream) {
+    MASIC_REQUIRE(a && y, MASIC_ERR_ARG, "elementwise: null pointer");
+    MASIC_REQUIRE(op >= 0 && op <= EW_ADD, MASIC_ERR_ARG, "elementwise: op %d", op);
+    hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, op, s0, s1);
+    return masic_launch_status("elementwise");
+}
+
+extern "C" int masic_channel_sum(const float* x, float* out, int B, int C, int HW, int ctot, int coff, void* stream) {
+    MASIC_REQUIRE(x && out, MASIC_ERR_ARG, "channel_sum: null pointer");
+    MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "channel_sum: view out of range");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW, ctot, coff);
+    return masic_launch_status("channel_sum");
+}
+
+extern "C" int masic_slice_copy(const float* x, float* y, int B, int C, int HW, int ctot, int coff, void* stream) {
+    MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "slice_copy: null pointer");
+    MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "slice_copy: view out of range");
+    const size_t total = (size_t)B * C * HW;
+    hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, ctot, coff, total);
+    return masic_launch_status("slice_copy");
+}
+
+extern "C" int masic_gate_bwd(const float* g, const float* x, const float* gate, float* gx, float* ggate,
+                              int B, int C, int HW, int gate_ctot, int gate_c, void* stream) {
+    MASIC_REQUIRE(g && x && gate && gx && ggate, MASIC_ERR_ARG, "gate_bwd: null pointer");
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)(((size_t)B * HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       g, x, gate, gx, ggate, B, C, HW, gate_ctot, gate_c);
+    return masic_launch_status("gate_bwd");
+}
+
+extern "C" int masic_softmax_k_bwd(const float* g, const float* y, float* gx, int B, int M, int K, int HW, void* stream) {
+    MASIC_REQUIRE(g && y && gx, MASIC_ERR_ARG, "softmax_k_bwd: null pointer");
+    const size_t total = (size_t)B * M * HW;
+    hipLaunchKernelGGL(softmax_k_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, y, gx, M, K, HW, total);
+    return masic_launch_status("softmax_k_bwd");
+}
+
+extern "C" int masic_gdn_bwd_pre(const float* x, const float* nrm, const float* g, float* s, float* t, size_t n, int inverse, void* stream) {
+    MASIC_REQUIRE(x && nrm && g && s && t, MASIC_ERR_ARG, "gdn_bwd_pre: null pointer");
+    hipLaunchKernelGGL(gdn_bwd_pre_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, nrm, g, s, t, n, inverse);
+    return masic_launch_status("gdn_bwd_pre");
+}
+
+extern "C" int masic_gdn_bwd_post(const float* x, const float* s, const float* u, float* dx, size_t n, void* stream) {
+    MASIC_REQUIRE(x && s && u && dx, MASIC_ERR_ARG, "gdn_bwd_post: null pointer");
+    hipLaunchKernelGGL(gdn_bwd_post_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, s, u, dx, n);
+    return masic_launch_status("gdn_bwd_post");
+}
+
+extern "C" int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,
+                                        const float* g_lik, const float* g_yhat, float* g_y, float* g_sigma, float* g_mu,
+                                        float* g_w, int B, int M, int K, int H, int W, int weights_are_logits,
+                                        float scale_bound, float lik_bound, void* stream) {
+    MASIC_REQUIRE(y_hat && sigma && mu && wts && g_lik && g_y && g_sigma && g_mu && g_w, MASIC_ERR_ARG, "gmm_likelihood_bwd: null pointer");
+    MASIC_REQUIRE(K >= 1 && K <= 8, MASIC_ERR_UNSUPPORTED, "gmm_likelihood_bwd: K=%d", K);
+    const size_t total = (size_t)B * M * H * W;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GMMB_CASE(KK)                                                                                                       \
+    case KK:                                                                                                                \
+        hipLaunchKernelGGL(gmm_bwd_kernel<KK>, grid, blk, 0, st, y_hat, sigma, mu, wts, g_lik, g_yhat, g_y, g_sigma, g_mu,  \
+                           g_w, M, H * W, weights_are_logits, scale_bound, lik_bound, total);                               \
+        break;
+    switch (K) { GMMB_CASE(1) GMMB_CASE(2) GMMB_CASE(3) GMMB_CASE(4) GMMB_CASE(5) GMMB_CASE(6) GMMB_CASE(7) GMMB_CASE(8) }
+#undef GMMB_CASE
+    return masic_launch_status("gmm_likelihood_bwd");
+}
+
+extern "C" int masic_entropy_bottleneck_bwd(const float* z_hat, const float* params, const float* g_lik, const float* g_zhat,
+                                            float* g_z, float* g_params, int B, int C, int H, int W, float lik_bound, void* stream) {
+    MASIC_REQUIRE(z_hat && params && g_lik && g_z && g_params, MASIC_ERR_ARG, "entropy_bottleneck_bwd: null pointer");
+    hipLaunchKernelGGL(eb_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, z_hat, params, g_lik, g_zhat, g_z, g_params,
+                       B, C, H * W, lik_bound);
+    return masic_launch_status("entropy_bottleneck_bwd");
+}
+
+extern "C" int masic_entropy_bottleneck_auxloss_bwd(const float* params, const float* quantiles, float* g_quantiles,
+                                                    int C, double tail_mass, float gout, void* stream) {
+    MASIC_REQUIRE(params && quantiles && g_quantiles, MASIC_ERR_ARG, "entropy_bottleneck_auxloss_bwd: null pointer");
+    const float target = (float)__builtin_log(2.0 / tail_mass - 1.0);
+    hipLaunchKernelGGL(eb_auxloss_bwd_kernel, dim3(ceil_div(C * 3, 256)), dim3(256), 0, (hipStream_t)stream, params, quantiles,
+                       g_quantiles, C, target, gout);
+    return masic_launch_status("entropy_bottleneck_auxloss_bwd");
+}
+
+extern "C" int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,
+                                          int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream) {
+    MASIC_REQUIRE(g_dst && minv_norm && g_src, MASIC_ERR_ARG, "warp_perspective_bwd: null pointer");
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(Hd * Wd, 256), B), dim3(256), 0, (hipStream_t)stream, g_dst, minv_norm,
+                       g_src, C, Hs, Ws, Hd, Wd);
+    return masic_launch_status("warp_perspective_bwd");
+}

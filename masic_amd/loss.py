@@ -22,6 +22,15 @@ class RateDistortionLoss:
 
 
 def rate_distortion(output, target1, target2, lmbda):
+    import torch
+    liks = output["likelihoods"]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (output["x1_hat"], output["x2_hat"], *liks.values())):
+        from .autograd import RateDistortionFn
+        loss = RateDistortionFn.apply(lmbda, target1, target2, output["x1_hat"], output["x2_hat"], *liks.values())
+        with torch.no_grad():
+            rest = rate_distortion(output, target1, target2, lmbda)
+        rest["loss"] = loss
+        return rest
     B, _, H, W = target1.shape
     num_pixels = B * H * W
     per = {k: ops.sum_log(v.contiguous()) / (-math.log(2) * num_pixels) for k, v in output["likelihoods"].items()}

@@ -57,12 +57,37 @@ class _PackedWeightMixin:
     def run(self, x, in_coff=0, out=None, out_coff=0, in_op=ops.INOP_NONE, act=ops.ACT_NONE, gate=None, gate_c=0,
             res1=None, res2=None):
         """Fused form: y = act(conv(in_op(x[:, in_coff:in_coff+Cin])) + bias) [* gate[:, gate_c]],
-        optionally written into channels [out_coff, out_coff+Cout) of `out` (a torch.cat target)."""
+        optionally written into channels [out_coff, out_coff+Cout) of `out` (a torch.cat target).
+        When autograd needs this node the same arithmetic is composed from differentiable HIP nodes instead
+        (masic_amd/autograd.py)."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return self._run_autograd(x, in_coff, out, in_op, act, gate, gate_c, res1, res2)
         desc = self._desc(x.shape, in_ctot=x.shape[1], in_coff=in_coff,
                           out_ctot=None if out is None else out.shape[1], out_coff=out_coff,
                           in_op=in_op, act=act, gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
         bias = None if self.bias is None else self.bias.detach()
         return ops.conv2d(x, self.packed_weight(desc), bias, desc, out=out, gate=gate, res1=res1, res2=res2)
+
+    def _run_autograd(self, x, in_coff, out, in_op, act, gate, gate_c, res1, res2):
+        from . import autograd as A
+        if out is not None:
+            raise RuntimeError("masic_amd: writing into a concat buffer is an inference-only fusion; use autograd.CatFn when training")
+        if in_coff != 0 or x.shape[1] != self.in_channels:
+            raise RuntimeError("masic_amd: channel-slice inputs are an inference-only fusion")
+        if in_op == ops.INOP_ABS:
+            x = A.AbsFn.apply(x)
+        elif in_op != ops.INOP_NONE:
+            raise RuntimeError("masic_amd: round() inputs have no gradient path (eval-mode fusion)")
+        if act == ops.ACT_SOFTMAX_C:
+            y = A.SoftmaxKFn.apply(A.conv(self, x), self.out_channels)
+        else:
+            y = A.conv(self, x, act)
+        if gate is not None:
+            y = A.GateFn.apply(y, gate, gate_c)
+        for r in (res1, res2):
+            if r is not None:
+                y = A.AddFn.apply(y, r)
+        return y
 
     def forward(self, x):
         return self.run(x)

@@ -344,3 +344,120 @@ def sse(a, b):
     out = torch.empty(1, dtype=torch.float64, device=a.device)
     check(lib.masic_sse(_p(a), _p(b), a.numel(), _p(out), _p(_workspace(a.device)), _stream()), "sse")
     return out[0]
+
+
+# --------------------------------------------------------------------------------------------- backward kernels
+EW_ACT_BWD, EW_ABS_BWD, EW_SQUARE, EW_ABS, EW_AXPY, EW_RECIP_SCALE, EW_DIFF_SCALE, EW_MUL, EW_REPARAM, EW_REPARAM_BWD, EW_ADD = range(11)
+
+
+def elementwise(op, a, b=None, s0=0.0, s1=0.0):
+    _dev(a, "a")
+    if b is not None:
+        _dev(b, "b")
+        if b.numel() != a.numel():
+            raise RuntimeError("masic_amd.elementwise: size mismatch")
+    y = torch.empty_like(a)
+    check(lib.masic_elementwise(_p(a), _p(b), _p(y), a.numel(), int(op), float(s0), float(s1), _stream()), "elementwise")
+    return y
+
+
+def channel_sum(x, C=None, coff=0):
+    _dev(x, "x")
+    B, ctot = x.shape[0], x.shape[1]
+    C = ctot if C is None else C
+    HW = x.numel() // (B * ctot)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(lib.masic_channel_sum(_p(x), _p(out), B, C, HW, ctot, coff, _stream()), "channel_sum")
+    return out
+
+
+def slice_copy(x, coff, C):
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib.masic_slice_copy(_p(x), _p(y), B, C, H * W, ctot, coff, _stream()), "slice_copy")
+    return y
+
+
+def gate_bwd(g, x, gate, gate_c):
+    _dev(g, "g"); _dev(x, "x"); _dev(gate, "gate")
+    B, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    ggate = torch.zeros_like(gate)
+    check(lib.masic_gate_bwd(_p(g), _p(x), _p(gate), _p(gx), _p(ggate), B, C, H * W, gate.shape[1], gate_c, _stream()), "gate_bwd")
+    return gx, ggate
+
+
+def softmax_k_bwd(g, y, K):
+    _dev(g, "g"); _dev(y, "y")
+    B, KM, H, W = y.shape
+    gx = torch.empty_like(y)
+    check(lib.masic_softmax_k_bwd(_p(g), _p(y), _p(gx), B, KM // K, K, H * W, _stream()), "softmax_k_bwd")
+    return gx
+
+
+def gdn_bwd_pre(x, nrm, g, inverse):
+    s = torch.empty_like(x)
+    t = torch.empty_like(x)
+    check(lib.masic_gdn_bwd_pre(_p(_dev(x)), _p(_dev(nrm)), _p(_dev(g)), _p(s), _p(t), x.numel(), int(inverse), _stream()), "gdn_bwd_pre")
+    return s, t
+
+
+def gdn_bwd_post(x, s, u):
+    dx = torch.empty_like(x)
+    check(lib.masic_gdn_bwd_post(_p(_dev(x)), _p(_dev(s)), _p(_dev(u)), _p(dx), x.numel(), _stream()), "gdn_bwd_post")
+    return dx
+
+
+def conv2d_wgrad(x, dy, desc, weight_shape):
+    _dev(x, "x"); _dev(dy, "dy")
+    if tuple(dy.shape) != (desc.B, desc.Cout, desc.Ho, desc.Wo):
+        raise RuntimeError(f"masic_amd.conv2d_wgrad: dy {tuple(dy.shape)} does not match the descriptor")
+    if tuple(x.shape) != (desc.B, desc.in_ctot, desc.Hi, desc.Wi):
+        raise RuntimeError(f"masic_amd.conv2d_wgrad: x {tuple(x.shape)} does not match the descriptor")
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    nbytes = lib.masic_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    if nbytes != dw.numel() * 4:
+        raise RuntimeError("masic_amd.conv2d_wgrad: weight shape does not match the descriptor")
+    ws = torch.empty(dw.numel(), dtype=torch.float32, device=x.device)
+    check(lib.masic_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), _stream()), "conv2d_wgrad")
+    return dw
+
+
+def gmm_likelihood_bwd(y_hat, sigma, mu, wts, g_lik, g_yhat, K, weights_are_logits, scale_bound=SCALE_BOUND, lik_bound=LIK_BOUND):
+    for t in (y_hat, sigma, mu, wts, g_lik):
+        _dev(t)
+    B, M, H, W = y_hat.shape
+    g_y = torch.empty_like(y_hat)
+    g_s, g_m, g_w = torch.empty_like(sigma), torch.empty_like(mu), torch.empty_like(wts)
+    check(lib.masic_gmm_likelihood_bwd(_p(y_hat), _p(sigma), _p(mu), _p(wts), _p(g_lik), _p(g_yhat), _p(g_y), _p(g_s), _p(g_m), _p(g_w),
+                                       B, M, K, H, W, int(weights_are_logits), float(scale_bound), float(lik_bound), _stream()),
+          "gmm_likelihood_bwd")
+    return g_y, g_s, g_m, g_w
+
+
+def entropy_bottleneck_bwd(z_hat, table, g_lik, g_zhat, lik_bound=LIK_BOUND):
+    _dev(z_hat); _dev(table); _dev(g_lik)
+    B, C, H, W = z_hat.shape
+    g_z = torch.empty_like(z_hat)
+    g_t = torch.empty_like(table)
+    check(lib.masic_entropy_bottleneck_bwd(_p(z_hat), _p(table), _p(g_lik), _p(g_zhat), _p(g_z), _p(g_t), B, C, H, W,
+                                           float(lik_bound), _stream()), "entropy_bottleneck_bwd")
+    return g_z, g_t
+
+
+def entropy_bottleneck_auxloss_bwd(table, quantiles, gout, tail_mass=1e-9):
+    _dev(table); _dev(quantiles)
+    g_q = torch.empty_like(quantiles)
+    check(lib.masic_entropy_bottleneck_auxloss_bwd(_p(table), _p(quantiles), _p(g_q), table.shape[0], float(tail_mass), float(gout), _stream()),
+          "entropy_bottleneck_auxloss_bwd")
+    return g_q
+
+
+def warp_perspective_bwd(g_dst, minv_norm, src_shape):
+    _dev(g_dst); _dev(minv_norm)
+    B, C, Hs, Ws = src_shape
+    Hd, Wd = g_dst.shape[-2:]
+    g_src = torch.zeros(src_shape, dtype=torch.float32, device=g_dst.device)
+    check(lib.masic_warp_perspective_bwd(_p(g_dst), _p(minv_norm), _p(g_src), B, C, Hs, Ws, Hd, Wd, _stream()), "warp_perspective_bwd")
+    return g_src

@@ -1,0 +1,247 @@
+"""GPU parity tests (-m gpu) of the backward kernels: every differentiable node of the training graph against
+torch autograd on the CPU oracle (same seeded inputs), then the whole training step against the gradient goldens the
+reference produced (tests/golden/hsic_tiny.npz: d loss / d parameter for all 166 parameters)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hsic_oracle as O
+from tests.util import assert_close, golden_state_dict, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GTOL = 2e-4
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(size=shape) * scale).astype(np.float32))
+
+
+CONV_BWD_CASES = [
+    # name,        B, Cin, H,  W,  Cout, k, s, transposed, masked, act
+    ("conv5s2",    2, 128, 32, 64, 128,  5, 2, False, False, 0),
+    ("conv5s2_in3", 2, 3,  64, 96, 128,  5, 2, False, False, 0),
+    ("conv5s1",    2, 192, 16, 24, 128,  5, 1, False, False, 1),
+    ("conv3s1",    2, 288, 16, 24, 384,  3, 1, False, False, 0),
+    ("conv1x1",    2, 768, 8,  12, 960,  1, 1, False, False, 2),
+    ("deconv1x1",  2, 768, 8,  12, 1152, 1, 1, True,  False, 1),
+    ("deconv5s2",  2, 192, 8,  12, 128,  5, 2, True,  False, 2),
+    ("deconv_to3", 2, 128, 16, 24, 3,    5, 2, True,  False, 0),
+    ("masked5",    2, 192, 16, 24, 384,  5, 1, False, True,  0),
+    ("conv6to3",   2, 6,   32, 48, 3,    5, 1, False, False, 0),
+    ("deconv6to3", 2, 6,   32, 48, 3,    5, 1, True,  False, 0),
+    ("m2w_3x3s2",  2, 3,   32, 48, 6,    3, 2, False, False, 1),
+    ("ragged",     1, 20,  18, 36, 72,   5, 2, False, False, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_BWD_CASES, ids=[c[0] for c in CONV_BWD_CASES])
+def test_conv_backward(case):
+    from masic_amd import autograd as A
+    from masic_amd import nn as mnn
+    from compressai.layers import MaskedConv2d
+    name, B, Cin, H, W, Cout, k, s, tr, masked, act = case
+    if masked:
+        mod = MaskedConv2d(Cin, Cout, kernel_size=k, padding=k // 2, stride=s)
+    elif tr:
+        mod = mnn.ConvTranspose2d(Cin, Cout, k, stride=s, padding=k // 2, output_padding=s - 1)
+    else:
+        mod = mnn.Conv2d(Cin, Cout, k, stride=s, padding=k // 2)
+    w = _rand(*mod.weight.shape, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    with torch.no_grad():
+        mod.weight.copy_(w)
+        mod.bias.copy_(b)
+    mod = mod.to(DEV)
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    # CPU reference through autograd
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    weff = O.masked_weight(wr) if masked else wr
+    yr = (F.conv_transpose2d(xr, weff, br, stride=s, padding=k // 2, output_padding=s - 1) if tr
+          else F.conv2d(xr, weff, br, stride=s, padding=k // 2))
+    yr = {0: lambda t: t, 1: F.relu, 2: F.leaky_relu}[act](yr)
+    go = _rand(*yr.shape, seed=4)
+    yr.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    y = A.conv(mod, xd, act)
+    assert_close(y, yr, name + ":fwd")
+    y.backward(go.to(DEV))
+    assert_close(xd.grad, xr.grad, name + ":dx", GTOL)
+    assert_close(mod.weight.grad, wr.grad, name + ":dw", GTOL)
+    assert_close(mod.bias.grad, br.grad, name + ":db", GTOL)
+
+
+@pytest.mark.parametrize("C,H,W,inverse", [(128, 16, 32, False), (128, 8, 8, True), (3, 32, 48, False), (3, 24, 40, True), (16, 8, 12, False)])
+def test_gdn_backward(C, H, W, inverse):
+    from compressai.layers import GDN
+    from masic_amd import synth
+    rs = np.random.RandomState(C + H)
+    beta = synth.synth_tensor("g.beta", (C,), rs)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs)
+    gamma[0, 1] = 1e-7
+    gamma[1, 0] = 1e-7
+    beta[0] = 1e-5
+    x = _rand(2, C, H, W, seed=10, scale=3.0)
+    xr, br, gr = x.clone().requires_grad_(True), beta.clone().requires_grad_(True), gamma.clone().requires_grad_(True)
+    yr = O.gdn(xr, br, gr, inverse=inverse)
+    go = _rand(*yr.shape, seed=11)
+    yr.backward(go)
+    m = GDN(C, inverse=inverse)
+    with torch.no_grad():
+        m.beta.copy_(beta)
+        m.gamma.copy_(gamma)
+    m = m.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd)
+    y.backward(go.to(DEV))
+    assert_close(xd.grad, xr.grad, "gdn:dx", GTOL)
+    assert_close(m.gamma.grad, gr.grad, "gdn:dgamma", GTOL)
+    assert_close(m.beta.grad, br.grad, "gdn:dbeta", GTOL)
+
+
+def test_entropy_bottleneck_backward_and_aux():
+    from compressai.entropy_models import EntropyBottleneck
+    from masic_amd import synth
+    C, B, H, W = 24, 3, 4, 6
+    eb = EntropyBottleneck(C)
+    sd = synth.synth_state_dict({k: v for k, v in eb.state_dict().items()}, seed=5)
+    eb.load_state_dict(sd)
+    z = _rand(B, C, H, W, seed=11, scale=4.0)
+    noise = torch.from_numpy(np.random.RandomState(12).uniform(-0.5, 0.5, size=(C, 1, H * W * B)).astype(np.float32))
+    pn = [n for n, _ in eb.named_parameters()]
+    sdr = {"eb." + k: (v.clone().requires_grad_(True) if k in pn else v) for k, v in sd.items()}
+    zr = z.clone().requires_grad_(True)
+    zh, lik = O.entropy_bottleneck(zr, sdr, "eb", training=True, noise=noise)
+    g1, g2 = _rand(*z.shape, seed=13), _rand(*z.shape, seed=14)
+    (zh * g1).sum().backward(retain_graph=True)
+    (lik * g2).sum().backward()
+    eb = eb.to(DEV).train()
+    eb._get_noise_cached = lambda x: noise.to(DEV).reshape(x.shape).contiguous()
+    zd = z.to(DEV).requires_grad_(True)
+    zh_d, lik_d = eb(zd)
+    ((zh_d * g1.to(DEV)).sum() + (lik_d * g2.to(DEV)).sum()).backward()
+    assert_close(zd.grad, zr.grad, "eb:dz", GTOL)
+    for n, p in eb.named_parameters():
+        if n == "quantiles":
+            continue
+        assert_close(p.grad, sdr["eb." + n].grad, "eb:d" + n, GTOL)
+    # aux loss: gradient w.r.t. the quantiles only
+    for p in eb.parameters():
+        p.grad = None
+    aux = eb.loss()
+    aux.backward()
+    sq = {k: v.detach().clone() for k, v in sdr.items()}
+    sq["eb.quantiles"].requires_grad_(True)
+    O.eb_aux_loss(sq, "eb").backward()
+    assert_close(eb.quantiles.grad, sq["eb.quantiles"].grad, "eb:aux dq", GTOL)
+    assert all(p.grad is None for n, p in eb.named_parameters() if n != "quantiles")
+
+
+def test_gmm_backward():
+    from masic_amd import autograd as A
+    B, M, K, H, W = 2, 24, 5, 6, 10
+    y = _rand(B, M, H, W, seed=13, scale=6.0)
+    sigma = F.relu(_rand(B, K * M, H, W, seed=14, scale=2.0))
+    mu = _rand(B, K * M, H, W, seed=15, scale=5.0)
+    raw = _rand(B, K * M, H, W, seed=16, scale=2.0)
+    y[0, 0, 0, :2] = torch.tensor([40.0, -35.0])
+    noise = torch.from_numpy(np.random.RandomState(17).uniform(-0.5, 0.5, size=y.shape).astype(np.float32))
+    t = [v.clone().requires_grad_(True) for v in (y, sigma, mu, raw)]
+    yh = t[0] + noise
+    lik = O.gmm_likelihood(yh, t[1], t[2], O._softmax_over_k(t[3], K), K)
+    g1, g2 = _rand(*y.shape, seed=18), _rand(*y.shape, seed=19, scale=3.0)
+    ((yh * g1).sum() + (lik * g2).sum()).backward()
+    d = [v.to(DEV).requires_grad_(True) for v in (y, sigma, mu, raw)]
+    yh_d, lik_d = A.GmmFn.apply(d[0], noise.to(DEV), d[1], d[2], d[3], K, 0.11, 1e-9)
+    ((yh_d * g1.to(DEV)).sum() + (lik_d * g2.to(DEV)).sum()).backward()
+    for a, b, n in zip(d, t, ("dy", "dsigma", "dmu", "dlogits")):
+        assert_close(a.grad, b.grad, "gmm:" + n, GTOL)
+    assert int((t[1].grad == 0).sum()) > 0      # LowerBound(sigma) blocked some gradients
+
+
+def test_warp_gate_cat_softmax_abs_backward():
+    from masic_amd import autograd as A
+    from masic_amd import synth
+    from masic_amd.homography import warp_matrices
+    H, W = 40, 56
+    x, _, hm = synth.synth_inputs(2, H, W, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = O.warp_perspective(xr, hm, (H, W))
+    go = _rand(*yr.shape, seed=5)
+    yr.backward(go)
+    m, _ = warp_matrices(hm.to(DEV), (H, W), (H, W))
+    xd = x.to(DEV).requires_grad_(True)
+    A.WarpFn.apply(xd, m, (H, W)).backward(go.to(DEV))
+    assert_close(xd.grad, xr.grad, "warp:dsrc", GTOL)
+    # gate + cat + softmax_k + abs in one small graph
+    a, b = _rand(2, 5, 6, 7, seed=6), _rand(2, 4, 6, 7, seed=7)
+    logits = _rand(2, 3, 6, 7, seed=8)
+    ts = [v.clone().requires_grad_(True) for v in (a, b, logits)]
+    gates = F.softmax(ts[2], dim=1)
+    out = torch.cat((ts[0].abs() * gates[:, 0:1], ts[1] * gates[:, 2:3]), dim=1)
+    go = _rand(*out.shape, seed=9)
+    out.backward(go)
+    td = [v.to(DEV).requires_grad_(True) for v in (a, b, logits)]
+    gd = A.SoftmaxKFn.apply(td[2], 3)
+    outd = A.cat(A.GateFn.apply(A.AbsFn.apply(td[0]), gd, 0), A.GateFn.apply(td[1], gd, 2))
+    assert_close(outd, out, "graph:fwd")
+    outd.backward(go.to(DEV))
+    for u, v, n in zip(td, ts, ("da", "db", "dlogits")):
+        assert_close(u.grad, v.grad, "graph:" + n, GTOL)
+
+
+def test_training_step_gradients_vs_reference_golden():
+    """HSIC(16,24,3) train-mode forward + RD loss + backward with the 7 recorded noise draws: every parameter gradient
+    against the reference's (tests/golden/hsic_tiny.npz), then the aux loss gradient."""
+    import MASIC
+    from compressai.entropy_models import EntropyModel
+    from masic_amd.loss import rate_distortion
+    fx = load_npz("hsic_tiny.npz")
+    N, M, K = (int(v) for v in fx["NMK"])
+    sd = golden_state_dict(fx, MASIC.HSIC(N, M, K).state_dict())
+    net = MASIC.HSIC(N, M, K)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x1, x2, H = (torch.from_numpy(fx[k]).to(DEV) for k in ("x1", "x2", "h_matrix"))
+    queue = [torch.from_numpy(fx["train/noise_" + k]).to(DEV) for k in O.NOISE_KEYS]
+    orig = EntropyModel._get_noise_cached
+    EntropyModel._get_noise_cached = lambda self, x: queue.pop(0).reshape(x.shape).contiguous()
+    try:
+        out = net(x1, x2, H)
+    finally:
+        EntropyModel._get_noise_cached = orig
+    assert not queue
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], torch.from_numpy(fx["train/" + k]), "train:" + k)
+    crit = rate_distortion(out, x1, x2, float(fx["lmbda"]))
+    assert abs(float(crit["loss"]) - float(fx["train/loss_loss"])) <= 1e-4 * abs(float(fx["train/loss_loss"]))
+    crit["loss"].backward()
+    worst, worst_name, n = 0.0, "", 0
+    grads = dict(net.named_parameters())
+    for key in fx:
+        if not key.startswith("train/grad/"):
+            continue
+        name = key[len("train/grad/"):]
+        ref = torch.from_numpy(fx[key])
+        got = grads[name].grad
+        assert got is not None, name
+        e = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        n += 1
+        if e > worst:
+            worst, worst_name = e, name
+    print(f"training step: {n} parameter gradients, worst relative error {worst:.2e} ({worst_name})")
+    assert n == 164 and worst <= 1e-3, (n, worst, worst_name)     # the 2 quantiles get no gradient from the main loss
+    assert net.entropy_bottleneck1.quantiles.grad is None
+    # masked taps of the context model do receive gradient, as in the reference
+    gm = net.context_prediction1.weight.grad
+    assert float(gm[:, :, 3:, :].abs().max()) > 0
+    net.zero_grad()
+    aux = net.aux_loss()
+    assert abs(float(aux) - float(fx["train/aux_loss"])) <= 1e-4 * float(fx["train/aux_loss"])
+    aux.backward()
+    for nm in ("entropy_bottleneck1.quantiles", "entropy_bottleneck2.quantiles"):
+        assert_close(grads[nm].grad, torch.from_numpy(fx["train/auxgrad/" + nm]), "aux:" + nm, GTOL)
