@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3,
+                    help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
+                         "2x Adam) after the headline region; reported under extras.train_step, 0 to skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +133,29 @@ def main():
         except Exception:
             pass
 
+    train_info = None
+    if args.train_steps > 0:
+        from masic_amd.parallel import GradientAllReducer
+        from masic_amd.train import make_optimizers, train_step
+        net.train()
+        optimizer, aux_optimizer = make_optimizers(net)
+        reducer = GradientAllReducer(net) if world > 1 else None
+        train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)        # warm-up (packs dgrad weights etc.)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            crit, _ = train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)
+        barrier()
+        tt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([tt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tt = float(t.item())
+        train_info = {"value": world * B * args.train_steps / tt, "unit": "stereo pairs/s", "steps": args.train_steps,
+                      "ms_per_step": tt / args.train_steps * 1e3, "loss_after": float(crit["loss"]),
+                      "what": "forward + RD loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
+                              " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146), f32"}
+
     if rank == 0:
         line = {
             "metric": "stereo pairs/sec (enc+dec)", "value": world * B * args.steps / elapsed, "unit": "stereo pairs/s",
@@ -140,6 +166,8 @@ def main():
                        "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world} (pairs sharded, no data-path collective)"},
             "roofline": roofline,
         }
+        if train_info is not None:
+            line["extras"] = {"train_step": train_info}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, M, K, H, W, seed=100)
         print(json.dumps(line), flush=True)

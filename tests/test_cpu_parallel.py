@@ -1,0 +1,94 @@
+"""CPU suite: the N>1 path -- pair sharding and the bucketed gradient all-reduce -- with world_size-2 gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from masic_amd.parallel import GradientAllReducer, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 16, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 40)
+        self.b = torch.nn.Linear(40, 40)
+        self.c = torch.nn.Linear(40, 3)
+        self.unused = torch.nn.Parameter(torch.zeros(5))      # like the EB quantiles: no gradient from the main loss
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _Net()
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    lo, hi = shard_range(8, rank, world)
+    red = GradientAllReducer(net, bucket_bytes=4096, overlap=overlap)       # several small buckets
+    assert len(red.buckets) >= 2
+    red.arm()
+    loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+    loss.backward()
+    red.finish()
+    grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    # single-process reference: the mean over equal shards of per-shard mean losses == full-batch mean loss
+    ref = _Net()
+    ref.load_state_dict(net.state_dict())
+    ((ref(x) - y) ** 2).mean().backward()
+    ok = all((g is None and rp.grad is None) or torch.allclose(g, rp.grad, rtol=1e-5, atol=1e-7)
+             for (n, g), (_, rp) in zip(grads.items(), ref.named_parameters()))
+    q.put((rank, ok, grads["unused"] is None))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gradient_allreduce_world2_gloo_matches_full_batch(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(unused_none for _, _, unused_none in res)
+
+
+def test_reducer_single_process_is_identity():
+    net = _Net()
+    red = GradientAllReducer(net, bucket_bytes=1024)
+    red.arm()
+    net(torch.randn(4, 6)).sum().backward()
+    before = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    red.finish()
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, before[n])
