@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("MASIC_PRECISION", "f32"),
+                    help="operand precision of the forward MFMA contractions (float32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
@@ -83,7 +85,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     import MASIC
+    from masic_amd import nn as mnn
     from masic_amd import ops, synth
+    mnn.set_precision(args.precision)
 
     N, M, K = 128, 192, 5
     B, H, W = args.batch, args.height, args.width

@@ -104,6 +104,8 @@ struct ConvCfg {
     int wn;             // pixel sub-tiles (of 32) per wave: 4 -> BM x 256 block tile, 1 -> BM x 64
     int buf_sz;         // floats per LDS buffer: patch [KC][PSZ] + weights [round4(taps*KC)][64]
     int vec4;           // 1x1 layers: the patch is staged with 16-byte DMA pieces
+    int bf16;           // bf16-operand kernel (desc.prec == MASIC_PREC_BF16 and Cout > 8)
+    int pf;             // bf16: small patch -> next chunk's pixels prefetched in registers
     int KC, KClog;      // input channels per LDS chunk
     int TW, TWlog, SR, TH;
     int Cin_pad, Cout_pad;
@@ -158,6 +160,25 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     c.PH = (c.TH - 1) * is + span_h;
     c.PW = (c.TW - 1) * is + span_w;
     c.PWp = c.PW;                                       // LDS-DMA writes 64 consecutive floats: no row padding
+    if (d.prec == MASIC_PREC_BF16) {
+        // [pixel][KC+8] bf16 patch in one LDS buffer (two workgroups per CU overlap staging and MFMA);
+        // the whole patch must fit MAXP*256 pixels
+        c.bf16 = 1;
+        while (c.wn > 1 && c.PH * c.PW > 6 * 256) {
+            c.wn >>= 1;
+            c.TH = c.SR * wvn * c.wn;
+            c.PH = (c.TH - 1) * is + span_h;
+        }
+        int KC = 32;
+        while (KC > 16 && ((size_t)c.PH * c.PW * (KC + 8) * 2 > 64 * 1024 || KC > round_up(d.Cin, 16))) KC >>= 1;
+        c.KC = KC; c.KClog = ilog2(KC);
+        c.Cin_pad = round_up(d.Cin, KC);
+        c.PSZ = c.PH * c.PW;
+        c.buf_sz = 0;
+        c.lds_bytes = (size_t)c.PH * c.PW * (KC + 8) * 2;
+        c.pf = (c.PH * c.PW * (KC / 8) <= 1024) ? 1 : 0;
+        return c;
+    }
     c.PSZ = round_up(c.PH * c.PW, 64);                  // whole wave-instructions per channel
     const int groups = c.PSZ / 64;                      // DMA wave-instructions per channel
     const int epw = ceil_div(groups, 4);                // ... per wave
@@ -604,6 +625,246 @@ __global__ void pack_deconv4_kernel(const float* __restrict__ w, float* __restri
     wp[i] = (ci < Cin && o < Cout) ? w[((size_t)ci * Cout + o) * 25 + tap] : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------ bf16-operand igemm
+// Same implicit GEMM with bf16 operands on v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate), float32 accumulate,
+// float32 NCHW tensors in HBM on both sides.  At this rate the contraction is no longer the bound -- operand delivery
+// is -- so the staging differs from the f32 kernel:
+//   * B (im2col) operand: a lane's fragment is 8 consecutive k = 8 consecutive input channels of one pixel, so the LDS
+//     patch is [pixel][channel] bf16 (pixel pitch KC+8 elements: 16-byte pad against bank conflicts) and one
+//     ds_read_b128 fetches a fragment.  NCHW float32 rows are read coalesced along W (one pixel per lane, 8 channel
+//     planes per task), converted (v_cvt_pk_bf16_f32; |.| / round() fused here) and written with ds_write_b128:
+//     the transpose happens in registers.
+//   * A (weight) operand: straight from L2 into registers -- the weights are pre-packed as
+//     [tap][ci/16][co][16 ci] bf16, so a wave's fragment load is 1 KiB contiguous -- prefetched one k-step ahead.
+//     Keeping the 25-tap weights out of LDS is what lets the whole 5x5 patch of a 128 x 256 tile fit.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int MAXP = 6;    // pixel tasks per thread per 8-channel group (patch <= 1536 pixels)
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int WVM, int WM, int WN, int INOP, bool PF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int BM = 32 * WM * WVM;
+    constexpr int DEPTH = 4;                                               // A-fragment prefetch distance (k-steps)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* patch = reinterpret_cast<unsigned short*>(lds);          // [NP][KCP] bf16
+    const int KCP = a.KC + 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WVM, wn = wave / WVM;
+    const int j = lane & 31, h = lane >> 5;
+
+    const int phase = blockIdx.x % a.nphase, tile = blockIdx.x / a.nphase;
+    const ConvGeom g = make_geom(a.q, phase);
+    const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
+    const int m0 = blockIdx.y * BM;
+    const int b = blockIdx.z;
+    const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
+    const int ih0 = r0 * g.is + g.dh_min, iw0 = c0 * g.is + g.dw_min;
+
+    const int NP = a.PH * a.PW;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    auto pixel_offset = [&](int p) {     // patch pixel -> offset in an input channel plane (-1: zero fill)
+        const int pr = p / a.PW, pc = p - pr * a.PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        return (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) ? ih * a.Wi + iw : -1;
+    };
+    // ---- staging maps.
+    //  !PF: pixel p = tid + 256 i for every 8-channel group in turn (big patches)
+    //   PF: (pixel, group) tasks t = tid + 256 i, t < NP * KC/8 <= 1024 (small patches: next chunk prefetched in registers)
+    constexpr int NT = PF ? 4 : MAXP;
+    int goff[NT], gch_t[PF ? 4 : 1], loff[PF ? 4 : 1];
+    const int ngroups = a.KC >> 3;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = tid + 256 * i;
+        if (PF) {
+            const int gq = t / NP, p = t - gq * NP;
+            goff[i] = gq >= ngroups ? -2 : pixel_offset(p);
+            gch_t[i] = gq * 8;
+            loff[i] = p * KCP + gq * 8;
+        } else {
+            goff[i] = t >= NP ? -2 : pixel_offset(t);
+        }
+    }
+
+    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
+    int lane_p[WN];        // LDS element offset of this lane's pixel (tap 0) + its k half
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int r = (wn * WN + n) * a.SR + jr;
+        lane_p[n] = ((r * g.is) * a.PW + jc * g.is) * KCP + 8 * h;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    const int ksteps = a.KC >> 4, kslog = ksteps >> 1;              // 16-channel MFMA steps per tap (1 or 2)
+    const int nsteps = g.ntaps * ksteps;
+    const int tap0_off = ((g.dh0 - g.dh_min) * a.PW + (g.dw0 - g.dw_min)) * KCP;
+    const int row_step = (g.dsh * a.PW - g.dsw * (g.ntw - 1)) * KCP;
+    const int col_step = g.dsw * KCP;
+    const int cin16 = a.Cin_pad >> 4;
+    // A fragment address: ((tap * cin16 + c16) * Cout_pad + co) * 16 + 8h   (bf16 elements)
+    const size_t a_lane = ((size_t)m0 + wm * (32 * WM) + j) * 16 + 8 * h;
+    const size_t a_tap_stride = (size_t)cin16 * a.Cout_pad * 16;
+    const size_t a_c16_stride = (size_t)a.Cout_pad * 16;
+
+    float pre[PF ? 4 : 1][8];
+    auto load_tasks = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < (PF ? 4 : 1); ++i) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int cg = cc + gch_t[i] + c;
+                pre[i][c] = (goff[i] >= 0 && cg < a.Cin) ? xb[(size_t)cg * plane + goff[i]] : 0.0f;
+            }
+        }
+    };
+    auto store_tasks = [&]() {
+#pragma unroll
+        for (int i = 0; i < (PF ? 4 : 1); ++i) {
+            if (goff[i] == -2) continue;
+            uint4 q;
+            q.x = pack_bf16x2(apply_inop(pre[i][0], INOP), apply_inop(pre[i][1], INOP));
+            q.y = pack_bf16x2(apply_inop(pre[i][2], INOP), apply_inop(pre[i][3], INOP));
+            q.z = pack_bf16x2(apply_inop(pre[i][4], INOP), apply_inop(pre[i][5], INOP));
+            q.w = pack_bf16x2(apply_inop(pre[i][6], INOP), apply_inop(pre[i][7], INOP));
+            *reinterpret_cast<uint4*>(patch + loff[i]) = q;
+        }
+    };
+    if (PF) load_tasks(0);
+
+    for (int cc = 0; cc < a.Cin_pad; cc += a.KC) {
+        // ---- stage: NCHW float32 -> [pixel][channel] bf16
+        if (PF) {
+            store_tasks();
+        } else {
+            for (int gch = 0; gch < a.KC; gch += 8) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (goff[i] == -2) continue;
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int cg = cc + gch + c;
+                        v[c] = (goff[i] >= 0 && cg < a.Cin) ? apply_inop(xb[(size_t)cg * plane + goff[i]], INOP) : 0.0f;
+                    }
+                    uint4 q;
+                    q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]);
+                    q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(patch + (size_t)(tid + 256 * i) * KCP + gch) = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (PF && cc + a.KC < a.Cin_pad) load_tasks(cc + a.KC);        // in flight during the contraction
+        // ---- contraction: k-steps (tap, 16 channels); A fragments stream from L2 through a DEPTH-deep register ring
+        const unsigned short* wa = wpk + (size_t)g.tap_base * a_tap_stride + (size_t)(cc >> 4) * a_c16_stride + a_lane;
+        auto a_offset = [&](int st) { return (size_t)(st >> kslog) * a_tap_stride + (size_t)(st & (ksteps - 1)) * a_c16_stride; };
+        uint4 ring[DEPTH][WM];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (u < nsteps) {
+                const unsigned short* pa = wa + a_offset(u);
+#pragma unroll
+                for (int m = 0; m < WM; ++m) ring[u][m] = *reinterpret_cast<const uint4*>(pa + m * 32 * 16);
+            }
+        int sp = tap0_off, kk = 0, tb = 0;
+        for (int st0 = 0; st0 < nsteps; st0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int st = st0 + u;
+                if (st < nsteps) {
+                    bf16x8 bfrag[WN], afr[WM];
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        bfrag[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + sp + lane_p[n] + kk * 16));
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) afr[m] = __builtin_bit_cast(bf16x8, ring[u][m]);
+                    if (st + DEPTH < nsteps) {
+                        const unsigned short* pa = wa + a_offset(st + DEPTH);
+#pragma unroll
+                        for (int m = 0; m < WM; ++m) ring[u][m] = *reinterpret_cast<const uint4*>(pa + m * 32 * 16);
+                    }
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[m], bfrag[n], acc[m][n], 0, 0, 0);
+                    if (++kk == ksteps) {
+                        kk = 0;
+                        if (++tb < g.ntw) sp += col_step;
+                        else { tb = 0; sp += row_step; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (same as the f32 kernel)
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
+        if (r >= g.Hp || c >= g.Wp) continue;
+        const int oh = r * g.os + g.oph, ow = c * g.os + g.opw;
+        const size_t opix = (size_t)oh * a.Wo + ow;
+        float gv = 1.0f;
+        if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + wm * (32 * WM) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < a.Cout) {
+                    float v = acc[m][n][e] + (a.bias ? a.bias[co] : 0.0f);
+                    v = apply_act(v, a.act);
+                    if (a.gate) v *= gv;
+                    if (a.res1) v += a.res1[((size_t)b * a.Cout + co) * oplane + opix];
+                    if (a.res2) v += a.res2[((size_t)b * a.Cout + co) * oplane + opix];
+                    a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+                }
+            }
+    }
+}
+
+// packed bf16 weights: [phase-tap][ci/16][co (padded to BM)][16 ci]
+__global__ void pack_weight_bf16_kernel(const PackArgs a, unsigned short* __restrict__ wp) {
+    const size_t per_tap = (size_t)a.Cin_pad * a.Cout_pad;
+    const size_t total = (size_t)a.g.ntaps * per_tap;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / per_tap);
+        const size_t rem = i - (size_t)t * per_tap;
+        const int c16 = (int)(rem / ((size_t)a.Cout_pad * 16));
+        const int rem2 = (int)(rem - (size_t)c16 * a.Cout_pad * 16);
+        const int co = rem2 >> 4, ci = c16 * 16 + (rem2 & 15);
+        float v = 0.0f;
+        if (ci < a.Cin && co < a.Cout) {
+            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
+            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const size_t src = a.transposed ? (((size_t)ci * a.Cout + co) * a.KH + kh) * a.KW + kw
+                                            : (((size_t)co * a.Cin + ci) * a.KH + kh) * a.KW + kw;
+            v = a.w[src];
+        }
+        const __bf16 bv = (__bf16)v;
+        wp[(size_t)a.g.tap_base * per_tap + i] = __builtin_bit_cast(unsigned short, bv);
+    }
+}
+
 int check_desc(const masic_conv_desc_t* d) {
     MASIC_REQUIRE(d != nullptr, MASIC_ERR_ARG, "conv: null descriptor");
     MASIC_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Hi > 0 && d->Wi > 0, MASIC_ERR_SHAPE,
@@ -623,7 +884,7 @@ int check_desc(const masic_conv_desc_t* d) {
     }
     MASIC_REQUIRE(ho == d->Ho && wo == d->Wo, MASIC_ERR_SHAPE, "conv: output size %dx%d given, %dx%d expected", d->Ho, d->Wo, ho, wo);
     MASIC_REQUIRE(d->act != MASIC_ACT_SOFTMAX_C || d->Cout <= 8, MASIC_ERR_UNSUPPORTED, "conv: channel softmax needs Cout <= 8");
-    MASIC_REQUIRE(d->prec == MASIC_PREC_F32, MASIC_ERR_UNSUPPORTED, "conv: precision %d not built", d->prec);
+    MASIC_REQUIRE(d->prec == MASIC_PREC_F32 || d->prec == MASIC_PREC_BF16, MASIC_ERR_UNSUPPORTED, "conv: precision %d not built", d->prec);
     return MASIC_OK;
 }
 
@@ -637,6 +898,7 @@ extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
     int taps = 0;
     for (int p = 0; p < np; ++p) taps += g[p].ntaps;
     if (c.direct == 2) return (size_t)c.Cin_pad * 100 * sizeof(float);
+    if (c.bf16) return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(unsigned short);
     return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
 }
 
@@ -649,6 +911,7 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     if (launches) *launches = 1;   // all phases ride in one launch
     if (c.direct == 2) return 6;
     if (c.direct) return d->Cout <= 3 ? 0 : 1;
+    if (c.bf16) return 10;
     if (c.wvm == 1) return c.wm == 1 ? 8 : 9;
     if (c.wm == 2) return c.wn == 4 ? 5 : 7;
     return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
@@ -668,6 +931,13 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
     }
     for (int p = 0; p < np; ++p) {
         PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, g[p]};
+        if (c.bf16) {
+            const size_t tot = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
+            int nb = (int)((tot + 255) / 256);
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+            continue;
+        }
         const size_t total = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -723,6 +993,32 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
                     c.PH, c.PW, c.PWp, c.PSZ, c.buf_sz, c.vec4,
                     d->in_op, d->act, d->gate_ctot, d->gate_c, q, np};
         dim3 grid(ceil_div(g[0].Wp, c.TW) * ceil_div(g[0].Hp, c.TH) * np, c.Cout_pad / (32 * c.wm * c.wvm), d->B);
+        if (c.bf16) {
+#define BF16_LAUNCH(WV, WMV, WNV, OPV)                                                                                            \
+    do {                                                                                                                          \
+        if (c.pf) hipLaunchKernelGGL((conv_igemm_bf16<WV, WMV, WNV, OPV, true>), grid, dim3(256), c.lds_bytes, st, a,             \
+                                     (const unsigned short*)w_packed);                                                           \
+        else hipLaunchKernelGGL((conv_igemm_bf16<WV, WMV, WNV, OPV, false>), grid, dim3(256), c.lds_bytes, st, a,                 \
+                                (const unsigned short*)w_packed);                                                                 \
+    } while (0)
+#define BF16_BY_OP(WV, WMV, WNV)                                                       \
+    do {                                                                               \
+        if (d->in_op == MASIC_INOP_ABS) BF16_LAUNCH(WV, WMV, WNV, MASIC_INOP_ABS);     \
+        else if (d->in_op == MASIC_INOP_ROUND) BF16_LAUNCH(WV, WMV, WNV, MASIC_INOP_ROUND); \
+        else BF16_LAUNCH(WV, WMV, WNV, MASIC_INOP_NONE);                               \
+    } while (0)
+            if (c.wvm == 1 && c.wm == 1) BF16_BY_OP(1, 1, 2);
+            else if (c.wvm == 1) BF16_BY_OP(1, 3, 2);
+            else if (c.wm == 2 && c.wn == 4) BF16_BY_OP(2, 2, 4);
+            else if (c.wm == 2 && c.wn == 2) BF16_BY_OP(2, 2, 2);
+            else if (c.wm == 2) BF16_BY_OP(2, 2, 1);
+            else if (c.wn == 4) BF16_BY_OP(2, 1, 4);
+            else if (c.wn == 2) BF16_BY_OP(2, 1, 2);
+            else BF16_BY_OP(2, 1, 1);
+#undef BF16_BY_OP
+#undef BF16_LAUNCH
+            return masic_launch_status("conv2d_fwd");
+        }
 #define IGEMM_LAUNCH(WV, WMV, WNV, OPV, V4) \
     hipLaunchKernelGGL((conv_igemm_f32<WV, WMV, WNV, OPV, V4>), grid, dim3(256), c.lds_bytes, st, a)
 #define IGEMM_BY_OP(WV, WMV, WNV)                                                               \

@@ -11,8 +11,23 @@ trigger a re-pack and eval loops do not.
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
-from ._lib import PREC_F32
+from ._lib import PREC_BF16, PREC_F32
+
+_PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16}[os.environ.get("MASIC_PRECISION", "f32")]
+
+
+def set_precision(name):
+    """Operand precision of the forward MFMA contractions: "f32" (parity path, exact float32 MFMA) or "bf16"
+    (bf16 operands, float32 accumulate; BASELINE's headline dtype). Backward contractions stay float32."""
+    global _PRECISION
+    _PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16}[name]
+
+
+def get_precision():
+    return "bf16" if _PRECISION == PREC_BF16 else "f32"
 
 
 def _pair(v):
@@ -40,11 +55,11 @@ class _PackedWeightMixin:
         return ops.make_conv_desc(B, self.in_channels, Hi, Wi, self.out_channels, kh, kw, s, p,
                                   transposed=self.transposed_conv, masked=self.masked_conv,
                                   in_ctot=in_ctot, in_coff=in_coff, out_ctot=out_ctot, out_coff=out_coff,
-                                  in_op=in_op, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=PREC_F32)
+                                  in_op=in_op, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=_PRECISION)
 
     def packed_weight(self, desc):
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi)
+        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi, desc.prec)
         cache = self.__dict__.get("_packed_cache")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_conv_weight(w.detach().contiguous(), desc))

@@ -56,7 +56,7 @@ def pack_conv_weight(weight, desc):
     nbytes = lib.masic_conv_packed_bytes(ctypes.byref(desc))
     if nbytes == 0:
         check(-1, "conv_packed_bytes")
-    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    packed = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=weight.device)
     check(lib.masic_conv_pack_weight(_p(weight), _p(packed), ctypes.byref(desc), _stream()), "conv_pack_weight")
     return packed
 
@@ -66,7 +66,7 @@ class KernelTimer:
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
     VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1,1>", 3: "conv_igemm_f32<1,2>",
                 4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout", 7: "conv_igemm_f32<2,2>",
-                8: "conv_igemm_f32<1w,1,2>", 9: "conv_igemm_f32<1w,3,2>"}
+                8: "conv_igemm_f32<1w,1,2>", 9: "conv_igemm_f32<1w,3,2>", 10: "conv_igemm_bf16"}
 
     def __init__(self):
         self.records = []

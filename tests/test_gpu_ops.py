@@ -236,3 +236,26 @@ def test_reductions_and_small_helpers():
     g = _rand(1000, seed=23)
     ref = torch.where((x >= 0.11) | (g < 0), g, torch.zeros_like(g))
     assert torch.equal(ops.lower_bound_bwd(x.to(DEV), g.to(DEV), 0.11).cpu(), ref)
+
+
+BF16_CASES = [c for c in CONV_CASES if c[5] > 8]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_conv_variants_bf16_operands(case):
+    """bf16-operand contraction (float32 accumulate): against the float32 oracle evaluated on bf16-rounded operands
+    (tight: only the accumulation order differs) and against the plain float32 oracle (loose: operand rounding)."""
+    ops = _ops()
+    from masic_amd._lib import PREC_BF16
+    name, B, Cin, H, W, Cout, k, s, tr, masked, in_op, act = case
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w = _rand(*wshape, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    xin = x.abs() if in_op == 1 else (torch.round(x) if in_op == 2 else x)
+    ref_q = _oracle_conv(xin.bfloat16().float(), w.bfloat16().float(), b, k, s, tr, masked, 0, act)
+    ref = _oracle_conv(x, w, b, k, s, tr, masked, in_op, act)
+    desc = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, k // 2, transposed=tr, masked=masked, in_op=in_op, act=act, prec=PREC_BF16)
+    y = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV), desc), b.to(DEV), desc)
+    assert_close(y, ref_q, name + ":bf16 vs bf16-rounded oracle", rtol=2e-5)
+    assert_close(y, ref, name + ":bf16 vs f32 oracle", rtol=3e-2)
