@@ -27,7 +27,9 @@ class GDN(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or self.gamma.requires_grad):
             from masic_amd.autograd import GdnFn
             return GdnFn.apply(x, self.beta, self.gamma, self.inverse, self.beta_min)
-        return _hip.gdn(x, self.beta.detach(), self.gamma.detach(), inverse=self.inverse, beta_min=self.beta_min)
+        from masic_amd import nn as _mnn
+        return _hip.gdn(x, self.beta.detach(), self.gamma.detach(), inverse=self.inverse, beta_min=self.beta_min,
+                        prec=_mnn._PRECISION)
 
 
 class GDN1(GDN):

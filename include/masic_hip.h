@@ -92,6 +92,10 @@ int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias,
  */
 int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* y,
                   int B, int C, int H, int W, int inverse, double beta_min, void* stream);
+/* prec = MASIC_PREC_BF16: the C x C contraction runs as a bf16x3 split product (gamma^ and x^2 as bf16 hi+lo, float32
+ * accumulate, ~2^-16 relative) at 16/3 of the f32 matrix rate -- HBM-bound; MASIC_PREC_F32: exact float32 MFMA */
+int masic_gdn_fwd_ex(const float* x, const float* beta, const float* gamma, float* y,
+                     int B, int C, int H, int W, int inverse, double beta_min, int prec, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Quantisation: compressai/entropy_models/entropy_models.py:98-125 with means=None.

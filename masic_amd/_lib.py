@@ -37,6 +37,7 @@ SIGNATURES = {
     "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
+    "masic_gdn_fwd_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int, _P]),
     "masic_quantize_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     "masic_symbols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "masic_entropy_bottleneck_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [c_float, _P]),

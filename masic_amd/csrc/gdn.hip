@@ -80,6 +80,110 @@ __global__ __launch_bounds__(256) void gdn_mfma_c128(const float* __restrict__ x
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3 variant (used when the forward runs with bf16 operands): gamma^ and x^2 are each split into bf16 hi + lo and
+// n = ghi*xhi + ghi*xlo + glo*xhi on v_mfma_f32_32x32x16_bf16 (relative error ~2^-16 of a term, float32 accumulate) at
+// 16/3 of the f32 matrix rate, which leaves the kernel HBM-bound.  No LDS round trip for x: with B = x^2 the fragment
+// of lane (pixel j, half h) is 8 channels of ONE pixel, i.e. 8 coalesced NCHW loads, and the k <-> channel assignment
+// of each MFMA step is chosen so that the 64 channels a lane loads are exactly the 64 output channels it owns in the
+// accumulator layout -- x is read from HBM once, reused from registers in the epilogue, and y is written once.
+// gamma^ fragments (hi, lo) sit in LDS in fragment order, built once per (persistent) workgroup.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256, 2) void gdn_bf16x3_c128(const float* __restrict__ x, const float* __restrict__ beta,
+                                                       const float* __restrict__ gamma, float* __restrict__ y,
+                                                       int HW, int strips_per_image, int nstrips, int inverse,
+                                                       float beta_bound, float gamma_bound, float pedestal) {
+    constexpr int C = 128;
+    __shared__ __attribute__((aligned(16))) uint4 Ahi[32 * 64];      // [(m*8+s)][lane] 8 bf16
+    __shared__ __attribute__((aligned(16))) uint4 Alo[32 * 64];
+    __shared__ float bet[C];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    // channel held by (step s, half hh, element c): 32-block q = s>>1, half-block t = s&1
+    auto chan = [](int s, int hh, int c) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (c >> 2) + 4 * hh + (c & 3); };
+
+    for (int idx = tid; idx < 32 * 64; idx += 256) {
+        const int ms = idx >> 6, l = idx & 63;
+        const int m = ms >> 3, s = ms & 7, r = l & 31, hh = l >> 5;
+        __bf16 vh[8], vl[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float gr = fmaxf(gamma[(size_t)(32 * m + r) * C + chan(s, hh, c)], gamma_bound);
+            split_bf16(__fsub_rn(__fmul_rn(gr, gr), pedestal), vh[c], vl[c]);
+        }
+        gbf16x8 ph, pl;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { ph[c] = vh[c]; pl[c] = vl[c]; }
+        Ahi[idx] = __builtin_bit_cast(uint4, ph);
+        Alo[idx] = __builtin_bit_cast(uint4, pl);
+    }
+    if (tid < C) {
+        const float bv = fmaxf(beta[tid], beta_bound);
+        bet[tid] = __fsub_rn(__fmul_rn(bv, bv), pedestal);
+    }
+    __syncthreads();
+
+    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int strip = gwave; strip < nstrips; strip += nwaves) {
+        const int b = __builtin_amdgcn_readfirstlane(strip / strips_per_image);
+        const int sp0 = __builtin_amdgcn_readfirstlane((strip - b * strips_per_image) * 32);
+        // wave-uniform base + ONE 32-bit per-lane index (half h owns channels +4h); the channel part of every address is
+        // a scalar offset, so the 64 loads / stores need no per-channel address registers
+        const float* xw = x + (size_t)b * C * HW + sp0;
+        float* yw = y + (size_t)b * C * HW + sp0;
+        const unsigned vidx = (unsigned)(4 * h) * (unsigned)HW + (unsigned)j;
+        float xv[8][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xv[s][c] = (xw + (size_t)chan(s, 0, c) * HW)[vidx];
+        f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            gbf16x8 bh, bl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                __bf16 hi, lo;
+                split_bf16(__fmul_rn(xv[s][c], xv[s][c]), hi, lo);
+                bh[c] = hi; bl[c] = lo;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const gbf16x8 ah = __builtin_bit_cast(gbf16x8, Ahi[(m * 8 + s) * 64 + lane]);
+                const gbf16x8 al = __builtin_bit_cast(gbf16x8, Alo[(m * 8 + s) * 64 + lane]);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the 64 fragment reads from being hoisted to the top (register blow-up)
+        }
+        // epilogue: accumulator register e of block m <-> the value this lane loaded as xv[2m + (e>>3)][4*((e>>2)&1) + (e&3)]
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch0 = 32 * m + (e & 3) + 8 * (e >> 2);          // + 4h per lane half
+                const float xval = xv[2 * m + (e >> 3)][4 * ((e >> 2) & 1) + (e & 3)];
+                const float n = acc[m][e] + bet[ch0 + 4 * h];
+                const float sq = sqrtf(n);
+                (yw + (size_t)ch0 * HW)[vidx] = inverse ? xval * sq : xval * (1.0f / sq);
+            }
+    }
+}
+
 // generic: 64 threads per block, one pixel per thread, x^2 column in LDS
 __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, const float* __restrict__ beta,
                                                   const float* __restrict__ gamma, float* __restrict__ y,
@@ -115,8 +219,16 @@ __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, c
 
 }  // namespace
 
+extern "C" int masic_gdn_fwd_ex(const float* x, const float* beta, const float* gamma, float* y,
+                                int B, int C, int H, int W, int inverse, double beta_min, int prec, void* stream);
+
 extern "C" int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* y,
                              int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    return masic_gdn_fwd_ex(x, beta, gamma, y, B, C, H, W, inverse, beta_min, MASIC_PREC_F32, stream);
+}
+
+extern "C" int masic_gdn_fwd_ex(const float* x, const float* beta, const float* gamma, float* y,
+                                int B, int C, int H, int W, int inverse, double beta_min, int prec, void* stream) {
     MASIC_REQUIRE(x && beta && gamma && y, MASIC_ERR_ARG, "gdn_fwd: null pointer");
     MASIC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, MASIC_ERR_SHAPE, "gdn_fwd: non-positive dimension");
     MASIC_REQUIRE(C <= 512, MASIC_ERR_UNSUPPORTED, "gdn_fwd: C=%d > 512", C);
@@ -127,7 +239,12 @@ extern "C" int masic_gdn_fwd(const float* x, const float* beta, const float* gam
     const float gamma_bound = (float)__builtin_sqrt(ped);
     const int HW = H * W;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 128 && HW % PT == 0) {
+    if (C == 128 && HW % 32 == 0 && prec == MASIC_PREC_BF16) {
+        const int spi = HW / 32, nstrips = spi * B;
+        const int grid = nstrips < 4 * 512 ? (nstrips + 3) / 4 : 512;
+        hipLaunchKernelGGL(gdn_bf16x3_c128, dim3(grid), dim3(256), 0, st, x, beta, gamma, y, HW, spi, nstrips, inverse,
+                           beta_bound, gamma_bound, pedestal);
+    } else if (C == 128 && HW % PT == 0) {
         const int tpi = HW / PT, ntiles = tpi * B;
         const int grid = ntiles < 1024 ? ntiles : 1024;
         hipLaunchKernelGGL(gdn_mfma_c128, dim3(grid), dim3(256), 0, st, x, beta, gamma, y, HW, tpi, ntiles, inverse,

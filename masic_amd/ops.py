@@ -145,13 +145,13 @@ def _conv2d(x, packed, bias, desc, out=None, gate=None, res1=None, res2=None):
 
 
 # --------------------------------------------------------------------------------------------- GDN
-def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+def gdn(x, beta, gamma, inverse=False, beta_min=1e-6, prec=_lib.PREC_F32):
     _dev(x, "gdn input"); _dev(beta, "beta"); _dev(gamma, "gamma")
     B, C, H, W = x.shape
     if beta.numel() != C or tuple(gamma.shape) != (C, C):
         raise RuntimeError("masic_amd.gdn: parameter shapes do not match the input channels")
     y = torch.empty_like(x)
-    check(lib.masic_gdn_fwd(_p(x), _p(beta), _p(gamma), _p(y), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_fwd")
+    check(lib.masic_gdn_fwd_ex(_p(x), _p(beta), _p(gamma), _p(y), B, C, H, W, int(inverse), float(beta_min), int(prec), _stream()), "gdn_fwd")
     return y
 
 

@@ -259,3 +259,22 @@ def test_conv_variants_bf16_operands(case):
     y = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV), desc), b.to(DEV), desc)
     assert_close(y, ref_q, name + ":bf16 vs bf16-rounded oracle", rtol=2e-5)
     assert_close(y, ref, name + ":bf16 vs f32 oracle", rtol=3e-2)
+
+
+@pytest.mark.parametrize("H,W,inverse", [(32, 48, False), (16, 24, True), (8, 8, False)])
+def test_gdn_bf16x3_split_product(H, W, inverse):
+    """C=128 GDN with the contraction as a bf16 hi/lo split product (used when the forward runs with bf16 operands):
+    stays within a few 1e-5 of the float32 oracle."""
+    ops = _ops()
+    from masic_amd import synth
+    from masic_amd._lib import PREC_BF16
+    C = 128
+    rs = np.random.RandomState(H)
+    x = _rand(2, C, H, W, seed=10, scale=3.0)
+    beta = synth.synth_tensor("g.beta", (C,), rs)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs)
+    gamma[0, 1] = 1e-7
+    ref = O.gdn(x, beta, gamma, inverse=inverse)
+    y = ops.gdn(x.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse, prec=PREC_BF16)
+    e = assert_close(y, ref, "gdn bf16x3", rtol=5e-5)
+    print(f"gdn bf16x3 relative error {e:.2e}")
