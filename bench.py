@@ -26,6 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "coremasic", "mywork")):
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -64,7 +65,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("MASIC_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("MASIC_PRECISION", "bf16"),
                     help="operand precision of the forward MFMA contractions (float32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3,
@@ -124,8 +125,9 @@ def main():
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
-    roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+    peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in dom else F32_MFMA_PEAK_TFLOPS
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": tflops / peak, "traffic": None,
                 "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,
                 "flops_per_launch": a["flops"] / a["launches"],
                 "share_of_step_time": a["ms"] / (elapsed * 1e3),
@@ -133,9 +135,39 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roofline["traffic"] = json.load(open(pmc)).get(dom)
+            roofline["traffic"] = json.load(open(pmc)).get(dom)   # keyed by kernel symbol; null when not profiled for it
         except Exception:
             pass
+
+    # ---- the float32 parity path on the same inputs: its rate, and what bf16 operands cost in codec terms
+    accuracy = None
+    f32_info = None
+    if args.precision == "bf16":
+        from masic_amd.loss import rate_distortion
+        with torch.no_grad():
+            sym_b = net.symbol_streams(x1, x2, hm)
+            crit_b = rate_distortion(out, x1, x2, 0.01)
+            mnn.set_precision("f32")
+            out_f = net(x1, x2, hm)
+            sym_f = net.symbol_streams(x1, x2, hm)
+            crit_f = rate_distortion(out_f, x1, x2, 0.01)
+            barrier()
+            t0 = time.perf_counter()
+            nf = max(2, args.steps // 4)
+            for _ in range(nf):
+                net(x1, x2, hm)
+            barrier()
+            tf = time.perf_counter() - t0
+            mnn.set_precision("bf16")
+        nsym = sum(v.numel() for v in sym_f.values())
+        nbad = sum(int((sym_b[k] != sym_f[k]).sum()) for k in sym_f)
+        accuracy = {"bpp_bf16": float(crit_b["bpp_loss"]), "bpp_f32": float(crit_f["bpp_loss"]),
+                    "bpp_rel_delta": float(crit_b["bpp_loss"]) / float(crit_f["bpp_loss"]) - 1.0,
+                    "psnr1_delta_db": crit_b["psnr1"] - crit_f["psnr1"], "psnr2_delta_db": crit_b["psnr2"] - crit_f["psnr2"],
+                    "symbol_mismatch_rate": nbad / nsym, "symbols": nsym,
+                    "note": "bf16-operand forward vs the float32 parity path (itself within 1e-4 of the reference, symbols bit-exact "
+                            "outside the tie zone), same inputs and weights, rank 0"}
+        f32_info = {"value": world * B * nf / tf, "unit": "stereo pairs/s", "steps": nf, "ms_per_step": tf / nf * 1e3, "dtype": "f32"}
 
     train_info = None
     if args.train_steps > 0:
@@ -157,21 +189,27 @@ def main():
             tt = float(t.item())
         train_info = {"value": world * B * args.train_steps / tt, "unit": "stereo pairs/s", "steps": args.train_steps,
                       "ms_per_step": tt / args.train_steps * 1e3, "loss_after": float(crit["loss"]),
-                      "what": "forward + RD loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
-                              " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146), f32"}
+                      "what": f"forward ({args.precision} operands) + RD loss + backward (f32)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
+                              " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146)"}
 
     if rank == 0:
         line = {
             "metric": "stereo pairs/sec (enc+dec)", "value": world * B * args.steps / elapsed, "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"HSIC(N=128,M=192,K=5) eval forward (enc+dec both views), {B}x3x{H}x{W} stereo pairs per GPU "
                                    "(BASELINE.json configs[1] shape), inputs resident in HBM",
                        "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world} (pairs sharded, no data-path collective)"},
             "roofline": roofline,
         }
+        extras = {}
         if train_info is not None:
-            line["extras"] = {"train_step": train_info}
+            extras["train_step"] = train_info
+        if f32_info is not None:
+            extras["f32_parity_path"] = f32_info
+            extras["accuracy_vs_f32"] = accuracy
+        if extras:
+            line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, M, K, H, W, seed=100)
         print(json.dumps(line), flush=True)

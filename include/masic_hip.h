@@ -77,6 +77,8 @@ int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc
  *   6: deconv5s2_small_cout; launches = phases (1, or
  *   stride^2 for transposed convs). Returns variant, writes *launches if non-NULL; <0 on bad desc. */
 int masic_conv_variant(const masic_conv_desc_t* d, int* launches);
+/* the kernel symbol (as rocprofv3 prints it, without namespace/arguments) that this layer launches */
+int masic_conv_kernel_name(const masic_conv_desc_t* d, char* buf, size_t n);
 /* y = act(conv(in_op(x), w) + bias) [* gate].  bias may be NULL. */
 int masic_conv2d_fwd(const float* x, const void* w_packed, const float* bias, const float* gate,
                      float* y, const masic_conv_desc_t* d, void* stream);

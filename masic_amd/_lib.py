@@ -33,6 +33,7 @@ SIGNATURES = {
     "masic_last_error": (ctypes.c_char_p, []),
     "masic_conv_packed_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "masic_conv_variant": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
+    "masic_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_size_t]),
     "masic_conv_pack_weight": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),

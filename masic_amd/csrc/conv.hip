@@ -251,6 +251,57 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- shared epilogue: bias, activation, gate, residual adds, NCHW store (32 consecutive pixels per half-wave).
+// Every load (bias, gate, residuals) is issued BEFORE the arithmetic of its tile: a load inside the per-element loop
+// would put an s_waitcnt vmcnt(0) in front of every store and serialise the epilogue on memory latency.
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, const ConvGeom& g, f32x16 (&acc)[WM][WN], int b, int m0w,
+                                               int r0, int c0, int wn, int jr, int jc, int h) {
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+    float bv[WM][16];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = m0w + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            bv[m][e] = (a.bias != nullptr) ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
+        const bool pok = r < g.Hp && c < g.Wp;
+        const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+        const size_t opix = (size_t)oh * a.Wo + ow;
+        const float gv = (a.gate != nullptr) ? a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix] : 1.0f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            float rv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rv[e] = 0.0f;
+            if (a.res1 != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0w + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    rv[e] = a.res1[((size_t)b * a.Cout + (co < a.Cout ? co : a.Cout - 1)) * oplane + opix];
+                }
+                if (a.res2 != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = m0w + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        rv[e] += a.res2[((size_t)b * a.Cout + (co < a.Cout ? co : a.Cout - 1)) * oplane + opix];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0w + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float v = apply_act(acc[m][n][e] + bv[m][e], a.act) * gv + rv[e];
+                if (pok && co < a.Cout) a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+            }
+        }
+    }
+}
+
 constexpr int MAXE = 6;   // DMA wave-instructions per wave per channel plane (patch <= 1536 floats)
 constexpr int MAXQ = 8;   // 16-byte-DMA wave-instructions per wave per chunk (1x1 layers: KC*PSZ <= 8192 floats)
 
@@ -424,31 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const IgemmArgs a) {
         }
     }
 
-    // ---- epilogue: bias, activation, gate, NCHW store (32 consecutive pixels per half-wave)
-    const size_t oplane = (size_t)a.Ho * a.Wo;
-#pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
-        if (r >= g.Hp || c >= g.Wp) continue;
-        const int oh = r * g.os + g.oph, ow = c * g.os + g.opw;
-        const size_t opix = (size_t)oh * a.Wo + ow;
-        float gv = 1.0f;
-        if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = m0 + wm * (32 * WM) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < a.Cout) {
-                    float v = acc[m][n][e] + (a.bias ? a.bias[co] : 0.0f);
-                    v = apply_act(v, a.act);
-                    if (a.gate) v *= gv;
-                    if (a.res1) v += a.res1[((size_t)b * a.Cout + co) * oplane + opix];
-                    if (a.res2) v += a.res2[((size_t)b * a.Cout + co) * oplane + opix];
-                    a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
-                }
-            }
-    }
+    igemm_epilogue<WM, WN>(a, g, acc, b, m0 + wm * (32 * WM), r0, c0, wn, jr, jc, h);
 }
 
 // ------------------------------------------------------------------------------------------ direct
@@ -723,25 +750,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
     const size_t a_c16_stride = (size_t)a.Cout_pad * 16;
 
     float pre[PF ? 4 : 1][8];
+    // raw, unconditional loads from clamped (always valid) addresses; the zero-fill select happens at store time so that
+    // nothing consumes a loaded value here (a consumer would put an s_waitcnt behind every single load)
     auto load_tasks = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < (PF ? 4 : 1); ++i) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int cg = cc + gch_t[i] + c;
-                pre[i][c] = (goff[i] >= 0 && cg < a.Cin) ? xb[(size_t)cg * plane + goff[i]] : 0.0f;
+                pre[i][c] = xb[(size_t)(cg < a.Cin ? cg : a.Cin - 1) * plane + (goff[i] >= 0 ? goff[i] : 0)];
             }
         }
     };
-    auto store_tasks = [&]() {
+    auto store_tasks = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < (PF ? 4 : 1); ++i) {
             if (goff[i] == -2) continue;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                v[c] = (goff[i] >= 0 && cc + gch_t[i] + c < a.Cin) ? apply_inop(pre[i][c], INOP) : 0.0f;
             uint4 q;
-            q.x = pack_bf16x2(apply_inop(pre[i][0], INOP), apply_inop(pre[i][1], INOP));
-            q.y = pack_bf16x2(apply_inop(pre[i][2], INOP), apply_inop(pre[i][3], INOP));
-            q.z = pack_bf16x2(apply_inop(pre[i][4], INOP), apply_inop(pre[i][5], INOP));
-            q.w = pack_bf16x2(apply_inop(pre[i][6], INOP), apply_inop(pre[i][7], INOP));
+            q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]);
+            q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
             *reinterpret_cast<uint4*>(patch + loff[i]) = q;
         }
     };
@@ -750,21 +781,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
     for (int cc = 0; cc < a.Cin_pad; cc += a.KC) {
         // ---- stage: NCHW float32 -> [pixel][channel] bf16
         if (PF) {
-            store_tasks();
+            store_tasks(cc);
         } else {
             for (int gch = 0; gch < a.KC; gch += 8) {
+                // all loads of this 8-channel group first (up to 48 in flight per lane), then convert + write:
+                // one memory latency per group instead of one per pixel task
+                float v[NT][8];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    if (goff[i] == -2) continue;
-                    float v[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const int cg = cc + gch + c;
-                        v[c] = (goff[i] >= 0 && cg < a.Cin) ? apply_inop(xb[(size_t)cg * plane + goff[i]], INOP) : 0.0f;
+                        const bool ok = goff[i] >= 0 && cg < a.Cin;
+                        const float t = xb[(size_t)(cg < a.Cin ? cg : a.Cin - 1) * plane + (goff[i] >= 0 ? goff[i] : 0)];
+                        v[i][c] = ok ? t : 0.0f;
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (goff[i] == -2) continue;
                     uint4 q;
-                    q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]);
-                    q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
+                    q.x = pack_bf16x2(apply_inop(v[i][0], INOP), apply_inop(v[i][1], INOP));
+                    q.y = pack_bf16x2(apply_inop(v[i][2], INOP), apply_inop(v[i][3], INOP));
+                    q.z = pack_bf16x2(apply_inop(v[i][4], INOP), apply_inop(v[i][5], INOP));
+                    q.w = pack_bf16x2(apply_inop(v[i][6], INOP), apply_inop(v[i][7], INOP));
                     *reinterpret_cast<uint4*>(patch + (size_t)(tid + 256 * i) * KCP + gch) = q;
                 }
             }
@@ -815,31 +855,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
         __syncthreads();
     }
 
-    // ---- epilogue (same as the f32 kernel)
-    const size_t oplane = (size_t)a.Ho * a.Wo;
-#pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const int r = r0 + (wn * WN + n) * a.SR + jr, c = c0 + jc;
-        if (r >= g.Hp || c >= g.Wp) continue;
-        const int oh = r * g.os + g.oph, ow = c * g.os + g.opw;
-        const size_t opix = (size_t)oh * a.Wo + ow;
-        float gv = 1.0f;
-        if (a.gate) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = m0 + wm * (32 * WM) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < a.Cout) {
-                    float v = acc[m][n][e] + (a.bias ? a.bias[co] : 0.0f);
-                    v = apply_act(v, a.act);
-                    if (a.gate) v *= gv;
-                    if (a.res1) v += a.res1[((size_t)b * a.Cout + co) * oplane + opix];
-                    if (a.res2) v += a.res2[((size_t)b * a.Cout + co) * oplane + opix];
-                    a.y[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
-                }
-            }
-    }
+    igemm_epilogue<WM, WN>(a, g, acc, b, m0 + wm * (32 * WM), r0, c0, wn, jr, jc, h);
 }
 
 // packed bf16 weights: [phase-tap][ci/16][co (padded to BM)][16 ci]
@@ -915,6 +931,20 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     if (c.wvm == 1) return c.wm == 1 ? 8 : 9;
     if (c.wm == 2) return c.wn == 4 ? 5 : 7;
     return c.wn == 4 ? 4 : (c.wn == 2 ? 3 : 2);
+}
+
+extern "C" int masic_conv_kernel_name(const masic_conv_desc_t* d, char* buf, size_t n) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(buf && n > 0, MASIC_ERR_ARG, "conv_kernel_name: null buffer");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const ConvCfg c = choose_cfg(*d, g, np);
+    if (c.direct == 2) snprintf(buf, n, "deconv5s2_small_cout");
+    else if (c.direct) snprintf(buf, n, "conv_direct_f32<%d>", d->Cout <= 3 ? 3 : 8);
+    else if (c.bf16) snprintf(buf, n, "conv_igemm_bf16<%d, %d, %d, %d, %s>", c.wvm, c.wm, c.wn, d->in_op, c.pf ? "true" : "false");
+    else snprintf(buf, n, "conv_igemm_f32<%d, %d, %d, %d, %s>", c.wvm, c.wm, c.wn, d->in_op, c.vec4 ? "true" : "false");
+    return MASIC_OK;
 }
 
 extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {

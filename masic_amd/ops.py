@@ -64,10 +64,6 @@ def pack_conv_weight(weight, desc):
 class KernelTimer:
     """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
-    VARIANTS = {0: "conv_direct_f32<3>", 1: "conv_direct_f32<8>", 2: "conv_igemm_f32<1,1>", 3: "conv_igemm_f32<1,2>",
-                4: "conv_igemm_f32<1,4>", 5: "conv_igemm_f32<2,4>", 6: "deconv5s2_small_cout", 7: "conv_igemm_f32<2,2>",
-                8: "conv_igemm_f32<1w,1,2>", 9: "conv_igemm_f32<1w,3,2>", 10: "conv_igemm_bf16"}
-
     def __init__(self):
         self.records = []
 
@@ -75,7 +71,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         agg = {}
         for variant, launches, flops, nbytes, e0, e1 in self.records:
-            a = agg.setdefault(self.VARIANTS[variant], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a = agg.setdefault(variant, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += launches
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
@@ -105,7 +101,10 @@ def conv_algorithmic_work(desc):
 def conv2d(x, packed, bias, desc, out=None, gate=None, res1=None, res2=None):
     if _timer is not None:
         n = ctypes.c_int(0)
-        variant = lib.masic_conv_variant(ctypes.byref(desc), ctypes.byref(n))
+        lib.masic_conv_variant(ctypes.byref(desc), ctypes.byref(n))
+        buf = ctypes.create_string_buffer(96)
+        lib.masic_conv_kernel_name(ctypes.byref(desc), buf, 96)
+        variant = buf.value.decode()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
