@@ -198,8 +198,10 @@ int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspa
  *   8 reparam max(a,s0)^2-s1 (parametrizers.py:61-64)   9 reparam_bwd (a=grad, b=stored param, s0=bound; incl. LowerBound rule)
  *   10 a+b */
 int masic_elementwise(const float* a, const float* b, float* y, size_t n, int op, float s0, float s1, void* stream);
-/* out[c] = sum over batch and pixels of channel coff+c of x[B,ctot,HW]  (bias / beta gradients; deterministic) */
-int masic_channel_sum(const float* x, float* out, int B, int C, int HW, int ctot, int coff, void* stream);
+/* out[c] = sum over batch and pixels of channel coff+c of x[B,ctot,HW]  (bias / beta gradients; deterministic two-stage
+ * reduction through `workspace` >= masic_channel_sum_workspace_bytes(C) bytes) */
+size_t masic_channel_sum_workspace_bytes(int C);
+int masic_channel_sum(const float* x, float* out, void* workspace, int B, int C, int HW, int ctot, int coff, void* stream);
 /* y[B,C,HW] = x[B,ctot,HW][:, coff:coff+C]  (backward of copy_view / torch.cat) */
 int masic_slice_copy(const float* x, float* y, int B, int C, int HW, int ctot, int coff, void* stream);
 /* backward of y = x * gate[:,gate_c]: gx = g*gate, ggate[:,gate_c] = sum_c g*x (other gate channels untouched) */

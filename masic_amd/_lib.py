@@ -58,7 +58,8 @@ SIGNATURES = {
     "masic_conv2d_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "masic_conv2d_wgrad": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_elementwise": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, c_float, _P]),
-    "masic_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_channel_sum_workspace_bytes": (c_size_t, [c_int]),
+    "masic_channel_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_slice_copy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_gate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_softmax_k_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

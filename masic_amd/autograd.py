@@ -46,7 +46,8 @@ class ConvFn(Function):
         Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=PREC_F32)
+            from . import nn as _mnn      # input gradients use the forward's operand precision; weight gradients stay f32
+            d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
             if (d.Ho, d.Wo) != (Hi, Wi):
                 raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
             gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)

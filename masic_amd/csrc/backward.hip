@@ -53,15 +53,23 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     }
 }
 
-// per-channel sum over batch and pixels: out[c] = sum_{b,p} x[b,c,p]   (bias / beta gradients); one block per channel
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+// per-channel sum over batch and pixels: out[c] = sum_{b,p} x[b,c,p]   (bias / beta gradients).
+// Two deterministic stages: grid (C, NSPLIT) partial sums in float64 over strided (b, pixel-chunk) slices, then one
+// block per channel adds the NSPLIT partials in a fixed order.
+constexpr int CS_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, double* __restrict__ partial,
                                                           int B, int C, int HW, int ctot, int coff) {
     __shared__ double red[256];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y;
+    // chunks of 1024 pixels, dealt round-robin over (b, chunk) pairs to the NSPLIT blocks of this channel
+    const int chunks = (HW + 1023) / 1024;
     double acc = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int w = sp; w < B * chunks; w += CS_SPLIT) {
+        const int b = w / chunks, ck = w - b * chunks;
         const float* p = x + ((size_t)b * ctot + coff + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) acc += (double)p[i];
+        const int lo = ck * 1024, hi = lo + 1024 < HW ? lo + 1024 : HW;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) acc += (double)p[i];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -69,7 +77,15 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = (float)red[0];
+    if (threadIdx.x == 0) partial[(size_t)c * CS_SPLIT + sp] = red[0];
+}
+
+__global__ __launch_bounds__(64) void channel_sum_stage2(const double* __restrict__ partial, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int i = 0; i < CS_SPLIT; ++i) acc += partial[(size_t)c * CS_SPLIT + i];
+    out[c] = (float)acc;
 }
 
 // slice of a wider buffer -> contiguous (the backward of copy_view / torch.cat)
@@ -423,10 +439,13 @@ extern "C" int masic_elementwise(const float* a, const float* b, float* y, size_
     return masic_launch_status("elementwise");
 }
 
-extern "C" int masic_channel_sum(const float* x, float* out, int B, int C, int HW, int ctot, int coff, void* stream) {
-    MASIC_REQUIRE(x && out, MASIC_ERR_ARG, "channel_sum: null pointer");
+extern "C" size_t masic_channel_sum_workspace_bytes(int C) { return (size_t)C * CS_SPLIT * sizeof(double); }
+
+extern "C" int masic_channel_sum(const float* x, float* out, void* workspace, int B, int C, int HW, int ctot, int coff, void* stream) {
+    MASIC_REQUIRE(x && out && workspace, MASIC_ERR_ARG, "channel_sum: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "channel_sum: view out of range");
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW, ctot, coff);
+    hipLaunchKernelGGL(channel_sum_stage1, dim3(C, CS_SPLIT), dim3(256), 0, (hipStream_t)stream, x, (double*)workspace, B, C, HW, ctot, coff);
+    hipLaunchKernelGGL(channel_sum_stage2, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, out, C);
     return masic_launch_status("channel_sum");
 }
 

@@ -366,7 +366,8 @@ def channel_sum(x, C=None, coff=0):
     C = ctot if C is None else C
     HW = x.numel() // (B * ctot)
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    check(lib.masic_channel_sum(_p(x), _p(out), B, C, HW, ctot, coff, _stream()), "channel_sum")
+    ws = torch.empty(lib.masic_channel_sum_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
+    check(lib.masic_channel_sum(_p(x), _p(out), _p(ws), B, C, HW, ctot, coff, _stream()), "channel_sum")
     return out
 
 
