@@ -8,12 +8,14 @@
 //   ConvTranspose2d: P = x  (a = ci), Q = dy (q = co)  -> dW laid out [Cin][Cout][kh][kw]
 // i.e. a GEMM  dW_t[a][q] = P[a][pixel] * Q_t[pixel][q]  per tap t whose K dimension is the pixel index.
 //
-// A workgroup owns a 64(a) x 64(q) tile of dW for ONE kernel row kh and a strided share of the pixel tiles (2 coarse
-// rows x 32 columns).  Per pixel tile the P rows and the two Q rows that this kernel row touches are staged into LDS
-// by global->LDS DMA (channel pitch odd, so that the 32 lanes of an MFMA operand -- 32 different channels -- hit 32
-// different banks); each wave issues v_mfma_f32_32x32x2_f32 with k = a pixel pair, one accumulator per kw.  Partial
-// tiles of all workgroups are reduced with float atomics into a [kh][kw][a][q] workspace (128-byte segments per
-// half wave = full atomic rate) and a final pass transposes it into the weight layout.
+// A workgroup (8 waves) owns a 64(a) x 32(q) tile of dW for ALL taps (1x1 layers: 64 x 128) and a strided share of the
+// pixel tiles (2 coarse rows x 32 columns): wave = (which 32 a-channels, tap group), 7 accumulators of 32x32 per wave
+// for a 5x5 kernel.  Per pixel tile the P rows and the whole fine patch of Q (s+KH rows) are staged ONCE into LDS by
+// global->LDS DMA -- double buffered, the next tile lands while this one is contracted -- with an odd channel pitch so
+// that the 32 lanes of an MFMA operand (32 different channels) hit 32 different banks; each wave issues
+// v_mfma_f32_32x32x2_f32 with k = a pixel pair.  Partial tiles of all workgroups are reduced with float atomics into a
+// [tap][a][q] workspace (q contiguous: 128-byte segments per half wave = full atomic rate) and a final pass transposes
+// it into the weight layout.
 #include "common.h"
 
 namespace {
@@ -30,91 +32,109 @@ struct WgradArgs {
     int B, CA, CQ;
     int p_ctot, p_coff, q_ctot, q_coff;
     int Hc, Wc, Hf, Wf;
-    int s, pad, KH;
+    int s, pad, KH, KW;
     int tiles_w, tiles_h, ntiles, nsplit;
     int q_tiles;
-    int PWq, QG, QS;      // fine columns per row of the patch, DMA groups per channel, channel pitch (odd)
+    int PWq, QROWS, QPIX, QG, QS;   // fine patch: columns, rows, pixels, DMA groups per channel, channel pitch (odd)
 };
 
 constexpr int PS = 65;    // P-tile channel pitch (64 pixels + 1)
 
-template <int KW>
-__global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a) {
+// 8 waves: wave = (wa: which 32 of the 64 a-channels, u: tap group [QT == 1] or 32-wide q sub-tile [QT == 4])
+//   T = KH*KW taps; QT q sub-tiles of 32 per block; each wave accumulates TPW taps of one 32a x 32q tile
+template <int QT, int TPW>
+__global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
+
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Pt = lds;                 // [64][PS]
-    float* Qt = lds + 64 * PS;       // [64][QS]
+    const int buf_sz = 64 * PS + 32 * QT * a.QS;     // [P 64][PS] | [Q 32*QT][QS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave & 1, wq = wave >> 1;
+    const int wa = wave & 1, u = wave >> 1;
+    const int tg = QT == 1 ? u : 0, qsub = QT == 1 ? 0 : u;
     const int j = lane & 31, h = lane >> 5;
-    const int a0 = (blockIdx.x / a.q_tiles) * 64, q0 = (blockIdx.x % a.q_tiles) * 64;
-    const int kh = blockIdx.y;
+    const int a0 = (blockIdx.x / a.q_tiles) * 64, q0 = (blockIdx.x % a.q_tiles) * (32 * QT);
+    const int T = a.KH * a.KW;
+    const int t_lo = tg * TPW, t_hi = (t_lo + TPW < T) ? t_lo + TPW : T;     // this wave's taps [t_lo, t_hi)
 
-    f32x16 acc[KW];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int k = 0; k < KW; ++k)
+    for (int k = 0; k < TPW; ++k)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[k][e] = 0.0f;
+    int toff[TPW];                                    // patch offset of tap k (row kh, column kw)
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int t = t_lo + k < T ? t_lo + k : T - 1;
+        toff[k] = (t / a.KW) * a.PWq + (t % a.KW);
+    }
 
     const size_t cplane = (size_t)a.Hc * a.Wc, fplane = (size_t)a.Hf * a.Wf;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
-    // lane -> (row, col) inside the P tile and inside each Q DMA group
     const int prr = lane >> 5, pcc = lane & 31;
 
-    for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit) {
+    auto issue = [&](int tile, float* buf) {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
         const int r0 = (trem / a.tiles_w) * 2, c0 = (trem % a.tiles_w) * 32;
-        // ---- stage P: 64 channels x (2 rows x 32 cols)
-        {
+        float* Pt = buf;
+        float* Qt = buf + 64 * PS;
+        {   // P: 64 channels x (2 rows x 32 cols), 8 channels per wave
             const int r = r0 + prr, c = c0 + pcc;
             const bool pok = r < a.Hc && c < a.Wc;
-            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * cplane + (size_t)r * a.Wc + c;
-            for (int ch = wave; ch < 64; ch += 4) {
+            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * cplane + (size_t)(pok ? r : 0) * a.Wc + (pok ? c : 0);
+            for (int ch = wave; ch < 64; ch += 8) {
                 const bool ok = pok && (a0 + ch) < a.CA;
                 dma4(ok ? pb + (size_t)(a0 + ch) * cplane : g_zero_wg, Pt + ch * PS);
             }
         }
-        // ---- stage Q: 64 channels x (2 fine rows of this kernel row x PWq cols)
-        {
+        {   // Q: 32*QT channels x (QROWS fine rows x PWq cols)
             const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * fplane;
             for (int g = 0; g < a.QG; ++g) {
                 const int e = g * 64 + lane;
                 const int rr = e / a.PWq, pc = e - rr * a.PWq;
-                const int fh = (r0 + rr) * a.s + kh - a.pad, fw = c0 * a.s - a.pad + pc;
-                const bool qok = rr < 2 && (r0 + rr) < a.Hc && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
-                const float* src = qb + (size_t)fh * a.Wf + fw;
-                for (int ch = wave; ch < 64; ch += 4) {
-                    const bool ok = qok && (q0 + ch) < a.CQ;
-                    dma4(ok ? src + (size_t)(q0 + ch) * fplane : g_zero_wg, Qt + ch * a.QS + g * 64);
+                const int fh = r0 * a.s - a.pad + rr, fw = c0 * a.s - a.pad + pc;
+                const bool inpatch = e < a.QPIX;
+                const bool qok = inpatch && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+                const float* src = qb + (size_t)(qok ? fh : 0) * a.Wf + (qok ? fw : 0);
+                if (inpatch) {                                   // lanes beyond the patch must not spill into the next channel
+                    for (int ch = wave; ch < 32 * QT; ch += 8) {
+                        const bool ok = qok && (q0 + ch) < a.CQ;
+                        dma4(ok ? src + (size_t)(q0 + ch) * fplane : g_zero_wg, Qt + ch * a.QS + g * 64);
+                    }
                 }
             }
         }
-        __syncthreads();     // vmcnt(0) + barrier: the tile has landed
-        // ---- contraction over the 64 pixels of the tile (k = pixel pair)
-        const float* pa = Pt + (wa * 32 + j) * PS + h;
-        const float* qa = Qt + (wq * 32 + j) * a.QS + h * a.s;
-#pragma unroll 2
+    };
+
+    int it = 0;
+    if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
+        float* cur = lds + (it & 1) * buf_sz;
+        __syncthreads();                                   // this tile landed; everyone left the other buffer
+        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        const float* pa = cur + (wa * 32 + j) * PS + h;
+        const float* qa = cur + 64 * PS + (qsub * 32 + j) * a.QS + h * a.s;
         for (int kk = 0; kk < 32; ++kk) {
             const int px = 2 * kk;                      // pixel of lane half 0; half 1 takes px+1 (same row: 32 is even)
             const int rr = px >> 5, cc = px & 31;
             const float av = pa[px];
-            const float* qrow = qa + rr * a.PWq + cc * a.s;
-            float bv[KW];
+            const float* qrow = qa + (rr * a.s) * a.PWq + cc * a.s;
+            float bv[TPW];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) bv[k] = qrow[k];
+            for (int k = 0; k < TPW; ++k) bv[k] = qrow[toff[k]];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
+            for (int k = 0; k < TPW; ++k)
+                if (t_lo + k < t_hi) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
         }
-        __syncthreads();     // everyone done reading before the next tile overwrites
     }
 
-    // ---- reduce into the [kh][kw][a][q] workspace (q contiguous: 128-byte segments per half wave)
-    const int q = q0 + wq * 32 + j;
+    // ---- reduce into the [tap][a][q] workspace (q contiguous: 128-byte segments per half wave)
+    const int q = q0 + qsub * 32 + j;
     if (q < a.CQ) {
 #pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            float* wsk = a.ws + (size_t)(kh * KW + k) * a.CA * a.CQ;
+        for (int k = 0; k < TPW; ++k) {
+            if (t_lo + k >= t_hi) continue;
+            float* wsk = a.ws + (size_t)(t_lo + k) * a.CA * a.CQ;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ai = a0 + wa * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -144,8 +164,7 @@ extern "C" size_t masic_conv2d_wgrad_workspace_bytes(const masic_conv_desc_t* d)
 extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace,
                                   const masic_conv_desc_t* d, void* stream) {
     MASIC_REQUIRE(x && dy && dw && workspace && d, MASIC_ERR_ARG, "conv2d_wgrad: null pointer");
-    MASIC_REQUIRE(d->KW == 1 || d->KW == 3 || d->KW == 5, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: kernel width %d", d->KW);
-    MASIC_REQUIRE(d->KH >= 1 && d->KH <= 5, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: kernel height %d", d->KH);
+    MASIC_REQUIRE(d->KH * d->KW == 1 || d->KH * d->KW <= 28, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: kernel %dx%d", d->KH, d->KW);
     MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: stride %d", d->stride);
     MASIC_REQUIRE(d->in_coff >= 0 && d->in_coff + d->Cin <= d->in_ctot, MASIC_ERR_SHAPE, "conv2d_wgrad: input view out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -159,28 +178,34 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         a.P = x; a.p_ctot = d->in_ctot; a.p_coff = d->in_coff; a.CA = d->Cin; a.Hc = d->Hi; a.Wc = d->Wi;
         a.Q = dy; a.q_ctot = d->Cout; a.q_coff = 0; a.CQ = d->Cout; a.Hf = d->Ho; a.Wf = d->Wo;
     }
+    a.KW = d->KW;
     a.tiles_w = ceil_div(a.Wc, 32); a.tiles_h = ceil_div(a.Hc, 2);
     a.ntiles = a.tiles_w * a.tiles_h * a.B;
+    const int Tt = d->KH * d->KW;
+    const int QT = Tt == 1 ? 4 : 1;                     // 1x1: four q sub-tiles per block; else four tap groups
     const int a_tiles = ceil_div(a.CA, 64);
-    a.q_tiles = ceil_div(a.CQ, 64);
-    const int base = a_tiles * a.q_tiles * a.KH;
-    int nsplit = ceil_div(1024, base);
+    a.q_tiles = ceil_div(a.CQ, 32 * QT);
+    const int base = a_tiles * a.q_tiles;
+    int nsplit = ceil_div(512, base);
     if (nsplit > a.ntiles) nsplit = a.ntiles;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = nsplit;
     a.PWq = 31 * a.s + d->KW;
-    a.QG = ceil_div(2 * a.PWq, 64);
-    a.QS = a.QG * 64 + 1;
-    const size_t lds = (size_t)(64 * PS + 64 * a.QS) * sizeof(float);
+    a.QROWS = a.s + d->KH;
+    a.QPIX = a.QROWS * a.PWq;
+    a.QG = ceil_div(a.QPIX, 64);
+    a.QS = a.QPIX | 1;
+    const size_t lds = (size_t)2 * (64 * PS + 32 * QT * a.QS) * sizeof(float);
+    MASIC_REQUIRE(lds <= 160 * 1024, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: tile does not fit LDS");
     const size_t wbytes = masic_conv2d_wgrad_workspace_bytes(d);
     if (hipMemsetAsync(workspace, 0, wbytes, st) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
-    dim3 grid(a_tiles * a.q_tiles, a.KH, nsplit);
-    if (d->KW == 5) hipLaunchKernelGGL(conv_wgrad_f32<5>, grid, dim3(256), lds, st, a);
-    else if (d->KW == 3) hipLaunchKernelGGL(conv_wgrad_f32<3>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, dim3(256), lds, st, a);
+    dim3 grid(a_tiles * a.q_tiles, 1, nsplit);
+    if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1>), grid, dim3(512), lds, st, a);
+    else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_f32<1, 7>), grid, dim3(512), lds, st, a);
     const int T = d->KH * d->KW, AQ = a.CA * a.CQ;
     const size_t total = (size_t)T * AQ;
     int tb = (int)((total + 255) / 256);
