@@ -144,6 +144,102 @@ __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
     }
 }
 
+// ---- packed variant for layers whose fine-side tensor has few channels (CQ <= 8: the 3-channel image ends of the
+// transforms, the 6<->3 pre/after convs).  A 32-wide q tile would be >= 75 % padding there; instead the 32 lanes of the
+// B operand enumerate (tap, q) pairs -- column n = t*CQ + q, T*CQ columns in all -- so a 5x5 kernel over 3 channels is
+// 75 columns = 3 MFMA column tiles instead of 25.  Wave = (which 32 a-channels, column-tile group); everything else
+// (pixel tiles, DMA double buffering, odd channel pitch, atomic reduction into [tap][a][q]) as above.
+template <int TPW>
+__global__ __launch_bounds__(512) void conv_wgrad_packed_f32(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int buf_sz = 64 * PS + a.CQ * a.QS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, u = wave >> 1;
+    const int j = lane & 31, h = lane >> 5;
+    const int a0 = blockIdx.x * 64;
+    const int T = a.KH * a.KW, NCOL = T * a.CQ;
+
+    f32x16 acc[TPW];
+    int coloff[TPW];       // LDS offset (within the Q tile) of this lane's column: q*QS + kh*PWq + kw; -1 beyond NCOL
+    int colidx[TPW];       // workspace index t*CA*CQ + q
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.0f;
+        const int n = (u + 4 * k) * 32 + j;
+        const int t = n / a.CQ, q = n - t * a.CQ;
+        coloff[k] = n < NCOL ? q * a.QS + (t / a.KW) * a.PWq + (t % a.KW) : 0;
+        colidx[k] = n < NCOL ? t * a.CA * a.CQ + q : -1;
+    }
+
+    const size_t cplane = (size_t)a.Hc * a.Wc, fplane = (size_t)a.Hf * a.Wf;
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int prr = lane >> 5, pcc = lane & 31;
+
+    auto issue = [&](int tile, float* buf) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int r0 = (trem / a.tiles_w) * 2, c0 = (trem % a.tiles_w) * 32;
+        float* Pt = buf;
+        float* Qt = buf + 64 * PS;
+        {
+            const int r = r0 + prr, c = c0 + pcc;
+            const bool pok = r < a.Hc && c < a.Wc;
+            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * cplane + (size_t)(pok ? r : 0) * a.Wc + (pok ? c : 0);
+            for (int ch = wave; ch < 64; ch += 8) {
+                const bool ok = pok && (a0 + ch) < a.CA;
+                dma4(ok ? pb + (size_t)(a0 + ch) * cplane : g_zero_wg, Pt + ch * PS);
+            }
+        }
+        {
+            const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * fplane;
+            // (channel, group) pairs dealt to the 8 waves
+            for (int cg = wave; cg < a.CQ * a.QG; cg += 8) {
+                const int ch = cg / a.QG, g = cg - ch * a.QG;
+                const int e = g * 64 + lane;
+                const int rr = e / a.PWq, pc = e - rr * a.PWq;
+                const int fh = r0 * a.s - a.pad + rr, fw = c0 * a.s - a.pad + pc;
+                const bool inpatch = e < a.QPIX;
+                const bool qok = inpatch && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+                const float* src = qb + (size_t)ch * fplane + (size_t)(qok ? fh : 0) * a.Wf + (qok ? fw : 0);
+                if (inpatch) dma4(qok ? src : g_zero_wg, Qt + ch * a.QS + g * 64);
+            }
+        }
+    };
+
+    int it = 0;
+    if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
+        float* cur = lds + (it & 1) * buf_sz;
+        __syncthreads();
+        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        const float* pa = cur + (wa * 32 + j) * PS + h;
+        const float* qa = cur + 64 * PS + h * a.s;
+        for (int kk = 0; kk < 32; ++kk) {
+            const int px = 2 * kk;
+            const int rr = px >> 5, cc = px & 31;
+            const float av = pa[px];
+            const float* qrow = qa + (rr * a.s) * a.PWq + cc * a.s;
+            float bv[TPW];
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) bv[k] = colidx[k] >= 0 ? qrow[coloff[k]] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if ((u + 4 * k) * 32 < NCOL) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        if (colidx[k] < 0) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ai = a0 + wa * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (ai < a.CA) atomicAdd(a.ws + (size_t)colidx[k] + (size_t)ai * a.CQ, acc[k][e]);
+        }
+    }
+}
+
 // ws [T][CA][CQ] -> dw [CA][CQ][T]
 __global__ __launch_bounds__(256) void wgrad_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int AQ) {
     const size_t total = (size_t)T * AQ;
@@ -182,30 +278,41 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
     a.tiles_w = ceil_div(a.Wc, 32); a.tiles_h = ceil_div(a.Hc, 2);
     a.ntiles = a.tiles_w * a.tiles_h * a.B;
     const int Tt = d->KH * d->KW;
-    const int QT = Tt == 1 ? 4 : 1;                     // 1x1: four q sub-tiles per block; else four tap groups
-    const int a_tiles = ceil_div(a.CA, 64);
-    a.q_tiles = ceil_div(a.CQ, 32 * QT);
-    const int base = a_tiles * a.q_tiles;
-    int nsplit = ceil_div(512, base);
-    if (nsplit > a.ntiles) nsplit = a.ntiles;
-    if (nsplit < 1) nsplit = 1;
-    a.nsplit = nsplit;
     a.PWq = 31 * a.s + d->KW;
     a.QROWS = a.s + d->KH;
     a.QPIX = a.QROWS * a.PWq;
     a.QG = ceil_div(a.QPIX, 64);
     a.QS = a.QPIX | 1;
-    const size_t lds = (size_t)2 * (64 * PS + 32 * QT * a.QS) * sizeof(float);
-    MASIC_REQUIRE(lds <= 160 * 1024, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: tile does not fit LDS");
     const size_t wbytes = masic_conv2d_wgrad_workspace_bytes(d);
     if (hipMemsetAsync(workspace, 0, wbytes, st) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
-    dim3 grid(a_tiles * a.q_tiles, 1, nsplit);
-    if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1>), grid, dim3(512), lds, st, a);
-    else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_f32<1, 7>), grid, dim3(512), lds, st, a);
+    const int a_tiles = ceil_div(a.CA, 64);
+    const int ncol_tiles = ceil_div(Tt * a.CQ, 32);
+    if (a.CQ <= 8 && Tt > 1 && ncol_tiles <= 8) {          // few fine-side channels: (tap, q) pairs packed into the 32 MFMA columns
+        a.q_tiles = 1;
+        int nsplit = ceil_div(512, a_tiles);
+        if (nsplit > a.ntiles) nsplit = a.ntiles;
+        a.nsplit = nsplit < 1 ? 1 : nsplit;
+        const size_t lds = (size_t)2 * (64 * PS + a.CQ * a.QS) * sizeof(float);
+        dim3 grid(a_tiles, 1, a.nsplit);
+        if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_packed_f32<2>), grid, dim3(512), lds, st, a);
+    } else {
+        const int QT = Tt == 1 ? 4 : 1;                     // 1x1: four q sub-tiles per block; else four tap groups
+        a.q_tiles = ceil_div(a.CQ, 32 * QT);
+        const int base = a_tiles * a.q_tiles;
+        int nsplit = ceil_div(512, base);
+        if (nsplit > a.ntiles) nsplit = a.ntiles;
+        a.nsplit = nsplit < 1 ? 1 : nsplit;
+        const size_t lds = (size_t)2 * (64 * PS + 32 * QT * a.QS) * sizeof(float);
+        MASIC_REQUIRE(lds <= 160 * 1024, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: tile does not fit LDS");
+        dim3 grid(a_tiles * a.q_tiles, 1, a.nsplit);
+        if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1>), grid, dim3(512), lds, st, a);
+        else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_f32<1, 7>), grid, dim3(512), lds, st, a);
+    }
     const int T = d->KH * d->KW, AQ = a.CA * a.CQ;
     const size_t total = (size_t)T * AQ;
     int tb = (int)((total + 255) / 256);
