@@ -149,6 +149,9 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     if (d.Cout <= 32) { c.wvm = 1; c.wm = 1; c.wn = 2; }                    // 32 x 256 tile (CQE 32-channel layers)
     else if (d.Cout > 64 && d.Cout <= 96) { c.wvm = 1; c.wm = 3; c.wn = 2; } // 96 x 256 tile (CQE 96-channel layers)
     else if (m128 && nblocks(2, 4) >= 512) { c.wm = 2; c.wn = 4; }
+    // bf16 1x1 layers are bound by operand staging, not MFMA: the widest tile amortises the weight stream and the
+    // barriers best, and its small LDS footprint keeps every workgroup of a ~1-wave grid resident at once
+    else if (m128 && d.prec == MASIC_PREC_BF16 && d.KH == 1 && d.KW == 1 && nblocks(2, 4) >= 192) { c.wm = 2; c.wn = 4; }
     else if (m128 && nblocks(2, 2) >= 512) { c.wm = 2; c.wn = 2; }
     else { c.wm = 1; c.wn = nblocks(1, 4) >= 768 ? 4 : (nblocks(1, 2) >= 512 ? 2 : 1); }
     const int wvn = 4 / c.wvm;
