@@ -124,7 +124,21 @@ class _GmmHeads(nn.Module):
         t = seq[2].run(t, act=acts[1])
         return seq[4].run(t, act=acts[2])
 
+    def _branch_f16k(self, seq, xf, B, H, W, acts):
+        """The same three layers as bf16 GEMMs; activations between them stay in the F16K layout on the device."""
+        t = _hip.gemm1x1_bf16(xf, seq[0].packed_gemm_weight(), seq[0].bias.detach(), B, seq[0].in_channels, seq[0].out_channels, H, W, acts[0])
+        t = _hip.gemm1x1_bf16(t, seq[2].packed_gemm_weight(), seq[2].bias.detach(), B, seq[2].in_channels, seq[2].out_channels, H, W, acts[1])
+        return _hip.gemm1x1_bf16(t, seq[4].packed_gemm_weight(), seq[4].bias.detach(), B, seq[4].in_channels, seq[4].out_channels, H, W,
+                                 acts[2], want_nchw=True)
+
     def heads(self, x):
+        from masic_amd import nn as _mnn
+        if _mnn.get_precision() == "bf16" and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
+            B, _, H, W = x.shape
+            xf = _hip.nchw_to_f16k(x)        # converted once, read by the three stacks
+            return (self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU)),
+                    self._branch_f16k(self.gmm_means, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)),
+                    self._branch_f16k(self.gmm_weights, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)))
         sigma = self._branch(self.gmm_sigma, x, (_RELU, _RELU, _RELU))
         means = self._branch(self.gmm_means, x, (_LEAKY, _LEAKY, _NONE))
         logits = self._branch(self.gmm_weights, x, (_LEAKY, _LEAKY, _NONE))

@@ -88,6 +88,19 @@ int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias,
                         const float* res1, const float* res2, float* y, const masic_conv_desc_t* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The 1x1 stacks of the GMM parameter heads (MASIC.py:330-468) as bf16 GEMMs whose intermediate activations stay in
+ * the matrix-core-friendly layout F16K = [B][C/16][H*W][16] bf16 (see masic_amd/csrc/gemm_bf16.hip):
+ *   masic_nchw_to_f16k     float32 NCHW channel view -> F16K (zero padded to a multiple of 16 channels)
+ *   masic_gemm1x1_*        y = act(W x + b) with x in F16K; output either F16K (next layer) or float32 NCHW view.
+ * `transposed` = 1 packs a ConvTranspose2d(k=1) weight [Cin,Cout] (the first two layers of the y1 stacks, :339-342). */
+size_t masic_f16k_bytes(int B, int C, int HW);
+int masic_nchw_to_f16k(const float* x, void* y, int B, int C, int HW, int ctot, int coff, void* stream);
+size_t masic_gemm1x1_packed_bytes(int Cin, int Cout);
+int masic_gemm1x1_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream);
+int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
+                           int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of
  * compressai/ops/parametrizers.py:47-64 applied to the *stored* beta[C], gamma[C,C] inside the
  * kernel: y = x * rsqrt(beta^ + gamma^ . x^2)  (inverse: * sqrt).  beta_min as gdn.py:57.

@@ -37,6 +37,11 @@ SIGNATURES = {
     "masic_conv_pack_weight": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_f16k_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "masic_nchw_to_f16k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_gemm1x1_packed_bytes": (c_size_t, [c_int, c_int]),
+    "masic_gemm1x1_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "masic_gemm1x1_bf16_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_gdn_fwd_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int, _P]),
     "masic_quantize_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),

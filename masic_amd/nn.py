@@ -66,6 +66,16 @@ class _PackedWeightMixin:
             self.__dict__["_packed_cache"] = cache
         return cache[1]
 
+    def packed_gemm_weight(self):
+        """[ci/16][co][16] bf16 pack of a 1x1 layer for the register-streamed GEMM (masic_amd/csrc/gemm_bf16.hip)."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        cache = self.__dict__.get("_packed_gemm_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.pack_gemm1x1_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))
+            self.__dict__["_packed_gemm_cache"] = cache
+        return cache[1]
+
     def invalidate_packed_weight(self):
         self.__dict__.pop("_packed_cache", None)
 

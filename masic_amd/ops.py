@@ -461,3 +461,36 @@ def warp_perspective_bwd(g_dst, minv_norm, src_shape):
     g_src = torch.zeros(src_shape, dtype=torch.float32, device=g_dst.device)
     check(lib.masic_warp_perspective_bwd(_p(g_dst), _p(minv_norm), _p(g_src), B, C, Hs, Ws, Hd, Wd, _stream()), "warp_perspective_bwd")
     return g_src
+
+
+# --------------------------------------------------------------------------------------------- bf16 1x1 GEMM stacks
+def nchw_to_f16k(x, C=None, coff=0):
+    """float32 NCHW (channel view) -> F16K bf16 [B][ceil16(C)/16][HW][16] (include/masic_hip.h)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    C = ctot if C is None else C
+    y = torch.empty(lib.masic_f16k_bytes(B, C, H * W) // 2, dtype=torch.int16, device=x.device)
+    check(lib.masic_nchw_to_f16k(_p(x), _p(y), B, C, H * W, ctot, coff, _stream()), "nchw_to_f16k")
+    return y
+
+
+def pack_gemm1x1_weight(weight, Cin, Cout, transposed):
+    _dev(weight, "weight")
+    wp = torch.empty(lib.masic_gemm1x1_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_gemm1x1_pack_weight(_p(weight), _p(wp), Cin, Cout, int(transposed), _stream()), "gemm1x1_pack_weight")
+    return wp
+
+
+def gemm1x1_bf16(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_coff=0, want_nchw=False):
+    """y = act(W x + b) on F16K activations; returns F16K (int16 buffer) or, with want_nchw / out_nchw, float32 NCHW."""
+    HW = H * W
+    y16 = y32 = None
+    out_ctot = 0
+    if want_nchw or out_nchw is not None:
+        y32 = out_nchw if out_nchw is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_f16k.device)
+        out_ctot = y32.shape[1]
+    else:
+        y16 = torch.empty(lib.masic_f16k_bytes(B, Cout, HW) // 2, dtype=torch.int16, device=x_f16k.device)
+    check(lib.masic_gemm1x1_bf16_fwd(_p(x_f16k), _p(wp), _p(bias), _p(y16), _p(y32), B, Cin, Cout, HW, out_ctot, out_coff, int(act), _stream()),
+          "gemm1x1_bf16_fwd")
+    return y32 if y32 is not None else y16

@@ -278,3 +278,24 @@ def test_gdn_bf16x3_split_product(H, W, inverse):
     y = ops.gdn(x.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse, prec=PREC_BF16)
     e = assert_close(y, ref, "gdn bf16x3", rtol=5e-5)
     print(f"gdn bf16x3 relative error {e:.2e}")
+
+
+@pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W,tr", [(2, 768, 1152, 960, 16, 24, True), (1, 960, 1152, 768, 8, 12, False), (2, 100, 72, 50, 5, 7, False)])
+def test_gemm1x1_bf16_stack_f16k(B, Cin, Cmid, Cout, H, W, tr):
+    """Two chained 1x1 layers through the F16K activation layout against the float32 oracle on bf16-rounded operands."""
+    ops = _ops()
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    w0 = _rand(*((Cin, Cmid) if tr else (Cmid, Cin)), seed=2, scale=(2.0 / Cin) ** 0.5)
+    b0 = _rand(Cmid, seed=3, scale=0.1)
+    w1 = _rand(Cout, Cmid, seed=4, scale=(2.0 / Cmid) ** 0.5)
+    b1 = _rand(Cout, seed=5, scale=0.1)
+    q = lambda t: t.bfloat16().float()
+    w0c = (q(w0).t() if tr else q(w0)).reshape(Cmid, Cin, 1, 1)
+    mid = F.leaky_relu(F.conv2d(q(x), w0c, b0))
+    ref = F.relu(F.conv2d(q(mid), q(w1).reshape(Cout, Cmid, 1, 1), b1))
+    xf = ops.nchw_to_f16k(x.to(DEV))
+    p0 = ops.pack_gemm1x1_weight(w0.to(DEV), Cin, Cmid, tr)
+    p1 = ops.pack_gemm1x1_weight(w1.to(DEV), Cmid, Cout, False)
+    t = ops.gemm1x1_bf16(xf, p0, b0.to(DEV), B, Cin, Cmid, H, W, ops.ACT_LEAKY)
+    y = ops.gemm1x1_bf16(t, p1, b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, want_nchw=True)
+    assert_close(y, ref, "gemm1x1 bf16 stack", rtol=1e-3)     # an intermediate that re-rounds to the neighbouring bf16 value moves the output by ~1e-4
