@@ -123,6 +123,11 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         c.direct = 2; c.Cin_pad = round_up(d.Cin, 8); c.Cout_pad = 4;      // packed [ci][5][5][4]
         return c;
     }
+    if (d.Cout <= 4 && d.Cin <= 8 && d.stride == 1 && d.KH == 5 && d.KW == 5 && d.pad == 2 && !d.masked &&
+        d.in_op == MASIC_INOP_NONE && d.act != MASIC_ACT_SOFTMAX_C) {
+        c.direct = 3; c.Cin_pad = d.Cin; c.Cout_pad = 4;                   // packed [ci][5][5][4]
+        return c;
+    }
     if (d.Cout <= 8) {
         c.direct = 1; c.Cin_pad = d.Cin; c.Cout_pad = 8;
         return c;
@@ -791,13 +796,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
                 // one memory latency per group instead of one per pixel task
                 float v[NT][8];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
+                for (int c = 0; c < 8; ++c) {
+                    const int cg = cc + gch + c;
+                    if (cg < a.Cin) {                     // wave-uniform: channels beyond Cin (3-channel image layers) cost no loads
+                        const float* xc = xb + (size_t)cg * plane;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int cg = cc + gch + c;
-                        const bool ok = goff[i] >= 0 && cg < a.Cin;
-                        const float t = xb[(size_t)(cg < a.Cin ? cg : a.Cin - 1) * plane + (goff[i] >= 0 ? goff[i] : 0)];
-                        v[i][c] = ok ? t : 0.0f;
+                        for (int i = 0; i < NT; ++i) {
+                            const float t = xc[goff[i] >= 0 ? goff[i] : 0];
+                            v[i][c] = goff[i] >= 0 ? t : 0.0f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) v[i][c] = 0.0f;
                     }
                 }
 #pragma unroll
@@ -884,6 +894,72 @@ __global__ void pack_weight_bf16_kernel(const PackArgs a, unsigned short* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ 5x5 stride-1, few channels
+// Conv2d / ConvTranspose2d(k=5, s=1, p=2) with Cin <= 8 and Cout <= 4: encoder2.pre_conv (6->3) and
+// decoder2.after_conv (6->3, transposed; MASIC.py:559,600).  Full-resolution, HBM-bound (reads Cin, writes Cout
+// planes): a 16x16 output tile per workgroup, the (16+4)^2 input tile of every channel staged by DMA, weights packed
+// [ci][kh][kw][4] (flipped for the transposed layer, so the kernel is always a correlation) as scalar operands.
+struct Conv5s1Args {
+    const float* x; const float* bias; const float* gate; const float* res1; float* y;
+    int Cin, H, W, in_ctot, in_coff, Cout, out_ctot, out_coff, act, tiles_w, gate_ctot, gate_c;
+};
+
+__global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const float* __restrict__ wpk) {
+    constexpr int T = 16, LW = T + 4, PLANE = LW * LW, PSZ = 448;       // 400 floats per channel -> 7 DMA groups
+    __shared__ __attribute__((aligned(16))) float lds[8 * PSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = tid & 15, ty = tid >> 4;
+    const int tile_x = blockIdx.x % a.tiles_w, tile_y = blockIdx.x / a.tiles_w;
+    const int b = blockIdx.y;
+    const int oy = tile_y * T + ty, ox = tile_x * T + tx;
+    const size_t plane = (size_t)a.H * a.W;
+    const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    for (int cg = wave; cg < a.Cin * 7; cg += 4) {
+        const int ci = cg / 7, g = cg - ci * 7;
+        const int e = g * 64 + lane;
+        const int pr = e / LW, pc = e - pr * LW;
+        const int ih = tile_y * T - 2 + pr, iw = tile_x * T - 2 + pc;
+        const bool ok = e < PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        if (e < PLANE) dma4(ok ? xb + (size_t)ci * plane + (size_t)ih * a.W + iw : g_zero_word, lds + ci * PSZ + g * 64);
+    }
+    __syncthreads();
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* base = lds + ty * LW + tx;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float* w = wpk + ci * 100;
+        const float* pl = base + ci * PSZ;
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const float xv = pl[kh * LW + kw];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(xv, w[(kh * 5 + kw) * 4 + o], acc[o]);
+            }
+    }
+    if (oy >= a.H || ox >= a.W) return;
+    const size_t opix = (size_t)oy * a.W + ox;
+    const float gv = a.gate ? a.gate[((size_t)b * a.gate_ctot + a.gate_c) * plane + opix] : 1.0f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o >= a.Cout) break;
+        float v = apply_act(acc[o] + (a.bias ? a.bias[o] : 0.0f), a.act) * gv;
+        if (a.res1) v += a.res1[((size_t)b * a.Cout + o) * plane + opix];
+        a.y[((size_t)b * a.out_ctot + a.out_coff + o) * plane + opix] = v;
+    }
+}
+
+// [ci][kh][kw][4]; the transposed layer's taps are flipped so that the kernel correlates
+__global__ void pack_conv5s1_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int transposed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * 100) return;
+    const int ci = i / 100, rem = i - ci * 100, tap = rem >> 2, o = rem & 3;
+    float v = 0.0f;
+    if (o < Cout) v = transposed ? w[((size_t)ci * Cout + o) * 25 + (24 - tap)] : w[((size_t)o * Cin + ci) * 25 + tap];
+    wp[i] = v;
+}
+
 int check_desc(const masic_conv_desc_t* d) {
     MASIC_REQUIRE(d != nullptr, MASIC_ERR_ARG, "conv: null descriptor");
     MASIC_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Hi > 0 && d->Wi > 0, MASIC_ERR_SHAPE,
@@ -916,7 +992,7 @@ extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
     const ConvCfg c = choose_cfg(*d, g, np);
     int taps = 0;
     for (int p = 0; p < np; ++p) taps += g[p].ntaps;
-    if (c.direct == 2) return (size_t)c.Cin_pad * 100 * sizeof(float);
+    if (c.direct == 2 || c.direct == 3) return (size_t)c.Cin_pad * 100 * sizeof(float);
     if (c.bf16) return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(unsigned short);
     return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
 }
@@ -929,6 +1005,7 @@ extern "C" int masic_conv_variant(const masic_conv_desc_t* d, int* launches) {
     const ConvCfg c = choose_cfg(*d, g, np);
     if (launches) *launches = 1;   // all phases ride in one launch
     if (c.direct == 2) return 6;
+    if (c.direct == 3) return 11;
     if (c.direct) return d->Cout <= 3 ? 0 : 1;
     if (c.bf16) return 10;
     if (c.wvm == 1) return c.wm == 1 ? 8 : 9;
@@ -944,6 +1021,7 @@ extern "C" int masic_conv_kernel_name(const masic_conv_desc_t* d, char* buf, siz
     const int np = build_geoms(*d, g);
     const ConvCfg c = choose_cfg(*d, g, np);
     if (c.direct == 2) snprintf(buf, n, "deconv5s2_small_cout");
+    else if (c.direct == 3) snprintf(buf, n, "conv5s1_small");
     else if (c.direct) snprintf(buf, n, "conv_direct_f32<%d>", d->Cout <= 3 ? 3 : 8);
     else if (c.bf16) snprintf(buf, n, "conv_igemm_bf16<%d, %d, %d, %d, %s>", c.wvm, c.wm, c.wn, d->in_op, c.pf ? "true" : "false");
     else snprintf(buf, n, "conv_igemm_f32<%d, %d, %d, %d, %s>", c.wvm, c.wm, c.wn, d->in_op, c.vec4 ? "true" : "false");
@@ -960,6 +1038,11 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
     if (c.direct == 2) {
         hipLaunchKernelGGL(pack_deconv4_kernel, dim3(ceil_div(c.Cin_pad * 100, 256)), dim3(256), 0, (hipStream_t)stream,
                            w, (float*)w_packed, d->Cin, c.Cin_pad, d->Cout);
+        return masic_launch_status("conv_pack_weight");
+    }
+    if (c.direct == 3) {
+        hipLaunchKernelGGL(pack_conv5s1_kernel, dim3(ceil_div(d->Cin * 100, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, (float*)w_packed, d->Cin, d->Cout, d->transposed);
         return masic_launch_status("conv_pack_weight");
     }
     for (int p = 0; p < np; ++p) {
@@ -1004,6 +1087,14 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
         Deconv4Args a{x, (const float*)w_packed, bias, y, d->Cin, c.Cin_pad, d->Hi, d->Wi, d->in_ctot, d->in_coff,
                       d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff, d->act, ceil_div(d->Wi, 16)};
         hipLaunchKernelGGL(deconv5s2_small_cout, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
+                           (const float*)w_packed);
+        return masic_launch_status("conv2d_fwd");
+    }
+    if (c.direct == 3) {
+        MASIC_REQUIRE(res2 == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: two residuals on the small 5x5 path");
+        Conv5s1Args a{x, bias, gate, res1, y, d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff, d->Cout, d->out_ctot, d->out_coff,
+                      d->act, ceil_div(d->Wi, 16), d->gate_ctot, d->gate_c};
+        hipLaunchKernelGGL(conv5s1_small, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
                            (const float*)w_packed);
         return masic_launch_status("conv2d_fwd");
     }
