@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("MASIC_PRECISION", "bf16"),
                     help="operand precision of the forward MFMA contractions (float32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-compare", action="store_true", help="skip the float32 parity-path timing/accuracy extras (profiling runs)")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
                          "2x Adam) after the headline region; reported under extras.train_step, 0 to skip")
@@ -103,9 +104,18 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup - 1, 0)):
             net(x1, x2, hm)
-        timer = ops.KernelTimer()
+        # last warm-up step: HIP events around every conv launch to find the dominant kernel symbol and the per-kernel
+        # split; the timed region then brackets launches of that symbol only (events between all ~70 conv launches
+        # of a step cost ~8% of it)
+        survey = ops.KernelTimer()
+        ops.set_kernel_timer(survey)
+        net(x1, x2, hm)
+        ops.set_kernel_timer(None)
+        survey_agg = survey.summary()
+        dom = max(survey_agg, key=lambda k: survey_agg[k]["ms"])
+        timer = ops.KernelTimer(only=dom)
         ops.set_kernel_timer(timer)
         barrier()
         t0 = time.perf_counter()
@@ -121,7 +131,6 @@ def main():
 
     # dominant conv kernel symbol by device time (HIP events on the launch stream, inside the timed region)
     agg = timer.summary()
-    dom = max(agg, key=lambda k: agg[k]["ms"])
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
@@ -131,7 +140,7 @@ def main():
                 "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,
                 "flops_per_launch": a["flops"] / a["launches"],
                 "share_of_step_time": a["ms"] / (elapsed * 1e3),
-                "all_conv_kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in agg.items()}}
+                "all_conv_kernels_ms_per_step_warmup_survey": {k: v["ms"] for k, v in survey_agg.items()}}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
@@ -142,7 +151,7 @@ def main():
     # ---- the float32 parity path on the same inputs: its rate, and what bf16 operands cost in codec terms
     accuracy = None
     f32_info = None
-    if args.precision == "bf16":
+    if args.precision == "bf16" and not args.no_f32_compare:
         from masic_amd.loss import rate_distortion
         with torch.no_grad():
             sym_b = net.symbol_streams(x1, x2, hm)

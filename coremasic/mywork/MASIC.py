@@ -395,7 +395,10 @@ class HSIC(CompressionModel):
             "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
         }
 
-    def forward(self, x1, x2, h_matrix):
+    def forward(self, x1, x2, h_matrix, warp_matrices=None):
+        """`warp_matrices` (optional): the (forward, inverse) normalised sampling matrices of masic_amd.homography for
+        this h_matrix, precomputed by the caller -- lets the whole forward be captured into a HIP graph
+        (masic_amd/graph.py), since their host-side float32 evaluation is the only synchronising step."""
         if self._needs_graph():
             return self._forward_graph(x1, x2, h_matrix)
         M, K = self.M, self.K
@@ -405,7 +408,7 @@ class HSIC(CompressionModel):
         train = self.training
         mode = "noise" if train else "dequantize"
 
-        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        m_fwd, m_back = warp_matrices if warp_matrices is not None else _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
 
         # ---- left view
         y1 = self.encoder1(x1)[0]

@@ -687,7 +687,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 template <int WVM, int WM, int WN, int INOP, bool PF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int BM = 32 * WM * WVM;
-    constexpr int DEPTH = 4;                                               // A-fragment prefetch distance (k-steps)
+    // A-fragment prefetch distance (k-steps): an L2 round trip under load is ~1-2 us, a k-step of a 1-MFMA wave tile
+    // 13 ns -- the fewer MFMAs per k-step, the deeper the ring (same 32-64 VGPRs either way)
+    constexpr int DEPTH = WM * WN >= 8 ? 4 : (WM * WN >= 2 ? 8 : 16);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* patch = reinterpret_cast<unsigned short*>(lds);          // [NP][KCP] bf16
     const int KCP = a.KC + 8;

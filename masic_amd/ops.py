@@ -64,8 +64,9 @@ def pack_conv_weight(weight, desc):
 class KernelTimer:
     """HIP-event timing of conv launches on torch's current stream (the stream the kernels are launched on),
     keyed by kernel symbol; used by bench.py for the live roofline figure."""
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []
+        self.only = only      # bracket launches of this kernel symbol only (events between every launch cost ~8% of a step)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -105,6 +106,8 @@ def conv2d(x, packed, bias, desc, out=None, gate=None, res1=None, res2=None):
         buf = ctypes.create_string_buffer(96)
         lib.masic_conv_kernel_name(ctypes.byref(desc), buf, 96)
         variant = buf.value.decode()
+        if _timer.only is not None and variant != _timer.only:
+            return _conv2d(x, packed, bias, desc, out, gate, res1, res2)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
