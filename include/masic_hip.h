@@ -101,6 +101,21 @@ int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float
                            int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same convolutions (nn.Conv2d / nn.ConvTranspose2d / MaskedConv2d of MASIC.py:510-622, :170-187, :690-700) with
+ * the input -- and optionally the output -- in F16K: the bf16-operand forward keeps the 128/192-channel activations of
+ * the analysis / synthesis / hyper transforms in that layout between layers, so both MFMA operands reach LDS by
+ * 16-byte DMA (masic_amd/csrc/conv_f16k.hip).  The descriptor is the one of masic_conv2d_fwd; in_ctot/in_coff (and
+ * out_ctot/out_coff for an F16K output) count channels of the F16K buffers and must be multiples of 16; in_op must
+ * be NONE.  Exactly one of y_nchw (float32 channel view, optional gate as in masic_conv2d_fwd) / y_f16k is non-null.
+ *   masic_conv_f16k_supported    1 when the layer shape has a configuration (Cout >= 64, Cin >= 16, ...), else 0
+ *   masic_conv_f16k_packed_bytes / _pack_weight   [phase-tap][ci/16][co][16] bf16 weights for this path */
+int masic_conv_f16k_supported(const masic_conv_desc_t* d);
+size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d);
+int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
+int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                        float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of
  * compressai/ops/parametrizers.py:47-64 applied to the *stored* beta[C], gamma[C,C] inside the
  * kernel: y = x * rsqrt(beta^ + gamma^ . x^2)  (inverse: * sqrt).  beta_min as gdn.py:57.

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmasic_hip.so")
+LIB_PATH = os.environ.get("MASIC_HIP_LIB") or os.path.join(_HERE, "lib", "libmasic_hip.so")   # override: kernel experiments (tools/)
 
 c_int, c_float, c_double, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p
 
@@ -39,6 +39,10 @@ SIGNATURES = {
     "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_f16k_bytes": (c_size_t, [c_int, c_int, c_int]),
     "masic_nchw_to_f16k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_conv_f16k_supported": (c_int, [_P]),
+    "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),
+    "masic_conv_f16k_pack_weight": (c_int, [_P, _P, _P, _P]),
+    "masic_conv_f16k_fwd": (c_int, [_P] * 8),
     "masic_gemm1x1_packed_bytes": (c_size_t, [c_int, c_int]),
     "masic_gemm1x1_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "masic_gemm1x1_bf16_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),

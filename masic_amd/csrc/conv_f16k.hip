@@ -1,0 +1,442 @@
+// conv_f16k.hip -- bf16 implicit-GEMM convolutions on channel-blocked activations (gfx950 / MI355X).
+//
+// Same layers and the same phase geometry as conv.hip (reference: coremasic/mywork/MASIC.py:510-622 analysis /
+// synthesis transforms, :170-187 and :690-700 hyper transforms; factories compressai/models/utils.py:128-146), for the
+// bf16-operand forward.  conv.hip's bf16 kernel reads float32 NCHW and converts while staging, which makes every
+// workgroup re-convert its halo and leaves the matrix cores waiting on VGPR staging and on L2 latency of the weight
+// fragments.  Here both operands reach LDS by DMA (global_load_lds, 16 bytes per lane, no VGPR round trip):
+//
+//   activations  F16K  [B][C/16][H*W][16] bf16 (gemm_bf16.hip): a pixel's 16 channels are one 32-byte record, so the
+//                patch of a tile for one 16-channel block is rows of contiguous records and an MFMA B fragment
+//                (8 consecutive k of one pixel) is one ds_read_b128;
+//   weights      [phase-tap][ci/16][co][16] bf16 (pack_weight_bf16_kernel): one (tap, 16-channel) slab of a
+//                128-channel block is 4 KiB contiguous, an A fragment is one ds_read_b128.
+//
+// Workgroup = 8 waves (2 along co x 4 along pixels), tile 128 co x 256 pixels, wave tile 64 x 64 (2 x 2 MFMA
+// 32x32x16 accumulators).  K runs over chunks of KS 16-channel blocks; within a chunk over "steps" of T taps.
+// Every step each wave issues the same number of DMA wave-instructions -- WI for the weight slab of step g+D
+// (D+1-deep ring) and PS for a slice of the patch of chunk c+L (L+1 buffers) -- so that completion can be awaited
+// with a counted `s_waitcnt vmcnt((D-1)*(WI+PS))` (never 0 inside the loop) followed by one raw s_barrier per step:
+// DMA stays in flight across barriers.  Unused issue slots go to a dummy 1 KiB LDS region to keep the count fixed.
+//
+// LDS images are XOR-swizzled in 16-byte slots, slot' = slot ^ ((slot >> 4) & 3): the stride-2 pixel walk of a
+// strided conv (64 B between lanes), the stride-1 walk (32 B) and the weight rows (32 B) all become conflict-free for
+// ds_read_b128's four 16-lane groups.  The swizzle is applied on the DMA side by permuting which record a lane fetches.
+//
+// Epilogue: bias + activation, then either float32 NCHW (channel view of a concat buffer, optional gate) or F16K bf16
+// for the next layer.
+#include "common.h"
+#include "conv_geom.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
+
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct F16kArgs {
+    const unsigned short* x;      // F16K [B][in_c16tot][Hi*Wi][16]
+    const unsigned short* w;      // [phase-tap][Cin16p][Cout_pad][16]
+    const float* bias;
+    const float* gate;            // float32 [B][gate_ctot][Ho][Wo] or null (NCHW output only)
+    float* y32;                   // float32 NCHW view, or null
+    unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
+    int in_c16tot, in_c16off, Cin16, Cin16p;
+    int Hi, Wi, Cout, Cout_pad, Ho, Wo;
+    int out_ctot, out_coff;       // channel view of the output (NCHW: channels; F16K: channels, multiples of 16)
+    int gate_ctot, gate_c, act;
+    int TW, TWlog, SR, TH, tiles_w, ntiles;
+    int PH, PW, PWh, NPIXp;       // patch rows / row length (pixels), ceil(PW/2), records per k-half plane of the LDS image (x32)
+    int PB;                       // bytes per patch buffer
+    GeomParams q;
+    int nphase;
+};
+
+#ifndef F16K_ABLATE
+#define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers, 3 fragments read once
+#endif
+constexpr int MAXSPC = 7;   // steps per chunk (unrolled)
+
+// KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
+// patch wave per step during the first PSTEPS steps of a chunk, L patch look-ahead (chunks), OUT 0: float32 NCHW, 1: F16K
+template <int KS, int T, int D, int PSP, int PSTEPS, int L, int OUT>
+__global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
+    constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab)
+    constexpr int NWS = D + 1;                   // weight ring slots
+    constexpr int WST = T * KS * 4096;           // bytes per weight slab (T taps x KS 16-channel blocks x 128 co x 32 B)
+    constexpr int NPI = PSP * PSTEPS;            // patch DMA wave-instructions per patch wave per chunk (incl. dummies)
+    constexpr int NB = L + 1;                    // patch buffers
+    constexpr int PATCH0 = NWS * WST;            // LDS byte offset of the patch buffers
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int dummy_off = PATCH0 + NB * a.PB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int j = lane & 31, h = lane >> 5;
+    // DMA roles: waves 0-3 stream the weight slabs, waves 4-7 the activation patch.  vmcnt is per wave and retires in
+    // order, so the roles are what keeps a long-latency patch load (HBM) from gating the wait for the next weight slab (L2).
+    const bool wrole = wave < 4;
+    const int wq = wave & 3;
+
+    // block -> (tile, phase): the phases of a tile sit 8 block ids apart, i.e. on the same XCD and next to each other in
+    // time, so their interleaved output pixels meet in one L2
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int phase = rest % a.nphase;
+    const int tile = (rest / a.nphase) * 8 + xcd;
+    if (tile >= a.ntiles) return;
+    const ConvGeom g = make_geom(a.q, phase);
+    const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
+    const int m0 = blockIdx.y * 128;
+    const int b = blockIdx.z;
+    const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
+    const int ih0 = r0 * g.is + g.dh_min, iw0 = c0 * g.is + g.dw_min;
+
+    const int SPC = (g.ntaps + T - 1) / T;                    // steps per chunk
+    const int nchunks = a.Cin16p / KS;
+    const int gpk = a.NPIXp >> 5;                             // DMA wave-instructions per 16-channel plane of the patch (2*NPIXp/64)
+    const int ninstr = KS * gpk;
+    const int plane_bytes = a.Hi * a.Wi * 32;                 // bytes per 16-channel plane of the input
+    const int PWe = g.is == 2 ? a.PWh : a.PW;                 // row pitch (records) of the LDS patch image
+
+    // Buffer resources: out-of-range offsets read as zero, so padding pixels (voffset = huge) and chunks past the last one
+    // (soffset >= num_records) need no special case, and the per-chunk / per-slab offset rides in an SGPR.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + ((size_t)b * a.in_c16tot + a.in_c16off) * (size_t)(a.Hi * a.Wi * 16)), 0, a.Cin16 * plane_bytes, 0x00020000);
+    const int slab_bytes = a.Cout_pad * 32;                   // one (tap, 16-channel) slab over all output channels
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + ((size_t)g.tap_base * a.Cin16p * a.Cout_pad + m0) * 16), 0, g.ntaps * a.Cin16p * slab_bytes - m0 * 32, 0x00020000);
+
+    // ---- LDS images (16-byte records, the two k-halves of a 32-byte record in separate planes so that the 16 lanes of a
+    // ds_read_b128 group read 256 contiguous bytes):
+    //   weight slab (tap, ks): [hh][co 128]
+    //   patch plane (ks):      [hh][pixel'] with pixel' = row * PW + col for stride-1 walks and, for strided convs,
+    //                          columns de-interleaved by parity, pixel' = ((col & 1) * PH + row) * PWh + (col >> 1),
+    //                          so that the stride-2 walk of a tap reads consecutive records too.
+    int goff[NPI];                                            // patch waves: byte offset of this lane's record in a chunk
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+        const int I = k * 4 + wq;
+        const int ks = I / gpk, grp = I - ks * gpk;
+        const int q = grp * 64 + lane;
+        const int hh = q >= a.NPIXp ? 1 : 0, pp = q - hh * a.NPIXp;
+        int pr, pc;
+        bool ok = I < ninstr;
+        if (g.is == 2) {
+            const int half = a.PH * a.PWh;
+            const int par = pp >= half ? 1 : 0, rem = pp - par * half;
+            pr = rem / a.PWh;
+            pc = 2 * (rem - pr * a.PWh) + par;
+            ok = ok && pp < 2 * half && pc < a.PW;
+        } else {
+            pr = pp / a.PW;
+            pc = pp - pr * a.PW;
+            ok = ok && pp < a.PH * a.PW;
+        }
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        ok = ok && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        goff[k] = ok ? ks * plane_bytes + (ih * a.Wi + iw) * 32 + hh * 16 : 0x7ffffff0;
+    }
+    auto issue_patch = [&](int k, int goffk, int pcn, int pbslot) {
+        const int I = k * 4 + wq;
+        const int dst = I < ninstr ? PATCH0 + pbslot * a.PB + I * 1024 : dummy_off;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(lds + dst), 16, goffk,
+                                                 pcn * (KS * plane_bytes), 0, 0);
+    };
+
+    // ---- weight DMA (weight waves): wave w fetches quarter w of every (tap, ks) slab of the step
+    const int wvoff = ((wq & 1) * 64 + lane) * 32 + (wq >> 1) * 16;      // record (hh = wq >> 1, co) of a [co][16] slab
+    auto issue_w = [&](int pc_, int pt_, int slot) {
+        const int pcc = pc_ < nchunks ? pc_ : nchunks - 1;                // past the end: a duplicate nobody reads
+#pragma unroll
+        for (int k = 0; k < WI; ++k) {
+            const int tt = k / KS, ks = k % KS;
+            int tap = pt_ * T + tt;
+            tap = tap < g.ntaps ? tap : g.ntaps - 1;                       // ragged last step: likewise
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds + slot * WST + k * 4096 + wq * 1024),
+                                                     16, wvoff, (tap * a.Cin16p + pcc * KS + ks) * slab_bytes, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses: lane part in a VGPR, (slot / tap / ks) part uniform
+    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
+    const int al = (h * 128 + wm * 64 + j) * 16;
+    int bl[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int r = (wn * 2 + n) * a.SR + jr;
+        bl[n] = (h * a.NPIXp + (r * g.is) * PWe + jc) * 16;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    const int ta0 = g.dh0 - g.dh_min, tb0 = g.dw0 - g.dw_min;               // patch coordinates of tap (0, 0)
+    auto tap_slot = [&](int ta, int tb) {                                    // record offset of a tap inside the LDS image
+        return g.is == 2 ? ((tb & 1) * a.PH + ta) * a.PWh + (tb >> 1) : ta * a.PW + tb;
+    };
+
+    // ---- prologue: weight slabs of the first D steps, the first L patch chunks
+    int pc_ = 0, pt_ = 0;                                                    // weight producer cursor (chunk, step)
+    if (wrole) {
+        for (int d = 0; d < D; ++d) {
+            issue_w(pc_, pt_, d);
+            if (++pt_ == SPC) { pt_ = 0; ++pc_; }
+        }
+    } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int k = 0; k < NPI; ++k) issue_patch(k, goff[k], l, l);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cslot = 0, pslot = D % NWS;
+    int cb = 0, pb = L % NB;                                                // patch buffer of chunk c / of chunk c+L
+    for (int c = 0; c < nchunks; ++c) {
+        const int pbuf = PATCH0 + cb * a.PB;
+        int ta = ta0, tb = tb0, tbi = 0;
+#pragma unroll
+        for (int t = 0; t < MAXSPC; ++t) {
+            if (t < SPC) {
+                if (F16K_ABLATE == 1) {
+                } else if (wrole) {                    // weight slab of step g+D
+                    issue_w(pc_, pt_, pslot);
+                    if (++pt_ == SPC) { pt_ = 0; ++pc_; }
+                    pslot = pslot + 1 == NWS ? 0 : pslot + 1;
+                } else if (t < PSTEPS) {               // patch slices of chunk c+L
+#pragma unroll
+                    for (int u = 0; u < PSP; ++u) issue_patch(t * PSP + u, goff[(t < PSTEPS ? t : 0) * PSP + u], c + L, pb);
+                }
+                // T taps x KS k-steps of 2x2 MFMAs
+                const unsigned char* wst = lds + (al + cslot * WST);
+#pragma unroll
+                for (int tt = 0; tt < T; ++tt) {
+                    if (t * T + tt < g.ntaps) {
+                        const int toff = pbuf + tap_slot(ta, tb) * 16;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            bf16x8 af[2], bfr[2];
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+                                bfr[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl[n] + (toff + ks * gpk * 1024))));
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+                                af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                        }
+                        if (++tbi < g.ntw) tb += g.dsw;
+                        else { tbi = 0; tb = tb0; ta += g.dsh; }
+                    }
+                }
+                cslot = cslot + 1 == NWS ? 0 : cslot + 1;
+                // weight waves: the slab of the next step has landed, the D-1 slabs after it stay in flight.
+                // patch waves: at the end of a chunk the next chunk's patch has landed, the L-1 chunks after it stay in flight.
+                if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * WI) : "memory");
+                else if (t + 1 == SPC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * NPI) : "memory");
+                if (F16K_ABLATE != 2) __builtin_amdgcn_s_barrier();
+            }
+        }
+        cb = cb + 1 == NB ? 0 : cb + 1;
+        pb = pb + 1 == NB ? 0 : pb + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int r = r0 + (wn * 2 + n) * a.SR + jr, c = c0 + jc;
+        const bool pok = r < g.Hp && c < g.Wp;
+        const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+        const size_t opix = (size_t)oh * a.Wo + ow;
+        float gv = 1.0f;
+        if (OUT == 0 && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cow = m0 + wm * 64 + m * 32 + 4 * h;
+            float bv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = cow + (e & 3) + 8 * (e >> 2);
+                bv[e] = a.bias != nullptr ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
+            }
+            if (OUT == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cow + (e & 3) + 8 * (e >> 2);
+                    const float v = apply_act(acc[m][n][e] + bv[e], a.act) * gv;
+                    if (pok && co < a.Cout) a.y32[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = cow + 8 * q;                              // 4 consecutive channels co .. co+3
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = apply_act(acc[m][n][4 * q + i] + bv[4 * q + i], a.act);
+                    uint2 st;
+                    st.x = pack2bf(v[0], v[1]);
+                    st.y = pack2bf(v[2], v[3]);
+                    if (pok && co < a.Cout) {
+                        const int cg = a.out_coff + co;
+                        *reinterpret_cast<uint2*>(a.y16 + (((size_t)b * (a.out_ctot >> 4) + (cg >> 4)) * oplane + opix) * 16 + (cg & 15)) = st;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct F16kCfg {
+    int ok;
+    int KS;                       // template selection: 1 = strided conv <1,4,3,5,2,1>, 2 = stride-1 walk <2,2,3,3,2,2>
+    int TW, TWlog, SR, TH, PH, PW, PWh, NPIXp, PB;
+    int Cin16, Cin16p, Cout_pad;
+    size_t lds_bytes;
+};
+
+constexpr int F16K_D = 3;
+
+F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
+    F16kCfg c{};
+    if (d.Cout < 64 || d.Cin < 16 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    int span_h = 0, span_w = 0, min_taps = 1 << 30, max_taps = 0;
+    for (int p = 0; p < nphase; ++p) {
+        span_h = span_h > g[p].nth ? span_h : g[p].nth;
+        span_w = span_w > g[p].ntw ? span_w : g[p].ntw;
+        min_taps = min_taps < g[p].ntaps ? min_taps : g[p].ntaps;
+        max_taps = max_taps > g[p].ntaps ? max_taps : g[p].ntaps;
+    }
+    const int is = g[0].is, Wp = g[0].Wp;
+    int T, NPI, L;
+    if (is == 2) { c.KS = 1; T = 4; NPI = 12; L = 1; }        // strided conv: big patch, 16-channel chunks, 4 taps per step
+    else { c.KS = 2; T = 2; NPI = 6; L = 2; }                 // stride-1 walk (transposed phases, 3x3, masked): 32-channel chunks
+    if (ceil_div(max_taps, T) > MAXSPC || ceil_div(min_taps, T) < 2) return c;
+    c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
+    c.TWlog = 0;
+    while ((1 << c.TWlog) < c.TW) ++c.TWlog;
+    c.SR = 32 / c.TW;
+    c.TH = c.SR * 8;
+    c.PH = (c.TH - 1) * is + span_h;
+    c.PW = (c.TW - 1) * is + span_w;
+    c.PWh = (c.PW + 1) / 2;
+    c.NPIXp = round_up(is == 2 ? 2 * c.PH * c.PWh : c.PH * c.PW, 32);
+    const int ninstr = c.KS * (c.NPIXp / 32);
+    if (ceil_div(ninstr, 4) > NPI) return c;
+    c.PB = ninstr * 1024;
+    c.Cin16 = ceil_div(d.Cin, 16);
+    c.Cin16p = round_up(c.Cin16, c.KS);
+    if (c.Cin16p != c.Cin16 || d.Cin % 16 != 0) return c;   // whole chunks only: a chunk past the last reads as zero, a partial one would not
+    c.Cout_pad = round_up(d.Cout, 128);
+    c.lds_bytes = (size_t)(F16K_D + 1) * T * c.KS * 4096 + (size_t)(L + 1) * c.PB + 1024;
+    if (c.lds_bytes > 160 * 1024) return c;
+    c.ok = 1;
+    return c;
+}
+
+}  // namespace
+
+extern "C" int masic_conv_f16k_supported(const masic_conv_desc_t* d) {
+    if (check_desc(d) != MASIC_OK) return 0;
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    return choose_f16k(*d, g, np).ok;
+}
+
+extern "C" size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d) {
+    if (check_desc(d) != MASIC_OK) return 0;
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const F16kCfg c = choose_f16k(*d, g, np);
+    if (!c.ok) return 0;
+    int taps = 0;
+    for (int p = 0; p < np; ++p) taps += g[p].ntaps;
+    return (size_t)taps * c.Cin16p * 16 * c.Cout_pad * sizeof(unsigned short);
+}
+
+extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(w && w_packed, MASIC_ERR_ARG, "conv_f16k_pack_weight: null pointer");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const F16kCfg c = choose_f16k(*d, g, np);
+    MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
+    for (int p = 0; p < np; ++p) {
+        PackArgs a{w, nullptr, d->Cin, d->Cout, d->KH, d->KW, c.Cin16p * 16, c.Cout_pad, d->transposed, g[p]};
+        const size_t tot = (size_t)g[p].ntaps * c.Cin16p * 16 * c.Cout_pad;
+        int nb = (int)((tot + 255) / 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+    }
+    return masic_launch_status("conv_f16k_pack_weight");
+}
+
+extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                                   float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(x_f16k && w_packed && ((y_nchw != nullptr) != (y_f16k != nullptr)), MASIC_ERR_ARG,
+                  "conv_f16k_fwd: need input, weights and exactly one output");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const F16kCfg c = choose_f16k(*d, g, np);
+    MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
+    MASIC_REQUIRE(d->in_ctot % 16 == 0 && d->in_coff % 16 == 0, MASIC_ERR_SHAPE, "conv_f16k: input channel view must be 16-aligned");
+    MASIC_REQUIRE(y_f16k == nullptr || (d->out_ctot % 16 == 0 && d->out_coff % 16 == 0 && d->Cout % 4 == 0 && gate == nullptr),
+                  MASIC_ERR_SHAPE, "conv_f16k: F16K output needs a 16-aligned channel view, Cout % 4 == 0 and no gate");
+    if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
+    const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
+    F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
+               d->in_ctot / 16, d->in_coff / 16, c.Cin16, c.Cin16p,
+               d->Hi, d->Wi, d->Cout, c.Cout_pad, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+               d->gate_ctot, d->gate_c, d->act,
+               c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
+               c.PH, c.PW, c.PWh, c.NPIXp, c.PB, geom_params(*d), np};
+    dim3 grid(round_up(ntiles, 8) * np, c.Cout_pad / 128, d->B);
+    hipStream_t st = (hipStream_t)stream;
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, OUTV)                                                                              \
+    do {                                                                                                             \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, 2, LV, OUTV>;                                                           \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
+    } while (0)
+    if (c.KS == 1) {
+        if (y_nchw) F16K_LAUNCH(1, 4, 6, 1, 0);
+        else F16K_LAUNCH(1, 4, 6, 1, 1);
+    } else {
+        if (y_nchw) F16K_LAUNCH(2, 2, 3, 2, 0);
+        else F16K_LAUNCH(2, 2, 3, 2, 1);
+    }
+#undef F16K_LAUNCH
+    return masic_launch_status("conv_f16k_fwd");
+}

@@ -497,3 +497,48 @@ def gemm1x1_bf16(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_c
     check(lib.masic_gemm1x1_bf16_fwd(_p(x_f16k), _p(wp), _p(bias), _p(y16), _p(y32), B, Cin, Cout, HW, out_ctot, out_coff, int(act), _stream()),
           "gemm1x1_bf16_fwd")
     return y32 if y32 is not None else y16
+
+
+# --------------------------------------------------------------------------------------------- F16K convolutions
+def f16k_to_nchw(y16, B, C, H, W):
+    """F16K int16 buffer -> float32 NCHW (torch ops; used by tests and by consumers outside the bf16 chain)."""
+    c16 = (C + 15) // 16
+    t = y16.view(torch.bfloat16).view(B, c16, H * W, 16).permute(0, 1, 3, 2).reshape(B, c16 * 16, H, W)
+    return t[:, :C].float().contiguous()
+
+
+def conv_f16k_supported(desc):
+    return bool(lib.masic_conv_f16k_supported(ctypes.byref(desc)))
+
+
+def pack_conv_f16k_weight(weight, desc):
+    _dev(weight, "weight")
+    nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+    if nbytes == 0:
+        check(-1, "conv_f16k_packed_bytes")
+    packed = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_conv_f16k_pack_weight(_p(weight), _p(packed), ctypes.byref(desc), _stream()), "conv_f16k_pack_weight")
+    return packed
+
+
+def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=None):
+    """Conv on an F16K input [B][in_ctot/16][Hi*Wi][16]; returns float32 NCHW (want_nchw / out_nchw) or an F16K buffer of
+    desc.out_ctot channels (a fresh one holds exactly ceil16(Cout) channels)."""
+    if x16.dtype != torch.int16 or not x16.is_cuda:
+        raise RuntimeError("masic_amd.conv2d_f16k: input must be an F16K int16 CUDA buffer")
+    if x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
+        raise RuntimeError(f"masic_amd.conv2d_f16k: input buffer of {x16.numel()} elements does not match descriptor "
+                           f"[{desc.B},{desc.in_ctot},{desc.Hi},{desc.Wi}]")
+    if bias is not None:
+        _dev(bias, "bias")
+    y32 = y16 = None
+    if want_nchw or out_nchw is not None:
+        y32 = out_nchw if out_nchw is not None else torch.empty((desc.B, desc.out_ctot, desc.Ho, desc.Wo), dtype=torch.float32, device=x16.device)
+        if tuple(y32.shape) != (desc.B, desc.out_ctot, desc.Ho, desc.Wo):
+            raise RuntimeError(f"masic_amd.conv2d_f16k: output buffer {tuple(y32.shape)} does not match descriptor")
+        if gate is not None and tuple(gate.shape) != (desc.B, desc.gate_ctot, desc.Ho, desc.Wo):
+            raise RuntimeError("masic_amd.conv2d_f16k: gate does not match descriptor")
+    else:
+        y16 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.int16, device=x16.device)
+    check(lib.masic_conv_f16k_fwd(_p(x16), _p(packed), _p(bias), _p(gate), _p(y32), _p(y16), ctypes.byref(desc), _stream()), "conv_f16k_fwd")
+    return y32 if y32 is not None else y16
