@@ -134,7 +134,7 @@ def main():
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
-    peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in dom else F32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS
     roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": tflops / peak, "traffic": None,
                 "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,

@@ -98,6 +98,35 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
+def _bf16_inference(*tensors):
+    """True when the forward runs with bf16 operands and nothing needs a gradient: the F16K chains apply."""
+    from masic_amd import nn as _mnn
+    if _mnn.get_precision() != "bf16":
+        return False
+    return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
+
+def _gdn_f16k(gdn, x):
+    return _hip.gdn_f16k(x, gdn.beta.detach(), gdn.gamma.detach(), inverse=gdn.inverse, beta_min=gdn.beta_min)
+
+
+def _analysis_f16k(convs, gdns, t):
+    """conv -> GDN -> conv -> GDN -> conv -> GDN -> conv with the 128-channel activations between GDN and the next
+    convolution in F16K bf16 (conv_f16k.hip). `t`: float32 NCHW output of the first convolution. None if a shape has no
+    F16K configuration (the caller then takes the NCHW path)."""
+    B, _, H, W = t.shape
+    sizes = [(H, W)]
+    for cv in convs:
+        if (sizes[-1][0] * sizes[-1][1]) % 32 != 0 or not cv.f16k_supported(B, *sizes[-1]):
+            return None
+        d = cv._desc_f16k(B, *sizes[-1])
+        sizes.append((d.Ho, d.Wo))
+    for cv, gd, (h, w) in zip(convs, gdns, sizes):
+        t16 = _gdn_f16k(gd, t)
+        t, _, _ = cv.run_f16k(t16, B, h, w, want_nchw=True)
+    return t
+
+
 # ------------------------------------------------------------------------------------------ sub-networks
 class encode_hyper(nn.Module):
     """|y| -> conv5x5 s1 -> ReLU -> conv5x5 s2 -> ReLU -> conv5x5 s2 (reference :170-187)."""
@@ -209,6 +238,28 @@ class mask2weights(nn.Module):
         return s[6].run(t, act=_hip.ACT_SOFTMAX_C)
 
 
+def _synthesis_f16k(dec, y_hat):
+    """deconv -> IGDN -> deconv -> IGDN -> deconv -> IGDN of a synthesis transform with F16K activations in between;
+    returns the float32 NCHW input of the last (128 -> 3) transposed convolution, or None if a shape is unsupported."""
+    B, _, H, W = y_hat.shape
+    convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3)
+    gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
+    sizes = [(H, W)]
+    for cv in convs:
+        if not cv.f16k_supported(B, *sizes[-1]):
+            return None
+        d = cv._desc_f16k(B, *sizes[-1])
+        if (d.Ho * d.Wo) % 32 != 0:
+            return None
+        sizes.append((d.Ho, d.Wo))
+    t16 = _hip.nchw_to_f16k(y_hat)
+    for i, (cv, gd) in enumerate(zip(convs, gdns)):
+        t, _, _ = cv.run_f16k(t16, B, *sizes[i], want_nchw=True)
+        if i == 2:
+            return gd(t)                                 # float32 NCHW for the few-output-channel kernel
+        t16 = _gdn_f16k(gd, t)
+
+
 class Encoder1(nn.Module):
     """Left analysis transform (reference :510-531)."""
 
@@ -227,6 +278,15 @@ class Encoder1(nn.Module):
         g2 = self.g_a_gdn2(self.g_a_conv2(g1))
         g3 = self.g_a_gdn3(self.g_a_conv3(g2))
         return self.g_a_conv4(g3), g1, g2, g3
+
+    def latent(self, x):
+        """forward(x)[0]; with bf16 operands and no autograd the intermediate activations stay in F16K."""
+        if _bf16_inference(x, self.g_a_conv1.weight):
+            y = _analysis_f16k((self.g_a_conv2, self.g_a_conv3, self.g_a_conv4), (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3),
+                               self.g_a_conv1(x))
+            if y is not None:
+                return y
+        return self.forward(x)[0]
 
 
 class Decoder1(nn.Module):
@@ -247,6 +307,14 @@ class Decoder1(nn.Module):
         g2 = self.g_s_gdn2(self.g_s_conv2(g1))
         g3 = self.g_s_gdn3(self.g_s_conv3(g2))
         return self.g_s_conv4(g3), g1, g2, g3
+
+    def reconstruct(self, y_hat):
+        """forward(y_hat)[0]; F16K chain with bf16 operands and no autograd."""
+        if _bf16_inference(y_hat, self.g_s_conv1.weight):
+            g3 = _synthesis_f16k(self, y_hat)
+            if g3 is not None:
+                return self.g_s_conv4(g3)
+        return self.forward(y_hat)[0]
 
 
 class Encoder2(nn.Module):
@@ -269,6 +337,11 @@ class Encoder2(nn.Module):
 
     def forward_pair(self, pair):
         t = self.pre_gdn(self.pre_conv(pair))
+        if _bf16_inference(pair, self.g_a_conv1.weight):
+            y = _analysis_f16k((self.g_a_conv2, self.g_a_conv3, self.g_a_conv4), (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3),
+                               self.g_a_conv1(t))
+            if y is not None:
+                return y
         t = self.g_a_gdn1(self.g_a_conv1(t))
         t = self.g_a_gdn2(self.g_a_conv2(t))
         t = self.g_a_gdn3(self.g_a_conv3(t))
@@ -291,9 +364,11 @@ class Decoder2(nn.Module):
         self.after_conv = deconv(6, 3, stride=1)
 
     def forward(self, y_hat, x1_hat_warp):
-        t = self.g_s_gdn1(self.g_s_conv1(y_hat))
-        t = self.g_s_gdn2(self.g_s_conv2(t))
-        t = self.g_s_gdn3(self.g_s_conv3(t))
+        t = _synthesis_f16k(self, y_hat) if _bf16_inference(y_hat, self.g_s_conv1.weight) else None
+        if t is None:
+            t = self.g_s_gdn1(self.g_s_conv1(y_hat))
+            t = self.g_s_gdn2(self.g_s_conv2(t))
+            t = self.g_s_gdn3(self.g_s_conv3(t))
         t = self.after_gdn(self.g_s_conv4(t))
         return self.after_conv(_ag.cat(t, x1_hat_warp))
 
@@ -411,7 +486,7 @@ class HSIC(CompressionModel):
         m_fwd, m_back = warp_matrices if warp_matrices is not None else _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
 
         # ---- left view
-        y1 = self.encoder1(x1)[0]
+        y1 = self.encoder1.latent(x1)
         z1 = self._h_a1(y1)
         z1_hat, z1_lik = self.entropy_bottleneck1(z1)
         h, w = y1.shape[-2:]
@@ -424,7 +499,7 @@ class HSIC(CompressionModel):
             self.context_prediction1.run(y1, in_op=_hip.INOP_ROUND, out=cat1, out_coff=2 * M)
         s1, m1, l1 = self._h_s1_same_resolution.heads(cat1)
         y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
-        x1_hat = self.decoder1(y1_hat)[0]
+        x1_hat = self.decoder1.reconstruct(y1_hat)
 
         # ---- right view
         pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
@@ -447,7 +522,7 @@ class HSIC(CompressionModel):
             self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
 
         x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
-        y1_warp = self.encoder1(x1_hat_warp)[0]
+        y1_warp = self.encoder1.latent(x1_hat_warp)
         noise = self.gaussian1._get_noise_cached(y1_warp) if train else None
         _hip.quantize(y1_warp, mode, noise=noise, out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
 
@@ -466,7 +541,7 @@ class HSIC(CompressionModel):
         range coder (reference compress(): MASIC.py:855-868)."""
         x1 = x1.contiguous()
         B, _, H, W = x1.shape
-        y1 = self.encoder1(x1)[0]
+        y1 = self.encoder1.latent(x1)
         z1 = self._h_a1(y1)
         m_fwd, _ = _warp_matrices(h_matrix, (H, W), (H, W))
         x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))

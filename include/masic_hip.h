@@ -110,6 +110,7 @@ int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float
  *   masic_conv_f16k_supported    1 when the layer shape has a configuration (Cout >= 64, Cin >= 16, ...), else 0
  *   masic_conv_f16k_packed_bytes / _pack_weight   [phase-tap][ci/16][co][16] bf16 weights for this path */
 int masic_conv_f16k_supported(const masic_conv_desc_t* d);
+int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_out, char* buf, size_t n);   /* symbol as rocprofv3 prints it */
 size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
 int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
@@ -126,6 +127,9 @@ int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* 
  * accumulate, ~2^-16 relative) at 16/3 of the f32 matrix rate -- HBM-bound; MASIC_PREC_F32: exact float32 MFMA */
 int masic_gdn_fwd_ex(const float* x, const float* beta, const float* gamma, float* y,
                      int B, int C, int H, int W, int inverse, double beta_min, int prec, void* stream);
+/* Same, C = 128 only, result written as F16K bf16 [B][8][H*W][16] for masic_conv_f16k_fwd (bf16x3 contraction). */
+int masic_gdn_fwd_f16k(const float* x, const float* beta, const float* gamma, void* y_f16k,
+                       int B, int C, int H, int W, int inverse, double beta_min, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Quantisation: compressai/entropy_models/entropy_models.py:98-125 with means=None.

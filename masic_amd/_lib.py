@@ -40,6 +40,7 @@ SIGNATURES = {
     "masic_f16k_bytes": (c_size_t, [c_int, c_int, c_int]),
     "masic_nchw_to_f16k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv_f16k_supported": (c_int, [_P]),
+    "masic_conv_f16k_kernel_name": (c_int, [_P, c_int, ctypes.c_char_p, c_size_t]),
     "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),
     "masic_conv_f16k_pack_weight": (c_int, [_P, _P, _P, _P]),
     "masic_conv_f16k_fwd": (c_int, [_P] * 8),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "masic_gemm1x1_bf16_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "masic_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_gdn_fwd_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int, _P]),
+    "masic_gdn_fwd_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_quantize_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     "masic_symbols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "masic_entropy_bottleneck_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [c_float, _P]),

@@ -368,6 +368,19 @@ extern "C" int masic_conv_f16k_supported(const masic_conv_desc_t* d) {
     return choose_f16k(*d, g, np).ok;
 }
 
+extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_out, char* buf, size_t n) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(buf && n > 0, MASIC_ERR_ARG, "conv_f16k_kernel_name: null buffer");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const F16kCfg c = choose_f16k(*d, g, np);
+    MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
+    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 2, 1, %d>", F16K_D, f16k_out ? 1 : 0);
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, 2, %d>", F16K_D, f16k_out ? 1 : 0);
+    return MASIC_OK;
+}
+
 extern "C" size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d) {
     if (check_desc(d) != MASIC_OK) return 0;
     ConvGeom g[4];

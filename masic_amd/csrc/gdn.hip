@@ -98,6 +98,7 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
 
 __global__ __launch_bounds__(256, 2) void gdn_bf16x3_c128(const float* __restrict__ x, const float* __restrict__ beta,
                                                        const float* __restrict__ gamma, float* __restrict__ y,
+                                                       unsigned short* __restrict__ y16,
                                                        int HW, int strips_per_image, int nstrips, int inverse,
                                                        float beta_bound, float gamma_bound, float pedestal) {
     constexpr int C = 128;
@@ -171,6 +172,32 @@ __global__ __launch_bounds__(256, 2) void gdn_bf16x3_c128(const float* __restric
             __builtin_amdgcn_sched_barrier(0);      // keep the 64 fragment reads from being hoisted to the top (register blow-up)
         }
         // epilogue: accumulator register e of block m <-> the value this lane loaded as xv[2m + (e>>3)][4*((e>>2)&1) + (e&3)]
+        if (y16 != nullptr) {
+            // F16K bf16 [B][8][HW][16] for the next convolution (conv_f16k.hip): 4 consecutive channels = one 8-byte store
+            unsigned short* yr = y16 + ((size_t)b * 8 * HW + sp0 + j) * 16 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * q + i;
+                        const float xval = xv[2 * m + (e >> 3)][4 * ((e >> 2) & 1) + (e & 3)];
+                        const float sq = sqrtf(acc[m][e] + bet[32 * m + 8 * q + i + 4 * h]);
+                        o[i] = inverse ? xval * sq : xval * (1.0f / sq);
+                    }
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    bf2 p0, p1;
+                    p0[0] = (__bf16)o[0]; p0[1] = (__bf16)o[1]; p1[0] = (__bf16)o[2]; p1[1] = (__bf16)o[3];
+                    uint2 st;
+                    st.x = __builtin_bit_cast(unsigned, p0);
+                    st.y = __builtin_bit_cast(unsigned, p1);
+                    // channels 32m + 8q + 4h ..+3: record 2m + (q >> 1), offset 8 (q & 1) + 4h
+                    *reinterpret_cast<uint2*>(yr + (size_t)(2 * m + (q >> 1)) * HW * 16 + 8 * (q & 1)) = st;
+                }
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -242,8 +269,8 @@ extern "C" int masic_gdn_fwd_ex(const float* x, const float* beta, const float* 
     if (C == 128 && HW % 32 == 0 && prec == MASIC_PREC_BF16) {
         const int spi = HW / 32, nstrips = spi * B;
         const int grid = nstrips < 4 * 512 ? (nstrips + 3) / 4 : 512;
-        hipLaunchKernelGGL(gdn_bf16x3_c128, dim3(grid), dim3(256), 0, st, x, beta, gamma, y, HW, spi, nstrips, inverse,
-                           beta_bound, gamma_bound, pedestal);
+        hipLaunchKernelGGL(gdn_bf16x3_c128, dim3(grid), dim3(256), 0, st, x, beta, gamma, y, (unsigned short*)nullptr, HW, spi, nstrips,
+                           inverse, beta_bound, gamma_bound, pedestal);
     } else if (C == 128 && HW % PT == 0) {
         const int tpi = HW / PT, ntiles = tpi * B;
         const int grid = ntiles < 1024 ? ntiles : 1024;
@@ -254,4 +281,21 @@ extern "C" int masic_gdn_fwd_ex(const float* x, const float* beta, const float* 
                            x, beta, gamma, y, C, HW, inverse, beta_bound, gamma_bound, pedestal);
     }
     return masic_launch_status("gdn_fwd");
+}
+
+// GDN of a 128-channel float32 NCHW tensor with the result written as F16K bf16 [B][8][H*W][16] -- the input layout of
+// masic_conv_f16k_fwd; the bf16-operand forward's analysis / synthesis chains (MASIC.py:521-531, :544-554) go
+// conv -> (float32) -> GDN -> (F16K) -> conv.
+extern "C" int masic_gdn_fwd_f16k(const float* x, const float* beta, const float* gamma, void* y_f16k,
+                                  int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    MASIC_REQUIRE(x && beta && gamma && y_f16k, MASIC_ERR_ARG, "gdn_fwd_f16k: null pointer");
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0, MASIC_ERR_SHAPE, "gdn_fwd_f16k: non-positive dimension");
+    MASIC_REQUIRE(C == 128 && (H * W) % 32 == 0, MASIC_ERR_UNSUPPORTED, "gdn_fwd_f16k: needs C = 128 and H*W %% 32 == 0");
+    const double ped = 0x1p-36;
+    const int HW = H * W, spi = HW / 32, nstrips = spi * B;
+    const int grid = nstrips < 4 * 512 ? (nstrips + 3) / 4 : 512;
+    hipLaunchKernelGGL(gdn_bf16x3_c128, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, gamma, (float*)nullptr,
+                       (unsigned short*)y_f16k, HW, spi, nstrips, inverse, (float)__builtin_sqrt(beta_min + ped),
+                       (float)__builtin_sqrt(ped), (float)ped);
+    return masic_launch_status("gdn_fwd_f16k");
 }

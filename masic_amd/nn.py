@@ -76,6 +76,41 @@ class _PackedWeightMixin:
             self.__dict__["_packed_gemm_cache"] = cache
         return cache[1]
 
+    # ---- F16K path (bf16 operands; activations [B][C/16][H*W][16] bf16 between layers, masic_amd/csrc/conv_f16k.hip)
+    def _desc_f16k(self, B, Hi, Wi, out_ctot=None, out_coff=0, act=ops.ACT_NONE, gate_ctot=0, gate_c=0, in_ctot=None, in_coff=0):
+        kh, kw, s, p = self._geometry()
+        cin16 = (self.in_channels + 15) // 16 * 16
+        return ops.make_conv_desc(B, self.in_channels, Hi, Wi, self.out_channels, kh, kw, s, p,
+                                  transposed=self.transposed_conv, masked=self.masked_conv,
+                                  in_ctot=cin16 if in_ctot is None else in_ctot, in_coff=in_coff,
+                                  out_ctot=out_ctot, out_coff=out_coff, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=PREC_BF16)
+
+    def f16k_supported(self, B, Hi, Wi):
+        return ops.conv_f16k_supported(self._desc_f16k(B, Hi, Wi))
+
+    def packed_f16k_weight(self, desc):
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi)
+        cache = self.__dict__.get("_packed_f16k_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.pack_conv_f16k_weight(w.detach().contiguous(), desc))
+            self.__dict__["_packed_f16k_cache"] = cache
+        return cache[1]
+
+    def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0):
+        """Inference-only: y = act(conv(x) + bias) on an F16K input buffer. Returns (y, Ho, Wo) with y an F16K buffer of
+        ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate)."""
+        if out is not None:
+            desc = self._desc_f16k(B, Hi, Wi, out_ctot=out.shape[1], out_coff=out_coff, act=act,
+                                   gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
+        elif want_nchw:
+            desc = self._desc_f16k(B, Hi, Wi, act=act)
+        else:
+            desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 15) // 16 * 16, act=act)
+        bias = None if self.bias is None else self.bias.detach()
+        y = ops.conv2d_f16k(x16, self.packed_f16k_weight(desc), bias, desc, out_nchw=out, want_nchw=want_nchw, gate=gate)
+        return y, desc.Ho, desc.Wo
+
     def invalidate_packed_weight(self):
         self.__dict__.pop("_packed_cache", None)
 

@@ -157,6 +157,15 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6, prec=_lib.PREC_F32):
     return y
 
 
+def gdn_f16k(x, beta, gamma, inverse=False, beta_min=1e-6):
+    """GDN of a 128-channel float32 NCHW tensor -> F16K bf16 buffer (input of conv2d_f16k)."""
+    _dev(x, "gdn input"); _dev(beta, "beta"); _dev(gamma, "gamma")
+    B, C, H, W = x.shape
+    y = torch.empty(B * C * H * W, dtype=torch.int16, device=x.device)
+    check(lib.masic_gdn_fwd_f16k(_p(x), _p(beta), _p(gamma), _p(y), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_fwd_f16k")
+    return y
+
+
 # --------------------------------------------------------------------------------------------- entropy
 def quantize(x, mode, noise=None, out=None, out_coff=0, gate=None, gate_c=0):
     """mode: 'dequantize' (round), 'noise' (x + noise) or 'copy' (identity; for gated writes into a concat slice)."""
@@ -540,5 +549,17 @@ def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=No
             raise RuntimeError("masic_amd.conv2d_f16k: gate does not match descriptor")
     else:
         y16 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.int16, device=x16.device)
+    timed = None
+    if _timer is not None:
+        buf = ctypes.create_string_buffer(96)
+        lib.masic_conv_f16k_kernel_name(ctypes.byref(desc), int(y16 is not None), buf, 96)
+        variant = buf.value.decode()
+        if _timer.only is None or variant == _timer.only:
+            timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timed[1].record()
     check(lib.masic_conv_f16k_fwd(_p(x16), _p(packed), _p(bias), _p(gate), _p(y32), _p(y16), ctypes.byref(desc), _stream()), "conv_f16k_fwd")
+    if timed is not None:
+        timed[2].record()
+        flops, nbytes = conv_algorithmic_work(desc)
+        _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
     return y32 if y32 is not None else y16
