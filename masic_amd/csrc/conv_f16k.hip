@@ -27,6 +27,7 @@
 // for the next layer.
 #include "common.h"
 #include "conv_geom.h"
+#include <type_traits>
 
 namespace {
 
@@ -51,39 +52,86 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 
 struct F16kArgs {
     const unsigned short* x;      // F16K [B][in_c16tot][Hi*Wi][16]
-    const unsigned short* w;      // [phase-tap][Cin16p][Cout_pad][16]
+    const unsigned short* w;      // slab stream, see pack_f16k_stream_kernel
     const float* bias;
     const float* gate;            // float32 [B][gate_ctot][Ho][Wo] or null (NCHW output only)
     float* y32;                   // float32 NCHW view, or null
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
-    int in_c16tot, in_c16off, Cin16, Cin16p;
-    int Hi, Wi, Cout, Cout_pad, Ho, Wo;
+    int in_c16tot, in_c16off, Cin16;
+    int Hi, Wi, Cout, Ho, Wo;
     int out_ctot, out_coff;       // channel view of the output (NCHW: channels; F16K: channels, multiples of 16)
     int gate_ctot, gate_c, act;
     int TW, TWlog, SR, TH, tiles_w, ntiles;
     int PH, PW, PWh, NPIXp;       // patch rows / row length (pixels), ceil(PW/2), records per k-half plane of the LDS image (x32)
     int PB;                       // bytes per patch buffer
+    unsigned phase_off[4];        // byte offset of each phase's slab streams
+    unsigned stream_bytes[4];     // bytes of one (phase, co-block) slab stream
     GeomParams q;
     int nphase;
 };
 
 #ifndef F16K_ABLATE
-#define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers, 3 fragments read once
+#define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers
 #endif
-constexpr int MAXSPC = 7;   // steps per chunk (unrolled)
+constexpr int MAXTAPS = 32;   // tap table entries (taps of a phase padded to a multiple of T)
+
+// Weights for this path, in the order the kernel consumes them ("slab stream"): for each phase, each 128-channel
+// co-block, each chunk c of KS 16-channel blocks, each step t of T taps (taps padded with zeros to a multiple of T):
+// T*KS slabs of 4 KiB, each the LDS image [k-half hh][co 128][8 ci] of W[co, (c*KS+ks)*16 + hh*8 + e, tap].
+// A step's slab group is one contiguous WST = T*KS*4096 bytes, so the DMA of step g is base + g*WST.
+struct PackStreamArgs {
+    const float* w;
+    int Cin, Cout, KH, KW, transposed;
+    int KS, T, nchunks, ncb;
+    ConvGeom g;
+    unsigned phase_off;       // bytes
+};
+
+__global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* __restrict__ wp) {
+    const int spc = (a.g.ntaps + a.T - 1) / a.T;
+    const size_t total = (size_t)a.ncb * a.nchunks * spc * a.T * a.KS * 2048;        // bf16 elements
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = (int)(r & 7); r >>= 3;
+        const int co = (int)(r & 127); r >>= 7;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r % a.KS); r /= a.KS;
+        const int tt = (int)(r % a.T); r /= a.T;
+        const int t = (int)(r % spc); r /= spc;
+        const int c = (int)(r % a.nchunks); r /= a.nchunks;
+        const int cb = (int)r;
+        const int tap = t * a.T + tt;
+        const int ci = (c * a.KS + ks) * 16 + hh * 8 + e, cog = cb * 128 + co;
+        float v = 0.0f;
+        if (tap < a.g.ntaps && ci < a.Cin && cog < a.Cout) {
+            const int ta = tap / a.g.ntw, tb = tap - ta * a.g.ntw;
+            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const size_t src = a.transposed ? (((size_t)ci * a.Cout + cog) * a.KH + kh) * a.KW + kw
+                                            : (((size_t)cog * a.Cin + ci) * a.KH + kh) * a.KW + kw;
+            v = a.w[src];
+        }
+        const __bf16 bv = (__bf16)v;
+        wp[(a.phase_off >> 1) + i] = __builtin_bit_cast(unsigned short, bv);
+    }
+}
+
+__device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
 
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
-// patch wave per step during the first PSTEPS steps of a chunk, L patch look-ahead (chunks), OUT 0: float32 NCHW, 1: F16K
-template <int KS, int T, int D, int PSP, int PSTEPS, int L, int OUT>
+// patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks), OUT 0: float32 NCHW, 1: F16K
+template <int KS, int T, int D, int PSP, int L, int OUT>
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
-    constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab)
+    constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
-    constexpr int WST = T * KS * 4096;           // bytes per weight slab (T taps x KS 16-channel blocks x 128 co x 32 B)
-    constexpr int NPI = PSP * PSTEPS;            // patch DMA wave-instructions per patch wave per chunk (incl. dummies)
+    constexpr int WST = T * KS * 4096;           // bytes per step of weights
+    constexpr int NPI = PSP * 2;                 // patch DMA wave-instructions per patch wave per chunk (incl. dummies)
     constexpr int NB = L + 1;                    // patch buffers
     constexpr int PATCH0 = NWS * WST;            // LDS byte offset of the patch buffers
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int dummy_off = PATCH0 + NB * a.PB;
+    const int dummy_off = PATCH0 + NB * a.PB;    // 1 KiB sink for unused DMA slots, then the tap table
+    const int table_off = dummy_off + 1024;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,88 +148,80 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int phase = rest % a.nphase;
     const int tile = (rest / a.nphase) * 8 + xcd;
     if (tile >= a.ntiles) return;
-    const ConvGeom g = make_geom(a.q, phase);
     const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
-    const int m0 = blockIdx.y * 128;
     const int b = blockIdx.z;
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
-    const int ih0 = r0 * g.is + g.dh_min, iw0 = c0 * g.is + g.dw_min;
-
-    const int SPC = (g.ntaps + T - 1) / T;                    // steps per chunk
-    const int nchunks = a.Cin16p / KS;
+    const int nchunks = a.Cin16 / KS;
     const int gpk = a.NPIXp >> 5;                             // DMA wave-instructions per 16-channel plane of the patch (2*NPIXp/64)
-    const int ninstr = KS * gpk;
     const int plane_bytes = a.Hi * a.Wi * 32;                 // bytes per 16-channel plane of the input
-    const int PWe = g.is == 2 ? a.PWh : a.PW;                 // row pitch (records) of the LDS patch image
+    int SPC;                                                  // steps per chunk
+    int bl[2];                                                // lane part of the B-fragment address
+    int goff[NPI];                                            // patch waves: byte offset of this lane's record in a chunk
 
-    // Buffer resources: out-of-range offsets read as zero, so padding pixels (voffset = huge) and chunks past the last one
-    // (soffset >= num_records) need no special case, and the per-chunk / per-slab offset rides in an SGPR.
+    // Buffer resources: out-of-range offsets read as zero, so padding pixels (voffset = huge), chunks past the last one and
+    // slab groups past the end of the stream need no special case, and the per-chunk / per-step offset rides in an SGPR.
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + ((size_t)b * a.in_c16tot + a.in_c16off) * (size_t)(a.Hi * a.Wi * 16)), 0, a.Cin16 * plane_bytes, 0x00020000);
-    const int slab_bytes = a.Cout_pad * 32;                   // one (tap, 16-channel) slab over all output channels
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.w + ((size_t)g.tap_base * a.Cin16p * a.Cout_pad + m0) * 16), 0, g.ntaps * a.Cin16p * slab_bytes - m0 * 32, 0x00020000);
+        (void*)((const unsigned char*)a.w + a.phase_off[phase] + (size_t)blockIdx.y * a.stream_bytes[phase]), 0, (int)a.stream_bytes[phase], 0x00020000);
 
-    // ---- LDS images (16-byte records, the two k-halves of a 32-byte record in separate planes so that the 16 lanes of a
-    // ds_read_b128 group read 256 contiguous bytes):
-    //   weight slab (tap, ks): [hh][co 128]
-    //   patch plane (ks):      [hh][pixel'] with pixel' = row * PW + col for stride-1 walks and, for strided convs,
-    //                          columns de-interleaved by parity, pixel' = ((col & 1) * PH + row) * PWh + (col >> 1),
-    //                          so that the stride-2 walk of a tap reads consecutive records too.
-    int goff[NPI];                                            // patch waves: byte offset of this lane's record in a chunk
+    {   // ---- geometry-dependent setup (kept in a scope: nothing of the phase geometry stays live in the K loop)
+        const ConvGeom g = make_geom(a.q, phase);
+        SPC = (g.ntaps + T - 1) / T;
+        const int ih0 = r0 * g.is + g.dh_min, iw0 = c0 * g.is + g.dw_min;
+        const int ninstr = KS * gpk;
+        // LDS images (16-byte records, the two k-halves of a 32-byte record in separate planes so that the 16 lanes of a
+        // ds_read_b128 group read 256 contiguous bytes):
+        //   weight slab (tap, ks): [hh][co 128]   (the packed stream already has this order: a linear copy)
+        //   patch plane (ks):      [hh][pixel'] with pixel' = row * PW + col for stride-1 walks and, for strided convs,
+        //                          columns de-interleaved by parity, pixel' = ((col & 1) * PH + row) * PWh + (col >> 1),
+        //                          so that the stride-2 walk of a tap reads consecutive records too.
 #pragma unroll
-    for (int k = 0; k < NPI; ++k) {
-        const int I = k * 4 + wq;
-        const int ks = I / gpk, grp = I - ks * gpk;
-        const int q = grp * 64 + lane;
-        const int hh = q >= a.NPIXp ? 1 : 0, pp = q - hh * a.NPIXp;
-        int pr, pc;
-        bool ok = I < ninstr;
-        if (g.is == 2) {
-            const int half = a.PH * a.PWh;
-            const int par = pp >= half ? 1 : 0, rem = pp - par * half;
-            pr = rem / a.PWh;
-            pc = 2 * (rem - pr * a.PWh) + par;
-            ok = ok && pp < 2 * half && pc < a.PW;
-        } else {
-            pr = pp / a.PW;
-            pc = pp - pr * a.PW;
-            ok = ok && pp < a.PH * a.PW;
+        for (int k = 0; k < NPI; ++k) {
+            const int I = k * 4 + wq;
+            const int ks = I / gpk, grp = I - ks * gpk;
+            const int q = grp * 64 + lane;
+            const int hh = q >= a.NPIXp ? 1 : 0, pp = q - hh * a.NPIXp;
+            int pr, pc;
+            bool ok = I < ninstr;
+            if (g.is == 2) {
+                const int half = a.PH * a.PWh;
+                const int par = pp >= half ? 1 : 0, rem = pp - par * half;
+                pr = rem / a.PWh;
+                pc = 2 * (rem - pr * a.PWh) + par;
+                ok = ok && pp < 2 * half && pc < a.PW;
+            } else {
+                pr = pp / a.PW;
+                pc = pp - pr * a.PW;
+                ok = ok && pp < a.PH * a.PW;
+            }
+            const int ih = ih0 + pr, iw = iw0 + pc;
+            ok = ok && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+            goff[k] = ok ? ks * plane_bytes + (ih * a.Wi + iw) * 32 + hh * 16 : 0x7ffffff0;
         }
-        const int ih = ih0 + pr, iw = iw0 + pc;
-        ok = ok && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-        goff[k] = ok ? ks * plane_bytes + (ih * a.Wi + iw) * 32 + hh * 16 : 0x7ffffff0;
-    }
-    auto issue_patch = [&](int k, int goffk, int pcn, int pbslot) {
-        const int I = k * 4 + wq;
-        const int dst = I < ninstr ? PATCH0 + pbslot * a.PB + I * 1024 : dummy_off;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(lds + dst), 16, goffk,
-                                                 pcn * (KS * plane_bytes), 0, 0);
-    };
-
-    // ---- weight DMA (weight waves): wave w fetches quarter w of every (tap, ks) slab of the step
-    const int wvoff = ((wq & 1) * 64 + lane) * 32 + (wq >> 1) * 16;      // record (hh = wq >> 1, co) of a [co][16] slab
-    auto issue_w = [&](int pc_, int pt_, int slot) {
-        const int pcc = pc_ < nchunks ? pc_ : nchunks - 1;                // past the end: a duplicate nobody reads
+        const int PWe = g.is == 2 ? a.PWh : a.PW;             // row pitch (records) of the LDS patch image
+        const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
 #pragma unroll
-        for (int k = 0; k < WI; ++k) {
-            const int tt = k / KS, ks = k % KS;
-            int tap = pt_ * T + tt;
-            tap = tap < g.ntaps ? tap : g.ntaps - 1;                       // ragged last step: likewise
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds + slot * WST + k * 4096 + wq * 1024),
-                                                     16, wvoff, (tap * a.Cin16p + pcc * KS + ks) * slab_bytes, 0, 0);
+        for (int n = 0; n < 2; ++n) {
+            const int r = (wn * 2 + n) * a.SR + jr;
+            bl[n] = (h * a.NPIXp + (r * g.is) * PWe + jc) * 16;
         }
-    };
-
-    // ---- fragment addresses: lane part in a VGPR, (slot / tap / ks) part uniform
-    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
-    const int al = (h * 128 + wm * 64 + j) * 16;
-    int bl[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int r = (wn * 2 + n) * a.SR + jr;
-        bl[n] = (h * a.NPIXp + (r * g.is) * PWe + jc) * 16;
+        // tap table: byte offset of each tap's record inside the LDS patch image (padding taps alias tap 0; their weights are zero)
+        if (tid < MAXTAPS) {
+            const int tap = tid < g.ntaps ? tid : 0;
+            const int ti = tap / g.ntw, tj = tap - ti * g.ntw;
+            const int ta = (g.dh0 - g.dh_min) + ti * g.dsh, tb = (g.dw0 - g.dw_min) + tj * g.dsw;
+            const int slot = g.is == 2 ? ((tb & 1) * a.PH + ta) * a.PWh + (tb >> 1) : ta * a.PW + tb;
+            reinterpret_cast<int*>(lds + table_off)[tid] = slot * 16;
+        }
     }
+    const int ninstr = KS * gpk;
+    const int wvoff = wq * 1024 + lane * 16;                  // weight waves: this lane's record inside a 4 KiB slab
+    const int al = (h * 128 + wm * 64 + j) * 16;              // lane part of the A-fragment address
+    int pdst[NPI];                                            // patch waves: LDS offset inside a patch buffer (or the sink)
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) pdst[k] = (k * 4 + wq) < ninstr ? (k * 4 + wq) * 1024 : -1;
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -190,83 +230,94 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
 
-    const int ta0 = g.dh0 - g.dh_min, tb0 = g.dw0 - g.dw_min;               // patch coordinates of tap (0, 0)
-    auto tap_slot = [&](int ta, int tb) {                                    // record offset of a tap inside the LDS image
-        return g.is == 2 ? ((tb & 1) * a.PH + ta) * a.PWh + (tb >> 1) : ta * a.PW + tb;
-    };
-
-    // ---- prologue: weight slabs of the first D steps, the first L patch chunks
-    int pc_ = 0, pt_ = 0;                                                    // weight producer cursor (chunk, step)
+    // ---- prologue: weight slab groups of the first D steps, the first L patch chunks
+    int wsoff = 0;                                            // weight producer: byte offset of the next slab group in the stream
     if (wrole) {
+#pragma unroll
         for (int d = 0; d < D; ++d) {
-            issue_w(pc_, pt_, d);
-            if (++pt_ == SPC) { pt_ = 0; ++pc_; }
+#pragma unroll
+            for (int k = 0; k < WI; ++k) dma_buf16(rw, lds + d * WST + k * 4096 + wq * 1024, wvoff, wsoff + k * 4096);
+            wsoff += WST;
         }
     } else {
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
-            for (int k = 0; k < NPI; ++k) issue_patch(k, goff[k], l, l);
+            for (int k = 0; k < NPI; ++k)
+                dma_buf16(rx, lds + (pdst[k] >= 0 ? PATCH0 + l * a.PB + pdst[k] : dummy_off), goff[k], l * (KS * plane_bytes));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();
 
-    int cslot = 0, pslot = D % NWS;
-    int cb = 0, pb = L % NB;                                                // patch buffer of chunk c / of chunk c+L
-    for (int c = 0; c < nchunks; ++c) {
-        const int pbuf = PATCH0 + cb * a.PB;
-        int ta = ta0, tb = tb0, tbi = 0;
+    int cslot = 0, pslot = (D % NWS) * WST;                   // byte offsets of the consumer / producer ring slots
+    int cb = PATCH0, pb = PATCH0 + (L % NB) * a.PB;           // byte offsets of the patch buffer of chunk c / of chunk c+L
+    int xsoff = L * (KS * plane_bytes);                       // patch producer: byte offset of chunk c+L in the input
+
+    // One step: slice S of the patch DMA (or none), T taps x KS k-steps of 2x2 MFMAs, counted wait, barrier.
+    auto step = [&](auto slice, int t, bool last) {
+        constexpr int S = decltype(slice)::value;
+        if (F16K_ABLATE == 1) {
+        } else if (wrole) {                                   // weight slab group of step g+D
 #pragma unroll
-        for (int t = 0; t < MAXSPC; ++t) {
-            if (t < SPC) {
-                if (F16K_ABLATE == 1) {
-                } else if (wrole) {                    // weight slab of step g+D
-                    issue_w(pc_, pt_, pslot);
-                    if (++pt_ == SPC) { pt_ = 0; ++pc_; }
-                    pslot = pslot + 1 == NWS ? 0 : pslot + 1;
-                } else if (t < PSTEPS) {               // patch slices of chunk c+L
+            for (int k = 0; k < WI; ++k) dma_buf16(rw, lds + pslot + k * 4096 + wq * 1024, wvoff, wsoff + k * 4096);
+            wsoff += WST;
+            pslot = pslot + WST == NWS * WST ? 0 : pslot + WST;
+        } else if (S >= 0) {                                  // patch slice S of chunk c+L
 #pragma unroll
-                    for (int u = 0; u < PSP; ++u) issue_patch(t * PSP + u, goff[(t < PSTEPS ? t : 0) * PSP + u], c + L, pb);
-                }
-                // T taps x KS k-steps of 2x2 MFMAs
-                const unsigned char* wst = lds + (al + cslot * WST);
-#pragma unroll
-                for (int tt = 0; tt < T; ++tt) {
-                    if (t * T + tt < g.ntaps) {
-                        const int toff = pbuf + tap_slot(ta, tb) * 16;
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            bf16x8 af[2], bfr[2];
-#pragma unroll
-                            for (int n = 0; n < 2; ++n)
-                                bfr[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl[n] + (toff + ks * gpk * 1024))));
-#pragma unroll
-                            for (int m = 0; m < 2; ++m)
-                                af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
-#pragma unroll
-                            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                                for (int n = 0; n < 2; ++n)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-                        }
-                        if (++tbi < g.ntw) tb += g.dsw;
-                        else { tbi = 0; tb = tb0; ta += g.dsh; }
-                    }
-                }
-                cslot = cslot + 1 == NWS ? 0 : cslot + 1;
-                // weight waves: the slab of the next step has landed, the D-1 slabs after it stay in flight.
-                // patch waves: at the end of a chunk the next chunk's patch has landed, the L-1 chunks after it stay in flight.
-                if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * WI) : "memory");
-                else if (t + 1 == SPC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * NPI) : "memory");
-                if (F16K_ABLATE != 2) __builtin_amdgcn_s_barrier();
+            for (int u = 0; u < PSP; ++u) {
+                constexpr int k = (S >= 0 ? S : 0) * PSP;
+                dma_buf16(rx, lds + (pdst[k + u] >= 0 ? pb + pdst[k + u] : dummy_off), goff[k + u], xsoff);
             }
         }
-        cb = cb + 1 == NB ? 0 : cb + 1;
-        pb = pb + 1 == NB ? 0 : pb + 1;
+        int tv[T];
+        if (T == 4) {
+            const int4 q = *reinterpret_cast<const int4*>(lds + table_off + t * 16);
+            tv[0] = q.x; tv[1] = q.y; tv[2 % T] = q.z; tv[3 % T] = q.w;
+        } else {
+            const int2 q = *reinterpret_cast<const int2*>(lds + table_off + t * 8);
+            tv[0] = q.x; tv[1 % T] = q.y;
+        }
+        const unsigned char* wst = lds + (al + cslot);
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    bfr[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl[n] + tv[tt] + (cb + ks * gpk * 1024))));
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
+        // weight waves: the slab group of the next step has landed, the D-1 groups after it stay in flight.
+        // patch waves: at the end of a chunk the next chunk's patch has landed, the L-1 chunks after it stay in flight.
+        if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * WI) : "memory");
+        else if (last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * NPI) : "memory");
+        if (F16K_ABLATE != 2) __builtin_amdgcn_s_barrier();
+    };
+
+    for (int c = 0; c < nchunks; ++c) {
+        step(std::integral_constant<int, 0>{}, 0, false);
+        step(std::integral_constant<int, 1>{}, 1, SPC == 2);
+        for (int t = 2; t < SPC; ++t) step(std::integral_constant<int, -1>{}, t, t + 1 == SPC);
+        cb = cb + a.PB == PATCH0 + NB * a.PB ? PATCH0 : cb + a.PB;
+        pb = pb + a.PB == PATCH0 + NB * a.PB ? PATCH0 : pb + a.PB;
+        xsoff += KS * plane_bytes;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue
+    const ConvGeom g = make_geom(a.q, phase);
+    const int m0 = blockIdx.y * 128;
+    const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
     const size_t oplane = (size_t)a.Ho * a.Wo;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -314,17 +365,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
 struct F16kCfg {
     int ok;
-    int KS;                       // template selection: 1 = strided conv <1,4,3,5,2,1>, 2 = stride-1 walk <2,2,3,3,2,2>
+    int KS, T, L;                 // template selection: strided conv <1,4,D,6,1>, stride-1 walk <2,2,D,3,2>
     int TW, TWlog, SR, TH, PH, PW, PWh, NPIXp, PB;
-    int Cin16, Cin16p, Cout_pad;
-    size_t lds_bytes;
+    int Cin16, ncb;
+    unsigned phase_off[4], stream_bytes[4];
+    size_t packed_bytes, lds_bytes;
 };
 
 constexpr int F16K_D = 3;
 
 F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     F16kCfg c{};
-    if (d.Cout < 64 || d.Cin < 16 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    if (d.Cout < 64 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
     int span_h = 0, span_w = 0, min_taps = 1 << 30, max_taps = 0;
     for (int p = 0; p < nphase; ++p) {
         span_h = span_h > g[p].nth ? span_h : g[p].nth;
@@ -333,10 +385,12 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         max_taps = max_taps > g[p].ntaps ? max_taps : g[p].ntaps;
     }
     const int is = g[0].is, Wp = g[0].Wp;
-    int T, NPI, L;
-    if (is == 2) { c.KS = 1; T = 4; NPI = 12; L = 1; }        // strided conv: big patch, 16-channel chunks, 4 taps per step
-    else { c.KS = 2; T = 2; NPI = 6; L = 2; }                 // stride-1 walk (transposed phases, 3x3, masked): 32-channel chunks
-    if (ceil_div(max_taps, T) > MAXSPC || ceil_div(min_taps, T) < 2) return c;
+    int NPI;
+    if (is == 2) { c.KS = 1; c.T = 4; NPI = 12; c.L = 1; }    // strided conv: big patch, 16-channel chunks, 4 taps per step
+    else { c.KS = 2; c.T = 2; NPI = 6; c.L = 2; }             // stride-1 walk (transposed phases, 3x3, masked): 32-channel chunks
+    if (round_up(max_taps, c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
+    c.Cin16 = d.Cin / 16;
+    if (c.Cin16 % c.KS != 0) return c;                        // whole chunks only
     c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
     c.TWlog = 0;
     while ((1 << c.TWlog) < c.TW) ++c.TWlog;
@@ -349,11 +403,18 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     const int ninstr = c.KS * (c.NPIXp / 32);
     if (ceil_div(ninstr, 4) > NPI) return c;
     c.PB = ninstr * 1024;
-    c.Cin16 = ceil_div(d.Cin, 16);
-    c.Cin16p = round_up(c.Cin16, c.KS);
-    if (c.Cin16p != c.Cin16 || d.Cin % 16 != 0) return c;   // whole chunks only: a chunk past the last reads as zero, a partial one would not
-    c.Cout_pad = round_up(d.Cout, 128);
-    c.lds_bytes = (size_t)(F16K_D + 1) * T * c.KS * 4096 + (size_t)(L + 1) * c.PB + 1024;
+    c.ncb = ceil_div(d.Cout, 128);
+    const int nchunks = c.Cin16 / c.KS;
+    size_t off = 0;
+    for (int p = 0; p < nphase; ++p) {
+        const size_t sb = (size_t)nchunks * ceil_div(g[p].ntaps, c.T) * c.T * c.KS * 4096;
+        c.phase_off[p] = (unsigned)off;
+        c.stream_bytes[p] = (unsigned)sb;
+        off += sb * c.ncb;
+    }
+    if (off >= (1u << 31)) return c;
+    c.packed_bytes = off;
+    c.lds_bytes = (size_t)(F16K_D + 1) * c.T * c.KS * 4096 + (size_t)(c.L + 1) * c.PB + 1024 + MAXTAPS * 4;
     if (c.lds_bytes > 160 * 1024) return c;
     c.ok = 1;
     return c;
@@ -376,8 +437,8 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
-    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 2, 1, %d>", F16K_D, f16k_out ? 1 : 0);
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, 2, %d>", F16K_D, f16k_out ? 1 : 0);
+    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %d>", F16K_D, f16k_out ? 1 : 0);
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %d>", F16K_D, f16k_out ? 1 : 0);
     return MASIC_OK;
 }
 
@@ -386,10 +447,7 @@ extern "C" size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d) {
     ConvGeom g[4];
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
-    if (!c.ok) return 0;
-    int taps = 0;
-    for (int p = 0; p < np; ++p) taps += g[p].ntaps;
-    return (size_t)taps * c.Cin16p * 16 * c.Cout_pad * sizeof(unsigned short);
+    return c.ok ? c.packed_bytes : 0;
 }
 
 extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
@@ -401,11 +459,11 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     for (int p = 0; p < np; ++p) {
-        PackArgs a{w, nullptr, d->Cin, d->Cout, d->KH, d->KW, c.Cin16p * 16, c.Cout_pad, d->transposed, g[p]};
-        const size_t tot = (size_t)g[p].ntaps * c.Cin16p * 16 * c.Cout_pad;
+        PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, g[p], c.phase_off[p]};
+        const size_t tot = (size_t)c.stream_bytes[p] / 2 * c.ncb;
         int nb = (int)((tot + 255) / 256);
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(pack_f16k_stream_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
     }
     return masic_launch_status("conv_f16k_pack_weight");
 }
@@ -426,19 +484,21 @@ extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               d->in_ctot / 16, d->in_coff / 16, c.Cin16, c.Cin16p,
-               d->Hi, d->Wi, d->Cout, c.Cout_pad, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+               d->in_ctot / 16, d->in_coff / 16, c.Cin16,
+               d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
-               c.PH, c.PW, c.PWh, c.NPIXp, c.PB, geom_params(*d), np};
-    dim3 grid(round_up(ntiles, 8) * np, c.Cout_pad / 128, d->B);
+               c.PH, c.PW, c.PWh, c.NPIXp, c.PB,
+               {c.phase_off[0], c.phase_off[1], c.phase_off[2], c.phase_off[3]},
+               {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
+    dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
-#define F16K_LAUNCH(KSV, TV, PSPV, LV, OUTV)                                                                              \
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, OUTV)                                                                         \
     do {                                                                                                             \
-        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, 2, LV, OUTV>;                                                           \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, OUTV>;                                                       \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
             attr_set = true;                                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
