@@ -111,20 +111,20 @@ def _gdn_f16k(gdn, x):
 
 
 def _analysis_f16k(convs, gdns, t):
-    """conv -> GDN -> conv -> GDN -> conv -> GDN -> conv with the 128-channel activations between GDN and the next
-    convolution in F16K bf16 (conv_f16k.hip). `t`: float32 NCHW output of the first convolution. None if a shape has no
-    F16K configuration (the caller then takes the NCHW path)."""
-    B, _, H, W = t.shape
+    """GDN -> conv+GDN -> conv+GDN -> conv of an analysis transform (`t`: float32 NCHW output of its first convolution):
+    the 128-channel activations stay in F16K bf16 and the second and third GDN run in the epilogue of the convolution
+    that feeds them (conv_f16k.hip). None if a shape has no F16K configuration (the caller then takes the NCHW path)."""
+    B, C, H, W = t.shape
     sizes = [(H, W)]
     for cv in convs:
-        if (sizes[-1][0] * sizes[-1][1]) % 32 != 0 or not cv.f16k_supported(B, *sizes[-1]):
+        if C != 128 or (sizes[-1][0] * sizes[-1][1]) % 32 != 0 or not cv.f16k_supported(B, *sizes[-1]):
             return None
         d = cv._desc_f16k(B, *sizes[-1])
         sizes.append((d.Ho, d.Wo))
-    for cv, gd, (h, w) in zip(convs, gdns, sizes):
-        t16 = _gdn_f16k(gd, t)
-        t, _, _ = cv.run_f16k(t16, B, h, w, want_nchw=True)
-    return t
+    t16 = _gdn_f16k(gdns[0], t)
+    t16, _, _ = convs[0].run_f16k(t16, B, *sizes[0], gdn=gdns[1])
+    t16, _, _ = convs[1].run_f16k(t16, B, *sizes[1], gdn=gdns[2])
+    return convs[2].run_f16k(t16, B, *sizes[2], want_nchw=True)[0]
 
 
 # ------------------------------------------------------------------------------------------ sub-networks
@@ -239,25 +239,22 @@ class mask2weights(nn.Module):
 
 
 def _synthesis_f16k(dec, y_hat):
-    """deconv -> IGDN -> deconv -> IGDN -> deconv -> IGDN of a synthesis transform with F16K activations in between;
-    returns the float32 NCHW input of the last (128 -> 3) transposed convolution, or None if a shape is unsupported."""
+    """deconv+IGDN -> deconv+IGDN -> deconv+IGDN of a synthesis transform, F16K in between, the inverse GDNs fused into
+    the transposed convolutions; returns the float32 NCHW input of the last (128 -> 3) transposed convolution, or None if
+    a shape is unsupported."""
     B, _, H, W = y_hat.shape
     convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3)
     gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
     sizes = [(H, W)]
     for cv in convs:
-        if not cv.f16k_supported(B, *sizes[-1]):
+        if cv.out_channels != 128 or not cv.f16k_supported(B, *sizes[-1]):
             return None
         d = cv._desc_f16k(B, *sizes[-1])
-        if (d.Ho * d.Wo) % 32 != 0:
-            return None
         sizes.append((d.Ho, d.Wo))
     t16 = _hip.nchw_to_f16k(y_hat)
-    for i, (cv, gd) in enumerate(zip(convs, gdns)):
-        t, _, _ = cv.run_f16k(t16, B, *sizes[i], want_nchw=True)
-        if i == 2:
-            return gd(t)                                 # float32 NCHW for the few-output-channel kernel
-        t16 = _gdn_f16k(gd, t)
+    t16, _, _ = convs[0].run_f16k(t16, B, *sizes[0], gdn=gdns[0])
+    t16, _, _ = convs[1].run_f16k(t16, B, *sizes[1], gdn=gdns[1])
+    return convs[2].run_f16k(t16, B, *sizes[2], want_nchw=True, gdn=gdns[2])[0]     # float32 NCHW for the few-output-channel kernel
 
 
 class Encoder1(nn.Module):

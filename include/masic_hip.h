@@ -110,11 +110,19 @@ int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float
  *   masic_conv_f16k_supported    1 when the layer shape has a configuration (Cout >= 64, Cin >= 16, ...), else 0
  *   masic_conv_f16k_packed_bytes / _pack_weight   [phase-tap][ci/16][co][16] bf16 weights for this path */
 int masic_conv_f16k_supported(const masic_conv_desc_t* d);
-int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_out, char* buf, size_t n);   /* symbol as rocprofv3 prints it */
+int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, char* buf, size_t n);   /* symbol as rocprofv3 prints it */
 size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
 int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                         float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream);
+/* The same with the (inverse) GDN that follows the 128-channel convolutions of the analysis / synthesis transforms
+ * (MASIC.py:521-531, :544-554; compressai/layers/gdn.py:77-92) fused into the epilogue: y = GDN(conv(x) + bias).
+ * gdn_packed: masic_gdn_pack_f16k of that GDN's stored beta/gamma (masic_gdn_f16k_packed_bytes bytes). */
+size_t masic_gdn_f16k_packed_bytes(void);
+int masic_gdn_pack_f16k(const float* beta, const float* gamma, void* packed, int C, double beta_min, void* stream);
+int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                            const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
+                            const masic_conv_desc_t* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of

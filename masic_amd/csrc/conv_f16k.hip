@@ -57,6 +57,8 @@ struct F16kArgs {
     const float* gate;            // float32 [B][gate_ctot][Ho][Wo] or null (NCHW output only)
     float* y32;                   // float32 NCHW view, or null
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
+    const uint4* gdn_img;         // GDN epilogue: gamma^ fragments (gdn.hip: gdn_pack_f16k_kernel), then beta^[128] floats
+    int gdn_inverse;
     int in_c16tot, in_c16off, Cin16;
     int Hi, Wi, Cout, Ho, Wo;
     int out_ctot, out_coff;       // channel view of the output (NCHW: channels; F16K: channels, multiples of 16)
@@ -120,8 +122,9 @@ __device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned cha
 }
 
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
-// patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks), OUT 0: float32 NCHW, 1: F16K
-template <int KS, int T, int D, int PSP, int L, int OUT>
+// patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks); GDN: (inverse) GDN over the 128
+// output channels fused into the epilogue.  Output: float32 NCHW if a.y32 else F16K.
+template <int KS, int T, int D, int PSP, int L, bool GDN>
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
@@ -135,7 +138,6 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
     const int j = lane & 31, h = lane >> 5;
     // DMA roles: waves 0-3 stream the weight slabs, waves 4-7 the activation patch.  vmcnt is per wave and retires in
     // order, so the roles are what keeps a long-latency patch load (HBM) from gating the wait for the next weight slab (L2).
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int gpk = a.NPIXp >> 5;                             // DMA wave-instructions per 16-channel plane of the patch (2*NPIXp/64)
     const int plane_bytes = a.Hi * a.Wi * 32;                 // bytes per 16-channel plane of the input
     int SPC;                                                  // steps per chunk
-    int bl[2];                                                // lane part of the B-fragment address
+    int bl;                                                   // lane part of the B-fragment address
     int goff[NPI];                                            // patch waves: byte offset of this lane's record in a chunk
 
     // Buffer resources: out-of-range offsets read as zero, so padding pixels (voffset = huge), chunks past the last one and
@@ -201,11 +203,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         }
         const int PWe = g.is == 2 ? a.PWh : a.PW;             // row pitch (records) of the LDS patch image
         const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int r = (wn * 2 + n) * a.SR + jr;
-            bl[n] = (h * a.NPIXp + (r * g.is) * PWe + jc) * 16;
-        }
+        bl = (h * a.NPIXp + ((wave * a.SR + jr) * g.is) * PWe + jc) * 16;
         // tap table: byte offset of each tap's record inside the LDS patch image (padding taps alias tap 0; their weights are zero)
         if (tid < MAXTAPS) {
             const int tap = tid < g.ntaps ? tid : 0;
@@ -217,18 +215,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     }
     const int ninstr = KS * gpk;
     const int wvoff = wq * 1024 + lane * 16;                  // weight waves: this lane's record inside a 4 KiB slab
-    const int al = (h * 128 + wm * 64 + j) * 16;              // lane part of the A-fragment address
+    const int al = (h * 128 + j) * 16;                        // lane part of the A-fragment address
     int pdst[NPI];                                            // patch waves: LDS offset inside a patch buffer (or the sink)
 #pragma unroll
     for (int k = 0; k < NPI; ++k) pdst[k] = (k * 4 + wq) < ninstr ? (k * 4 + wq) * 1024 : -1;
 
-    f32x16 acc[2][2];
+    // wave w owns all 128 output channels of pixel sub-tile w (4 accumulator tiles): the GDN epilogue needs every channel
+    // of a pixel, and this way it finds them in the wave's own registers
+    f32x16 acc[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
 
     // ---- prologue: weight slab groups of the first D steps, the first L patch chunks
     int wsoff = 0;                                            // weight producer: byte offset of the next slab group in the stream
@@ -282,18 +280,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         for (int tt = 0; tt < T; ++tt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 af[2], bfr[2];
+                bf16x8 af[4];
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl + tv[tt] + (cb + ks * gpk * 1024))));
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    bfr[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl[n] + tv[tt] + (cb + ks * gpk * 1024))));
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 4; ++m)
                     af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m], 0, 0, 0);
             }
         }
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
@@ -319,46 +312,119 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int m0 = blockIdx.y * 128;
     const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
     const size_t oplane = (size_t)a.Ho * a.Wo;
+    const int r = r0 + wave * a.SR + jr, c = c0 + jc;
+    const bool pok = r < g.Hp && c < g.Wp;
+    const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+    const size_t opix = (size_t)oh * a.Wo + ow;
+    float gv = 1.0f;
+    if (!GDN && a.y32 != nullptr && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+    // bias, then (inverse) GDN or the activation.  Cout is a multiple of 32, so a 32-channel block is valid or not as a whole.
+    if (a.bias != nullptr) {
+        const float* bp = a.bias + m0 + 4 * h;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int r = r0 + (wn * 2 + n) * a.SR + jr, c = c0 + jc;
-        const bool pok = r < g.Hp && c < g.Wp;
-        const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
-        const size_t opix = (size_t)oh * a.Wo + ow;
-        float gv = 1.0f;
-        if (OUT == 0 && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+        for (int m = 0; m < 4; ++m) {
+            if (m0 + m * 32 < a.Cout) {
+                float bv[16];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int cow = m0 + wm * 64 + m * 32 + 4 * h;
-            float bv[16];
+                for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = cow + (e & 3) + 8 * (e >> 2);
-                bv[e] = a.bias != nullptr ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
+                for (int e = 0; e < 16; ++e) acc[m][e] += bv[e];
             }
-            if (OUT == 0) {
+        }
+    }
+    if (!GDN) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = cow + (e & 3) + 8 * (e >> 2);
-                    const float v = apply_act(acc[m][n][e] + bv[e], a.act) * gv;
-                    if (pok && co < a.Cout) a.y32[((size_t)b * a.out_ctot + a.out_coff + co) * oplane + opix] = v;
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] = apply_act(acc[m][e], a.act) * gv;
+    }
+    if (GDN) {
+        // y_i = x_i * rsqrt(beta^_i + sum_j gamma^_ij x_j^2)  (inverse: * sqrt), gdn.py:77-92.  The 128 x 128 contraction runs
+        // on the matrix cores with gamma^ and x^2 each split into bf16 hi + lo (three products: error ~2^-16 of a term).
+        // k-step s covers channels 32(s>>1) + 16(s&1) + 8(c>>2) + 4hh + (c&3), c = 0..7 -- exactly the 8 accumulator
+        // registers acc[s>>1][8(s&1) + c] this lane already holds for its pixel, so the B operand needs no data movement;
+        // the gamma^ fragments come pre-arranged in that order (gdn_pack_f16k_kernel) straight from L2.
+        // The 64 KiB fragment image is shared by the 8 waves through LDS (the weight ring is free now): one DMA, one barrier.
+        static_assert(NWS * WST == 65536, "the gamma image takes the place of the weight ring");
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
+        const float* bet = reinterpret_cast<const float*>(a.gdn_img + 4 * 8 * 2 * 64);
+        float bt[4][16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bt[m][e] = bet[m * 32 + 4 * h + (e & 3) + 8 * (e >> 2)];
+        f32x16 nrm[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) nrm[m][e] = 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* gimg = lds + lane * 16;
+#pragma unroll
+        for (int sx = 0; sx < 8; ++sx) {
+            bf16x8 bh, blo;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const float xv = acc[sx >> 1][8 * (sx & 1) + cc];
+                const float sq = __fmul_rn(xv, xv);
+                const __bf16 hi = (__bf16)sq;
+                bh[cc] = hi;
+                blo[cc] = (__bf16)(sq - (float)hi);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x8 gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 0) * 1024));
+                const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 1) * 1024));
+                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, bh, nrm[m], 0, 0, 0);
+                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, blo, nrm[m], 0, 0, 0);
+                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, bh, nrm[m], 0, 0, 0);
+            }
+        }
+        // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway
+        if (a.gdn_inverse) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_sqrtf(nrm[m][e] + bt[m][e]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_rsqf(nrm[m][e] + bt[m][e]);
+        }
+    }
+    // stores: one 64-bit base per lane, 32-bit channel offsets
+    if (pok) {
+        if (a.y32 != nullptr) {
+            float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * oplane + opix;
+            const unsigned op = (unsigned)oplane;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[m][e];
                 }
-            } else {
+        } else {
+            // record of channels cg .. cg+3, cg = out_coff + m0 + 32m + 8q + 4h: 16-channel block cg >> 4, offset cg & 15
+            const int cg0 = a.out_coff + m0 + 4 * h;
+            unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + (cg0 >> 4)) * oplane + opix) * 16 + (cg0 & 15);
+            const unsigned op16 = (unsigned)oplane * 16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = cow + 8 * q;                              // 4 consecutive channels co .. co+3
-                    float v[4];
+            for (int m = 0; m < 4; ++m)
+                if (m0 + m * 32 < a.Cout) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = apply_act(acc[m][n][4 * q + i] + bv[4 * q + i], a.act);
-                    uint2 st;
-                    st.x = pack2bf(v[0], v[1]);
-                    st.y = pack2bf(v[2], v[3]);
-                    if (pok && co < a.Cout) {
-                        const int cg = a.out_coff + co;
-                        *reinterpret_cast<uint2*>(a.y16 + (((size_t)b * (a.out_ctot >> 4) + (cg >> 4)) * oplane + opix) * 16 + (cg & 15)) = st;
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 st;
+                        st.x = pack2bf(acc[m][4 * q], acc[m][4 * q + 1]);
+                        st.y = pack2bf(acc[m][4 * q + 2], acc[m][4 * q + 3]);
+                        // + 8q channels: (cg0 & 15) + 8q may cross into the next 16-channel block
+                        const int cq = (cg0 & 15) + m * 32 + 8 * q;
+                        *reinterpret_cast<uint2*>(yb + (unsigned)(cq >> 4) * op16 + ((cq & 15) - (cg0 & 15))) = st;
                     }
                 }
-            }
         }
     }
 }
@@ -376,7 +442,7 @@ constexpr int F16K_D = 3;
 
 F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     F16kCfg c{};
-    if (d.Cout < 64 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    if (d.Cout < 64 || d.Cout % 32 != 0 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
     int span_h = 0, span_w = 0, min_taps = 1 << 30, max_taps = 0;
     for (int p = 0; p < nphase; ++p) {
         span_h = span_h > g[p].nth ? span_h : g[p].nth;
@@ -429,7 +495,7 @@ extern "C" int masic_conv_f16k_supported(const masic_conv_desc_t* d) {
     return choose_f16k(*d, g, np).ok;
 }
 
-extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_out, char* buf, size_t n) {
+extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, char* buf, size_t n) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     MASIC_REQUIRE(buf && n > 0, MASIC_ERR_ARG, "conv_f16k_kernel_name: null buffer");
@@ -437,8 +503,8 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int f16k_
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
-    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %d>", F16K_D, f16k_out ? 1 : 0);
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %d>", F16K_D, f16k_out ? 1 : 0);
+    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s>", F16K_D, gdn ? "true" : "false");
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s>", F16K_D, gdn ? "true" : "false");
     return MASIC_OK;
 }
 
@@ -468,8 +534,18 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
     return masic_launch_status("conv_f16k_pack_weight");
 }
 
+extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                                       const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
+                                       const masic_conv_desc_t* d, void* stream);
+
 extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                                    float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream) {
+    return masic_conv_f16k_gdn_fwd(x_f16k, w_packed, bias, gate, nullptr, 0, y_nchw, y_f16k, d, stream);
+}
+
+extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                                       const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
+                                       const masic_conv_desc_t* d, void* stream) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     MASIC_REQUIRE(x_f16k && w_packed && ((y_nchw != nullptr) != (y_f16k != nullptr)), MASIC_ERR_ARG,
@@ -481,10 +557,12 @@ extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, con
     MASIC_REQUIRE(d->in_ctot % 16 == 0 && d->in_coff % 16 == 0, MASIC_ERR_SHAPE, "conv_f16k: input channel view must be 16-aligned");
     MASIC_REQUIRE(y_f16k == nullptr || (d->out_ctot % 16 == 0 && d->out_coff % 16 == 0 && d->Cout % 4 == 0 && gate == nullptr),
                   MASIC_ERR_SHAPE, "conv_f16k: F16K output needs a 16-aligned channel view, Cout % 4 == 0 and no gate");
+    MASIC_REQUIRE(gdn_packed == nullptr || (d->Cout == 128 && d->act == MASIC_ACT_NONE && gate == nullptr), MASIC_ERR_UNSUPPORTED,
+                  "conv_f16k: the fused GDN needs Cout = 128, no activation and no gate");
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               d->in_ctot / 16, d->in_coff / 16, c.Cin16,
+               (const uint4*)gdn_packed, gdn_inverse, d->in_ctot / 16, d->in_coff / 16, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
@@ -493,9 +571,9 @@ extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, con
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
-#define F16K_LAUNCH(KSV, TV, PSPV, LV, OUTV)                                                                         \
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV)                                                                         \
     do {                                                                                                             \
-        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, OUTV>;                                                       \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV>;                                                       \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -504,11 +582,11 @@ extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, con
         hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
     } while (0)
     if (c.KS == 1) {
-        if (y_nchw) F16K_LAUNCH(1, 4, 6, 1, 0);
-        else F16K_LAUNCH(1, 4, 6, 1, 1);
+        if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true);
+        else F16K_LAUNCH(1, 4, 6, 1, false);
     } else {
-        if (y_nchw) F16K_LAUNCH(2, 2, 3, 2, 0);
-        else F16K_LAUNCH(2, 2, 3, 2, 1);
+        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true);
+        else F16K_LAUNCH(2, 2, 3, 2, false);
     }
 #undef F16K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");

@@ -211,6 +211,33 @@ __global__ __launch_bounds__(256, 2) void gdn_bf16x3_c128(const float* __restric
     }
 }
 
+// gamma^ (bf16 hi, lo) in MFMA A-fragment order and beta^ for the GDN epilogue of conv_f16k.hip:
+//   img[((m*8 + s)*2 + hl)*64 + lane] = 8 bf16: gamma^[32m + (lane & 31)][chan(s, lane >> 5, c)], c = 0..7;  then beta^[128] floats
+__global__ void gdn_pack_f16k_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, uint4* __restrict__ img,
+                                     float beta_bound, float gamma_bound, float pedestal) {
+    constexpr int C = 128;
+    auto chan = [](int s, int hh, int c) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (c >> 2) + 4 * hh + (c & 3); };
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 32 * 64) {
+        const int ms = idx >> 6, l = idx & 63;
+        const int m = ms >> 3, s = ms & 7, r = l & 31, hh = l >> 5;
+        gbf16x8 ph, pl;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float gr = fmaxf(gamma[(size_t)(32 * m + r) * C + chan(s, hh, c)], gamma_bound);
+            __bf16 hi, lo;
+            split_bf16(__fsub_rn(__fmul_rn(gr, gr), pedestal), hi, lo);
+            ph[c] = hi; pl[c] = lo;
+        }
+        img[(ms * 2 + 0) * 64 + l] = __builtin_bit_cast(uint4, ph);
+        img[(ms * 2 + 1) * 64 + l] = __builtin_bit_cast(uint4, pl);
+    }
+    if (idx < C) {
+        const float bv = fmaxf(beta[idx], beta_bound);
+        reinterpret_cast<float*>(img + 4 * 8 * 2 * 64)[idx] = __fsub_rn(__fmul_rn(bv, bv), pedestal);
+    }
+}
+
 // generic: 64 threads per block, one pixel per thread, x^2 column in LDS
 __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, const float* __restrict__ beta,
                                                   const float* __restrict__ gamma, float* __restrict__ y,
@@ -298,4 +325,15 @@ extern "C" int masic_gdn_fwd_f16k(const float* x, const float* beta, const float
                        (unsigned short*)y_f16k, HW, spi, nstrips, inverse, (float)__builtin_sqrt(beta_min + ped),
                        (float)__builtin_sqrt(ped), (float)ped);
     return masic_launch_status("gdn_fwd_f16k");
+}
+
+// Parameters of a 128-channel GDN re-laid out for the fused epilogue of masic_conv_f16k_gdn_fwd: 65536 + 512 bytes.
+extern "C" size_t masic_gdn_f16k_packed_bytes(void) { return 65536 + 512; }
+extern "C" int masic_gdn_pack_f16k(const float* beta, const float* gamma, void* packed, int C, double beta_min, void* stream) {
+    MASIC_REQUIRE(beta && gamma && packed, MASIC_ERR_ARG, "gdn_pack_f16k: null pointer");
+    MASIC_REQUIRE(C == 128, MASIC_ERR_UNSUPPORTED, "gdn_pack_f16k: needs C = 128");
+    const double ped = 0x1p-36;
+    hipLaunchKernelGGL(gdn_pack_f16k_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, beta, gamma, (uint4*)packed,
+                       (float)__builtin_sqrt(beta_min + ped), (float)__builtin_sqrt(ped), (float)ped);
+    return masic_launch_status("gdn_pack_f16k");
 }

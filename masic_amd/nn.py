@@ -34,6 +34,16 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def packed_gdn_f16k(gdn):
+    """Fragment-order parameters of a GDN module for conv_f16k's fused epilogue, cached per parameter version."""
+    key = (gdn.beta._version, gdn.gamma._version, gdn.beta.data_ptr(), gdn.gamma.data_ptr())
+    cache = gdn.__dict__.get("_packed_f16k_cache")
+    if cache is None or cache[0] != key:
+        cache = (key, ops.pack_gdn_f16k(gdn.beta.detach(), gdn.gamma.detach().contiguous(), gdn.beta_min))
+        gdn.__dict__["_packed_f16k_cache"] = cache
+    return cache[1]
+
+
 class _PackedWeightMixin:
     transposed_conv = False
     masked_conv = False
@@ -97,9 +107,10 @@ class _PackedWeightMixin:
             self.__dict__["_packed_f16k_cache"] = cache
         return cache[1]
 
-    def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0):
+    def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0, gdn=None):
         """Inference-only: y = act(conv(x) + bias) on an F16K input buffer. Returns (y, Ho, Wo) with y an F16K buffer of
-        ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate)."""
+        ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate).
+        `gdn`: a 128-channel compressai GDN module applied to the result inside the kernel's epilogue."""
         if out is not None:
             desc = self._desc_f16k(B, Hi, Wi, out_ctot=out.shape[1], out_coff=out_coff, act=act,
                                    gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
@@ -108,7 +119,8 @@ class _PackedWeightMixin:
         else:
             desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 15) // 16 * 16, act=act)
         bias = None if self.bias is None else self.bias.detach()
-        y = ops.conv2d_f16k(x16, self.packed_f16k_weight(desc), bias, desc, out_nchw=out, want_nchw=want_nchw, gate=gate)
+        y = ops.conv2d_f16k(x16, self.packed_f16k_weight(desc), bias, desc, out_nchw=out, want_nchw=want_nchw, gate=gate,
+                            gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
         return y, desc.Ho, desc.Wo
 
     def invalidate_packed_weight(self):

@@ -530,7 +530,15 @@ def pack_conv_f16k_weight(weight, desc):
     return packed
 
 
-def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=None):
+def pack_gdn_f16k(beta, gamma, beta_min=1e-6):
+    """A 128-channel GDN's stored parameters in the fragment order of conv_f16k's fused epilogue."""
+    _dev(beta, "beta"); _dev(gamma, "gamma")
+    packed = torch.empty(lib.masic_gdn_f16k_packed_bytes() // 2, dtype=torch.int16, device=beta.device)
+    check(lib.masic_gdn_pack_f16k(_p(beta), _p(gamma), _p(packed), beta.numel(), float(beta_min), _stream()), "gdn_pack_f16k")
+    return packed
+
+
+def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=None, gdn=None):
     """Conv on an F16K input [B][in_ctot/16][Hi*Wi][16]; returns float32 NCHW (want_nchw / out_nchw) or an F16K buffer of
     desc.out_ctot channels (a fresh one holds exactly ceil16(Cout) channels)."""
     if x16.dtype != torch.int16 or not x16.is_cuda:
@@ -552,12 +560,14 @@ def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=No
     timed = None
     if _timer is not None:
         buf = ctypes.create_string_buffer(96)
-        lib.masic_conv_f16k_kernel_name(ctypes.byref(desc), int(y16 is not None), buf, 96)
+        lib.masic_conv_f16k_kernel_name(ctypes.byref(desc), int(gdn is not None), buf, 96)
         variant = buf.value.decode()
         if _timer.only is None or variant == _timer.only:
             timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             timed[1].record()
-    check(lib.masic_conv_f16k_fwd(_p(x16), _p(packed), _p(bias), _p(gate), _p(y32), _p(y16), ctypes.byref(desc), _stream()), "conv_f16k_fwd")
+    gp, ginv = (None, 0) if gdn is None else (gdn[0], int(gdn[1]))       # gdn = (pack_gdn_f16k(...), inverse)
+    check(lib.masic_conv_f16k_gdn_fwd(_p(x16), _p(packed), _p(bias), _p(gate), _p(gp), ginv, _p(y32), _p(y16), ctypes.byref(desc), _stream()),
+          "conv_f16k_fwd")
     if timed is not None:
         timed[2].record()
         flops, nbytes = conv_algorithmic_work(desc)

@@ -44,6 +44,36 @@ def run(name, B, Cin, H, W, Cout, k, s, transposed=False, masked=False, act=ops.
             msg += f" | {tag} {dt * 1e6:7.1f} us {flops / dt / 1e12:6.1f} TF"
     print(msg, flush=True)
 
+def run_gdn(name, B, Cin, H, W, k, s, transposed=False, inverse=False, reps=0):
+    Cout, pad = 128, k // 2
+    x = torch.randn(B, Cin, H, W, device=dev)
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = torch.randn(wshape, device=dev) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, device=dev)
+    beta = torch.rand(Cout, device=dev) + 0.5
+    gamma = (torch.rand(Cout, Cout, device=dev) * 0.2).contiguous()
+    d1 = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, pad, transposed=transposed, in_ctot=Cin, prec=_lib.PREC_BF16)
+    d2 = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, pad, transposed=transposed, in_ctot=Cin, out_ctot=Cout, prec=_lib.PREC_BF16)
+    x16 = ops.nchw_to_f16k(x)
+    wp = ops.pack_conv_f16k_weight(w, d1)
+    gp = ops.pack_gdn_f16k(beta, gamma)
+    t = ops.conv2d_f16k(x16, wp, bias, d1, want_nchw=True)
+    ref = ops.gdn(t, beta, gamma, inverse=inverse)                       # exact float32 GDN kernel
+    y = ops.conv2d_f16k(x16, wp, bias, d1, want_nchw=True, gdn=(gp, inverse))
+    y16 = ops.conv2d_f16k(x16, wp, bias, d2, gdn=(gp, inverse))
+    torch.cuda.synchronize()
+    yb = ops.f16k_to_nchw(y16, B, Cout, d2.Ho, d2.Wo)
+    scale = ref.abs().max().item()
+    msg = f"{name:28s} fused-gdn nchw err {(y - ref).abs().max().item() / scale:.2e}  f16k err {(yb - ref).abs().max().item() / scale:.2e}"
+    if reps:
+        for tag, fn in (("conv->nchw + gdn_f16k", lambda: ops.gdn_f16k(ops.conv2d_f16k(x16, wp, bias, d1, want_nchw=True), beta, gamma, inverse=inverse)),
+                        ("fused", lambda: ops.conv2d_f16k(x16, wp, bias, d2, gdn=(gp, inverse)))):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps): fn()
+            torch.cuda.synchronize(); msg += f" | {tag} {(time.perf_counter() - t0) / reps * 1e6:7.1f} us"
+    print(msg, flush=True)
+
 big = len(sys.argv) > 1 and sys.argv[1] == "big"
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":      # timing only (results of ablated builds are garbage)
     run("B  conv5s2 128->128 256^2", 8, 128, 256, 256, 128, 5, 2, reps=10)
@@ -56,7 +86,11 @@ run("deconv5s2 192->128 9x13", 1, 192, 9, 13, 128, 5, 2, transposed=True, act=op
 run("conv3s1 192->128 32x32", 2, 192, 32, 32, 128, 3, 1)
 run("masked5 192->384 32x32", 1, 192, 32, 32, 384, 5, 1, masked=True)
 run("conv3s1 288->384 16x16", 1, 288, 16, 16, 384, 3, 1)
+run_gdn("gdn conv5s2 64x64", 2, 128, 64, 64, 5, 2)
+run_gdn("igdn deconv 192 24x40", 1, 192, 24, 40, 5, 2, transposed=True, inverse=True)
 if big:
+    run_gdn("B  conv+gdn 256^2", 8, 128, 256, 256, 5, 2, reps=10)
+    run_gdn("B' deconv+igdn 128^2", 8, 128, 128, 128, 5, 2, transposed=True, inverse=True, reps=10)
     run("B  conv5s2 128->128 256^2", 8, 128, 256, 256, 128, 5, 2, reps=10)
     run("C  conv5s2 128->128 128^2", 8, 128, 128, 128, 128, 5, 2, reps=10)
     run("D  conv5s2 128->192 64^2", 8, 128, 64, 64, 192, 5, 2, reps=10)
