@@ -299,3 +299,85 @@ def test_gemm1x1_bf16_stack_f16k(B, Cin, Cmid, Cout, H, W, tr):
     t = ops.gemm1x1_bf16(xf, p0, b0.to(DEV), B, Cin, Cmid, H, W, ops.ACT_LEAKY)
     y = ops.gemm1x1_bf16(t, p1, b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, want_nchw=True)
     assert_close(y, ref, "gemm1x1 bf16 stack", rtol=1e-3)     # an intermediate that re-rounds to the neighbouring bf16 value moves the output by ~1e-4
+
+
+F16K_CASES = [c for c in CONV_CASES if c[2] % 16 == 0 and c[5] >= 64 and c[5] % 32 == 0 and c[6] > 1 and c[10] == 0] + [
+    ("ctx_masked_f16k", 2, 192, 16, 24, 384, 5, 1, False, True, 0, 0),
+    ("g_a_conv2_big",   1, 128, 136, 200, 128, 5, 2, False, False, 0, 0),     # several tiles, ragged right / bottom edges
+    ("g_s_conv3_big",   1, 128, 40, 72, 128, 5, 2, True, False, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", F16K_CASES, ids=[c[0] for c in F16K_CASES])
+def test_conv_f16k(case):
+    """Convolutions on F16K (channel-blocked bf16) activations, both operands DMA-staged (conv_f16k.hip): float32 NCHW
+    output against the float32 oracle on bf16-rounded operands (only the accumulation order differs), F16K output against
+    the same rounded to bf16; ragged tiles, transposed phases and the masked conv included."""
+    ops = _ops()
+    from masic_amd._lib import PREC_BF16
+    name, B, Cin, H, W, Cout, k, s, tr, masked, in_op, act = case
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w = _rand(*wshape, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    ref = _oracle_conv(x.bfloat16().float(), w.bfloat16().float(), b, k, s, tr, masked, 0, act)
+    d = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, k // 2, transposed=tr, masked=masked, act=act, prec=PREC_BF16)
+    assert ops.conv_f16k_supported(d), "layer shapes of the codec must have an F16K configuration"
+    x16 = ops.nchw_to_f16k(x.to(DEV))
+    wp = ops.pack_conv_f16k_weight(w.to(DEV), d)
+    y = ops.conv2d_f16k(x16, wp, b.to(DEV), d, want_nchw=True)
+    assert_close(y, ref, name + ":f16k -> nchw", rtol=2e-5)
+    y16 = ops.conv2d_f16k(x16, wp, b.to(DEV), d)
+    yb = ops.f16k_to_nchw(y16, B, Cout, d.Ho, d.Wo)
+    assert_close(yb, ref, name + ":f16k -> f16k", rtol=2.0 ** -8)      # bf16 rounding of the output
+
+
+def test_conv_f16k_views_gate_and_unsupported():
+    """Channel views on both sides (a slice of a wider F16K buffer in, a slice of a concat buffer out, gated), and the
+    shapes the path declines (the caller falls back to the NCHW kernels)."""
+    ops = _ops()
+    from masic_amd._lib import PREC_BF16
+    B, H, W, k = 2, 16, 24, 3
+    xall = _rand(B, 224, H, W, seed=4)
+    w = _rand(384, 192, k, k, seed=5, scale=0.05)
+    b = _rand(384, seed=6, scale=0.1)
+    gates = torch.rand(B, 3, H, W)
+    ref = F.conv2d(xall[:, 32:].bfloat16().float(), w.bfloat16().float(), b, padding=1) * gates[:, 1:2]
+    d = ops.make_conv_desc(B, 192, H, W, 384, k, k, 1, 1, in_ctot=224, in_coff=32, out_ctot=768, out_coff=128, gate_ctot=3, gate_c=1,
+                           prec=PREC_BF16)
+    out = torch.full((B, 768, H, W), 7.0, device=DEV)
+    ops.conv2d_f16k(ops.nchw_to_f16k(xall.to(DEV)), ops.pack_conv_f16k_weight(w.to(DEV), d), b.to(DEV), d, out_nchw=out, gate=gates.to(DEV))
+    assert_close(out[:, 128:512], ref, "f16k views+gate", rtol=2e-5)
+    assert torch.all(out[:, :128] == 7.0) and torch.all(out[:, 512:] == 7.0)
+    for cin, cout, kk, in_op in ((3, 128, 5, 0), (128, 3, 5, 0), (768, 960, 1, 0), (192, 128, 5, 1), (20, 72, 5, 0)):
+        dd = ops.make_conv_desc(1, cin, 16, 16, cout, kk, kk, 1, kk // 2, in_op=in_op, prec=PREC_BF16)
+        assert not ops.conv_f16k_supported(dd)
+
+
+@pytest.mark.parametrize("Cin,H,W,tr,inverse", [(128, 48, 64, False, False), (192, 8, 12, True, True), (128, 24, 40, True, True)])
+def test_conv_f16k_fused_gdn(Cin, H, W, tr, inverse):
+    """(Inverse) GDN in the epilogue of the 128-channel convolutions: against oracle GDN of the oracle convolution
+    (bf16-rounded conv operands; the GDN contraction itself is a bf16 hi/lo split product, ~1e-5)."""
+    ops = _ops()
+    from masic_amd import synth
+    from masic_amd._lib import PREC_BF16
+    B, C, k, s = 2, 128, 5, 2
+    rs = np.random.RandomState(H)
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    w = _rand(*((Cin, C, k, k) if tr else (C, Cin, k, k)), seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(C, seed=3, scale=0.1)
+    beta = synth.synth_tensor("g.beta", (C,), rs)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs)
+    ref = O.gdn(_oracle_conv(x.bfloat16().float(), w.bfloat16().float(), b, k, s, tr, False, 0, 0), beta, gamma, inverse=inverse)
+    d = ops.make_conv_desc(B, Cin, H, W, C, k, k, s, 2, transposed=tr, prec=PREC_BF16)
+    x16 = ops.nchw_to_f16k(x.to(DEV))
+    wp = ops.pack_conv_f16k_weight(w.to(DEV), d)
+    gp = ops.pack_gdn_f16k(beta.to(DEV), gamma.to(DEV))
+    y = ops.conv2d_f16k(x16, wp, b.to(DEV), d, want_nchw=True, gdn=(gp, inverse))
+    assert_close(y, ref, "conv+gdn fused, nchw out", rtol=5e-5)
+    yb = ops.f16k_to_nchw(ops.conv2d_f16k(x16, wp, b.to(DEV), d, gdn=(gp, inverse)), B, C, d.Ho, d.Wo)
+    assert_close(yb, ref, "conv+gdn fused, f16k out", rtol=2.0 ** -8)
+    # the standalone F16K-output GDN kernel (first layer of the chains)
+    t = _rand(B, C, H, W, seed=9, scale=3.0)
+    g16 = ops.gdn_f16k(t.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse)
+    assert_close(ops.f16k_to_nchw(g16, B, C, H, W), O.gdn(t, beta, gamma, inverse=inverse), "gdn -> f16k", rtol=2.0 ** -8)
