@@ -110,21 +110,28 @@ def _gdn_f16k(gdn, x):
     return _hip.gdn_f16k(x, gdn.beta.detach(), gdn.gamma.detach(), inverse=gdn.inverse, beta_min=gdn.beta_min)
 
 
-def _analysis_f16k(convs, gdns, t):
-    """GDN -> conv+GDN -> conv+GDN -> conv of an analysis transform (`t`: float32 NCHW output of its first convolution):
-    the 128-channel activations stay in F16K bf16 and the second and third GDN run in the epilogue of the convolution
-    that feeds them (conv_f16k.hip). None if a shape has no F16K configuration (the caller then takes the NCHW path)."""
-    B, C, H, W = t.shape
-    sizes = [(H, W)]
-    for cv in convs:
-        if C != 128 or (sizes[-1][0] * sizes[-1][1]) % 32 != 0 or not cv.f16k_supported(B, *sizes[-1]):
+def _analysis_f16k(convs, gdns, x):
+    """conv+GDN x3 -> conv of an analysis transform on the float32 NCHW image `x` with bf16 operands: every GDN runs in
+    the epilogue of the convolution that feeds it and the 128-channel activations stay in F16K bf16 in between
+    (conv_f16k.hip). None if a shape has no such configuration (the caller then takes the NCHW path)."""
+    from masic_amd import nn as _mnn
+    B, C, H, W = x.shape
+    c1 = convs[0]
+    if (C, c1.out_channels, tuple(c1.kernel_size), tuple(c1.stride), tuple(c1.padding)) != (3, 128, (5, 5), (2, 2), (2, 2)):
+        return None
+    sizes = [((H - 1) // 2 + 1, (W - 1) // 2 + 1)]
+    for cv in convs[1:]:
+        if not cv.f16k_supported(B, *sizes[-1]):
             return None
         d = cv._desc_f16k(B, *sizes[-1])
         sizes.append((d.Ho, d.Wo))
-    t16 = _gdn_f16k(gdns[0], t)
-    t16, _, _ = convs[0].run_f16k(t16, B, *sizes[0], gdn=gdns[1])
-    t16, _, _ = convs[1].run_f16k(t16, B, *sizes[1], gdn=gdns[2])
-    return convs[2].run_f16k(t16, B, *sizes[2], want_nchw=True)[0]
+    if convs[1].out_channels != 128 or convs[2].out_channels != 128:
+        return None
+    t16, _, _ = _hip.conv_a_gdn_f16k(x, c1.packed_first_layer_weight(), None if c1.bias is None else c1.bias.detach(),
+                                     (_mnn.packed_gdn_f16k(gdns[0]), gdns[0].inverse))
+    t16, _, _ = convs[1].run_f16k(t16, B, *sizes[0], gdn=gdns[1])
+    t16, _, _ = convs[2].run_f16k(t16, B, *sizes[1], gdn=gdns[2])
+    return convs[3].run_f16k(t16, B, *sizes[2], want_nchw=True)[0]
 
 
 # ------------------------------------------------------------------------------------------ sub-networks
@@ -279,8 +286,8 @@ class Encoder1(nn.Module):
     def latent(self, x):
         """forward(x)[0]; with bf16 operands and no autograd the intermediate activations stay in F16K."""
         if _bf16_inference(x, self.g_a_conv1.weight):
-            y = _analysis_f16k((self.g_a_conv2, self.g_a_conv3, self.g_a_conv4), (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3),
-                               self.g_a_conv1(x))
+            y = _analysis_f16k((self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
+                               (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), x.contiguous())
             if y is not None:
                 return y
         return self.forward(x)[0]
@@ -335,8 +342,8 @@ class Encoder2(nn.Module):
     def forward_pair(self, pair):
         t = self.pre_gdn(self.pre_conv(pair))
         if _bf16_inference(pair, self.g_a_conv1.weight):
-            y = _analysis_f16k((self.g_a_conv2, self.g_a_conv3, self.g_a_conv4), (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3),
-                               self.g_a_conv1(t))
+            y = _analysis_f16k((self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
+                               (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), t)
             if y is not None:
                 return y
         t = self.g_a_gdn1(self.g_a_conv1(t))

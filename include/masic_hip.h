@@ -124,6 +124,13 @@ int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const floa
                             const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
                             const masic_conv_desc_t* d, void* stream);
 
+/* First analysis layer g_a_conv1 + g_a_gdn1 (MASIC.py:515-516, :563-564) in one kernel: Conv2d(3 -> 128, k5, s2, p2) on
+ * channels in_coff..in_coff+2 of a float32 NCHW tensor, GDN, result in F16K [B][8][Ho*Wo][16]. */
+size_t masic_conv_a_packed_bytes(void);
+int masic_conv_a_pack_weight(const float* w, void* w_packed, void* stream);
+int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                         void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GDN / inverse GDN: compressai/layers/gdn.py:77-92 with the NonNegativeParametrizer of
  * compressai/ops/parametrizers.py:47-64 applied to the *stored* beta[C], gamma[C,C] inside the

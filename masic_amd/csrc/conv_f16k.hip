@@ -121,6 +121,53 @@ __device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned cha
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
+// (Inverse) GDN over the 128 channels a wave holds for its 32 pixels (accumulator layout of four 32x32 MFMA tiles):
+//   y_i = x_i * rsqrt(beta^_i + sum_j gamma^_ij x_j^2)  (inverse: * sqrt), compressai/layers/gdn.py:77-92.
+// The 128 x 128 contraction runs on the matrix cores with gamma^ and x^2 each split into bf16 hi + lo (three products:
+// error ~2^-16 of a term).  k-step s covers channels 32(s>>1) + 16(s&1) + 8(c>>2) + 4hh + (c&3), c = 0..7 -- exactly the
+// 8 accumulator registers acc[s>>1][8(s&1) + c] the lane already holds for its pixel, so the B operand needs no data
+// movement; the gamma^ fragments lie in LDS pre-arranged in that order (gdn.hip: gdn_pack_f16k_kernel).
+// gimg: LDS address of the fragment image + lane * 16;  bt: beta^ of the lane's channels.
+__device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigned char* gimg, const float (&bt)[4][16], int inverse) {
+    f32x16 nrm[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) nrm[m][e] = 0.0f;
+#pragma unroll
+    for (int sx = 0; sx < 8; ++sx) {
+        bf16x8 bh, blo;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const float xv = acc[sx >> 1][8 * (sx & 1) + cc];
+            const float sq = __fmul_rn(xv, xv);
+            const __bf16 hi = (__bf16)sq;
+            bh[cc] = hi;
+            blo[cc] = (__bf16)(sq - (float)hi);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const bf16x8 gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 0) * 1024));
+            const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 1) * 1024));
+            nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, bh, nrm[m], 0, 0, 0);
+            nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, blo, nrm[m], 0, 0, 0);
+            nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, bh, nrm[m], 0, 0, 0);
+        }
+    }
+    // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway
+    if (inverse) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_sqrtf(nrm[m][e] + bt[m][e]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_rsqf(nrm[m][e] + bt[m][e]);
+    }
+}
+
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
 // patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks); GDN: (inverse) GDN over the 128
 // output channels fused into the epilogue.  Output: float32 NCHW if a.y32 else F16K.
@@ -339,11 +386,6 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             for (int e = 0; e < 16; ++e) acc[m][e] = apply_act(acc[m][e], a.act) * gv;
     }
     if (GDN) {
-        // y_i = x_i * rsqrt(beta^_i + sum_j gamma^_ij x_j^2)  (inverse: * sqrt), gdn.py:77-92.  The 128 x 128 contraction runs
-        // on the matrix cores with gamma^ and x^2 each split into bf16 hi + lo (three products: error ~2^-16 of a term).
-        // k-step s covers channels 32(s>>1) + 16(s&1) + 8(c>>2) + 4hh + (c&3), c = 0..7 -- exactly the 8 accumulator
-        // registers acc[s>>1][8(s&1) + c] this lane already holds for its pixel, so the B operand needs no data movement;
-        // the gamma^ fragments come pre-arranged in that order (gdn_pack_f16k_kernel) straight from L2.
         // The 64 KiB fragment image is shared by the 8 waves through LDS (the weight ring is free now): one DMA, one barrier.
         static_assert(NWS * WST == 65536, "the gamma image takes the place of the weight ring");
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
@@ -355,46 +397,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) bt[m][e] = bet[m * 32 + 4 * h + (e & 3) + 8 * (e >> 2)];
-        f32x16 nrm[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) nrm[m][e] = 0.0f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const unsigned char* gimg = lds + lane * 16;
-#pragma unroll
-        for (int sx = 0; sx < 8; ++sx) {
-            bf16x8 bh, blo;
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-                const float xv = acc[sx >> 1][8 * (sx & 1) + cc];
-                const float sq = __fmul_rn(xv, xv);
-                const __bf16 hi = (__bf16)sq;
-                bh[cc] = hi;
-                blo[cc] = (__bf16)(sq - (float)hi);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const bf16x8 gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 0) * 1024));
-                const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 1) * 1024));
-                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, bh, nrm[m], 0, 0, 0);
-                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, blo, nrm[m], 0, 0, 0);
-                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, bh, nrm[m], 0, 0, 0);
-            }
-        }
-        // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway
-        if (a.gdn_inverse) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_sqrtf(nrm[m][e] + bt[m][e]);
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_rsqf(nrm[m][e] + bt[m][e]);
-        }
+        gdn_in_registers(acc, lds + lane * 16, bt, a.gdn_inverse);
     }
     // stores: one 64-bit base per lane, 32-bit channel offsets
     if (pok) {
@@ -426,6 +431,162 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                     }
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ first analysis layer
+// g_a_conv1 + g_a_gdn1 (MASIC.py:515-516, :563-564): Conv2d(3 -> 128, k5, s2, p2) on the float32 NCHW image followed by
+// GDN, written as F16K for the next convolution.  K = 75 (padded to 80 = 5 MFMA k-steps), so the layer is bound by its
+// output (B x 128 x H/2 x W/2) and by the GDN contraction, not by the convolution: persistent workgroups (8 waves, one
+// 8 x 32 output tile per iteration, wave w = row w) keep the gamma^ image (64 KiB), the weight fragments (20 KiB), bias
+// and beta^ in LDS for all their tiles; the 3 x 19 x 67 input patch of the next tile is fetched into registers while the
+// current one is contracted.  k = tap * 3 + ci; a lane's B fragment is 8 two-byte LDS reads of the bf16 patch.
+struct ConvAArgs {
+    const float* x;               // float32 NCHW [B][in_ctot][Hi][Wi], channels in_coff .. in_coff+2
+    const uint4* wimg;            // [m 4][s 5][lane 64] x 8 bf16: W[32m + (lane & 31)][k = 16s + 8(lane >> 5) + c]
+    const float* bias;            // [128] or null
+    const uint4* gdn_img;         // gdn_pack_f16k_kernel image, then beta^[128]
+    unsigned short* y16;          // F16K [B][8][Ho*Wo][16]
+    int gdn_inverse, Hi, Wi, in_ctot, in_coff, Ho, Wo, tiles_w, tiles_per_img, ntiles;
+};
+
+constexpr int CA_PH = 19, CA_PW = 67, CA_PITCH = 68, CA_NEL = 3 * CA_PH * CA_PW;     // patch of an 8 x 32 tile, stride 2, 5 x 5
+constexpr int CA_PATCH_BYTES = 8192;                                                 // 3 * 19 * 68 * 2 = 7752, padded
+constexpr int CA_NPT = (CA_NEL + 511) / 512;                                          // patch elements per thread
+
+__global__ void pack_conv_a_kernel(const float* __restrict__ w, uint4* __restrict__ wimg) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * 5 * 64) return;
+    const int ms = idx >> 6, l = idx & 63, m = ms / 5, sx = ms - m * 5, r = l & 31, hh = l >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = 16 * sx + 8 * hh + c, tap = k / 3, ci = k - tap * 3;
+        v[c] = (__bf16)(k < 75 ? w[((size_t)(32 * m + r) * 3 + ci) * 25 + tap] : 0.0f);
+    }
+    wimg[idx] = __builtin_bit_cast(uint4, v);
+}
+
+__global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int WIMG = 65536, VEC = WIMG + 20480, PATCH = VEC + 1024;      // LDS map: gamma image | weights | bias, beta^ | 2 patches
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    // ---- once per workgroup: fragment images by DMA, bias / beta^ by plain stores
+    {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, 20480, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (wave * 3 + k < 20) dma_buf16(rw, lds + WIMG + (wave * 3 + k) * 1024, lane * 16, (wave * 3 + k) * 1024);
+        float* vec = reinterpret_cast<float*>(lds + VEC);
+        if (tid < 128) {
+            vec[tid] = a.bias != nullptr ? a.bias[tid] : 0.0f;
+            vec[128 + tid] = reinterpret_cast<const float*>(a.gdn_img + 4 * 8 * 2 * 64)[tid];
+        }
+    }
+    // ---- patch element map of this thread (tile independent): element = tid + 512 i -> (ci, row, col)
+    int prow[CA_NPT], pcol[CA_NPT], pci[CA_NPT];
+#pragma unroll
+    for (int i = 0; i < CA_NPT; ++i) {
+        const int el = tid + 512 * i;
+        const int ci = el / (CA_PH * CA_PW), rem = el - ci * (CA_PH * CA_PW);
+        pci[i] = el < CA_NEL ? ci : -1;
+        prow[i] = rem / CA_PW;
+        pcol[i] = rem - prow[i] * CA_PW;
+    }
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    float pre[CA_NPT];
+    auto fetch = [&](int tile) {           // global -> registers (zero padding outside the image)
+        const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
+        const int ih0 = (t / a.tiles_w) * 16 - 2, iw0 = (t % a.tiles_w) * 64 - 2;
+        const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+#pragma unroll
+        for (int i = 0; i < CA_NPT; ++i) {
+            const int ih = ih0 + prow[i], iw = iw0 + pcol[i];
+            const bool ok = pci[i] >= 0 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+            const float v = xb[ok ? (size_t)pci[i] * plane + (size_t)ih * a.Wi + iw : 0];
+            pre[i] = ok ? v : 0.0f;
+        }
+    };
+    auto stash = [&](int buf) {            // registers -> bf16 LDS patch [ci][row][pitch 68]
+        __bf16* p = reinterpret_cast<__bf16*>(lds + PATCH + buf * CA_PATCH_BYTES);
+#pragma unroll
+        for (int i = 0; i < CA_NPT; ++i)
+            if (pci[i] >= 0) p[(pci[i] * CA_PH + prow[i]) * CA_PITCH + pcol[i]] = (__bf16)pre[i];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) { fetch(tile); stash(0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* gimg = lds + lane * 16;
+    const float* vec = reinterpret_cast<const float*>(lds + VEC);
+    const size_t oplane = (size_t)a.Ho * a.Wo;
+    int buf = 0;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < a.ntiles) fetch(next);                        // in flight during this tile's contraction
+        // ---- convolution: 5 k-steps x 4 channel blocks
+        const __bf16* pl = reinterpret_cast<const __bf16*>(lds + PATCH + buf * CA_PATCH_BYTES) + (2 * wave) * CA_PITCH + 2 * j;
+        f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+        for (int sx = 0; sx < 5; ++sx) {
+            bf16x8 bfr;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                // k = 16 sx + 8 h + c; both halves' offsets are compile-time, the lane picks its own
+                const int k0 = 16 * sx + c, k1 = k0 + 8;
+                const int t0 = k0 / 3, c0 = k0 - 3 * t0, t1 = k1 / 3, c1 = k1 - 3 * t1;
+                const int o0 = k0 < 75 ? (c0 * CA_PH + t0 / 5) * CA_PITCH + t0 % 5 : 0;
+                const int o1 = k1 < 75 ? (c1 * CA_PH + t1 / 5) * CA_PITCH + t1 % 5 : 0;
+                bfr[c] = pl[h ? o1 : o0];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + WIMG + (m * 5 + sx) * 1024 + lane * 16));
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[m], 0, 0, 0);
+            }
+        }
+        // ---- bias, GDN, F16K store
+        float bt[4][16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(vec + m * 32 + 8 * q + 4 * h);
+                const float4 be = *reinterpret_cast<const float4*>(vec + 128 + m * 32 + 8 * q + 4 * h);
+                acc[m][4 * q] += bv.x; acc[m][4 * q + 1] += bv.y; acc[m][4 * q + 2] += bv.z; acc[m][4 * q + 3] += bv.w;
+                bt[m][4 * q] = be.x; bt[m][4 * q + 1] = be.y; bt[m][4 * q + 2] = be.z; bt[m][4 * q + 3] = be.w;
+            }
+        gdn_in_registers(acc, gimg, bt, a.gdn_inverse);
+        {
+            const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
+            const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
+            if (oh < a.Ho && ow < a.Wo) {
+                unsigned short* yb = a.y16 + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 4 * h;
+                const unsigned op16 = (unsigned)oplane * 16;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 st;
+                        st.x = pack2bf(acc[m][4 * q], acc[m][4 * q + 1]);
+                        st.y = pack2bf(acc[m][4 * q + 2], acc[m][4 * q + 3]);
+                        *reinterpret_cast<uint2*>(yb + (unsigned)(2 * m + (q >> 1)) * op16 + 8 * (q & 1)) = st;
+                    }
+            }
+        }
+        if (next < a.ntiles) stash(buf ^ 1);
+        __syncthreads();
     }
 }
 
@@ -590,4 +751,29 @@ extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed,
     }
 #undef F16K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");
+}
+
+// First analysis layer: Conv2d(3 -> 128, k5, s2, p2) + GDN -> F16K (conv_a_gdn_f16k above).  x: float32 NCHW channel view.
+extern "C" size_t masic_conv_a_packed_bytes(void) { return 20480; }
+extern "C" int masic_conv_a_pack_weight(const float* w, void* w_packed, void* stream) {
+    MASIC_REQUIRE(w && w_packed, MASIC_ERR_ARG, "conv_a_pack_weight: null pointer");
+    hipLaunchKernelGGL(pack_conv_a_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, w, (uint4*)w_packed);
+    return masic_launch_status("conv_a_pack_weight");
+}
+extern "C" int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                    void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
+    MASIC_REQUIRE(x && w_packed && gdn_packed && y_f16k, MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer");
+    MASIC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && in_coff >= 0 && in_coff + 3 <= in_ctot, MASIC_ERR_SHAPE, "conv_a_gdn_fwd: bad shape");
+    const int Ho = (Hi + 4 - 5) / 2 + 1, Wo = (Wi + 4 - 5) / 2 + 1;
+    const int tiles_w = ceil_div(Wo, 32), tiles_per_img = tiles_w * ceil_div(Ho, 8), ntiles = tiles_per_img * B;
+    ConvAArgs a{x, (const uint4*)w_packed, bias, (const uint4*)gdn_packed, (unsigned short*)y_f16k, gdn_inverse, Hi, Wi, in_ctot, in_coff,
+                Ho, Wo, tiles_w, tiles_per_img, ntiles};
+    static bool attr_set = false;
+    const size_t lds_bytes = 65536 + 20480 + 1024 + 2 * CA_PATCH_BYTES;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_a_gdn_f16k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_a_gdn_f16k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, (hipStream_t)stream, a);
+    return masic_launch_status("conv_a_gdn_fwd");
 }

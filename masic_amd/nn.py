@@ -107,6 +107,16 @@ class _PackedWeightMixin:
             self.__dict__["_packed_f16k_cache"] = cache
         return cache[1]
 
+    def packed_first_layer_weight(self):
+        """Fragment image of a Conv2d(3, 128, 5, stride 2) weight for the fused conv + GDN kernel of the first analysis layer."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        cache = self.__dict__.get("_packed_conv_a_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.pack_conv_a_weight(w.detach().contiguous()))
+            self.__dict__["_packed_conv_a_cache"] = cache
+        return cache[1]
+
     def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0, gdn=None):
         """Inference-only: y = act(conv(x) + bias) on an F16K input buffer. Returns (y, Ho, Wo) with y an F16K buffer of
         ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate).

@@ -573,3 +573,22 @@ def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=No
         flops, nbytes = conv_algorithmic_work(desc)
         _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
     return y32 if y32 is not None else y16
+
+
+def pack_conv_a_weight(weight):
+    _dev(weight, "weight")
+    if tuple(weight.shape) != (128, 3, 5, 5):
+        raise RuntimeError("masic_amd.pack_conv_a_weight: the first-layer kernel is built for Conv2d(3, 128, 5, stride 2)")
+    packed = torch.empty(lib.masic_conv_a_packed_bytes() // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_conv_a_pack_weight(_p(weight), _p(packed), _stream()), "conv_a_pack_weight")
+    return packed
+
+
+def conv_a_gdn_f16k(x, packed, bias, gdn, in_coff=0):
+    """GDN(Conv2d(3 -> 128, k5, s2, p2)(x[:, in_coff:in_coff+3]) + bias) -> (F16K buffer, Ho, Wo); gdn = (pack_gdn_f16k(..), inverse)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
+    check(lib.masic_conv_a_gdn_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), int(gdn[1]), _p(y), B, H, W, ctot, in_coff, _stream()), "conv_a_gdn_fwd")
+    return y, Ho, Wo
