@@ -246,9 +246,9 @@ class mask2weights(nn.Module):
 
 
 def _synthesis_f16k(dec, y_hat):
-    """deconv+IGDN -> deconv+IGDN -> deconv+IGDN of a synthesis transform, F16K in between, the inverse GDNs fused into
-    the transposed convolutions; returns the float32 NCHW input of the last (128 -> 3) transposed convolution, or None if
-    a shape is unsupported."""
+    """The synthesis transform deconv+IGDN x3 -> deconv(128 -> 3) with bf16 operands: F16K activations in between, the
+    inverse GDNs fused into the transposed convolutions, the last layer as a 3x3 convolution with a depth-to-space store.
+    Returns the float32 NCHW output of g_s_conv4, or None if a shape is unsupported."""
     B, _, H, W = y_hat.shape
     convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3)
     gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
@@ -258,10 +258,12 @@ def _synthesis_f16k(dec, y_hat):
             return None
         d = cv._desc_f16k(B, *sizes[-1])
         sizes.append((d.Ho, d.Wo))
+    if not dec.g_s_conv4.d2s_supported(B, *sizes[3]):
+        return None
     t16 = _hip.nchw_to_f16k(y_hat)
-    t16, _, _ = convs[0].run_f16k(t16, B, *sizes[0], gdn=gdns[0])
-    t16, _, _ = convs[1].run_f16k(t16, B, *sizes[1], gdn=gdns[1])
-    return convs[2].run_f16k(t16, B, *sizes[2], want_nchw=True, gdn=gdns[2])[0]     # float32 NCHW for the few-output-channel kernel
+    for i in range(3):
+        t16, _, _ = convs[i].run_f16k(t16, B, *sizes[i], gdn=gdns[i])
+    return dec.g_s_conv4.run_f16k_d2s(t16, B, *sizes[3])
 
 
 class Encoder1(nn.Module):
@@ -315,9 +317,9 @@ class Decoder1(nn.Module):
     def reconstruct(self, y_hat):
         """forward(y_hat)[0]; F16K chain with bf16 operands and no autograd."""
         if _bf16_inference(y_hat, self.g_s_conv1.weight):
-            g3 = _synthesis_f16k(self, y_hat)
-            if g3 is not None:
-                return self.g_s_conv4(g3)
+            x_hat = _synthesis_f16k(self, y_hat)
+            if x_hat is not None:
+                return x_hat
         return self.forward(y_hat)[0]
 
 
@@ -373,7 +375,8 @@ class Decoder2(nn.Module):
             t = self.g_s_gdn1(self.g_s_conv1(y_hat))
             t = self.g_s_gdn2(self.g_s_conv2(t))
             t = self.g_s_gdn3(self.g_s_conv3(t))
-        t = self.after_gdn(self.g_s_conv4(t))
+            t = self.g_s_conv4(t)
+        t = self.after_gdn(t)
         return self.after_conv(_ag.cat(t, x1_hat_warp))
 
 

@@ -124,6 +124,13 @@ int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const floa
                             const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
                             const masic_conv_desc_t* d, void* stream);
 
+/* The last synthesis layer g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2) (MASIC.py:550, :598) as its equivalent stride-1
+ * 3x3 convolution to (2x2 phases) x C channels with a depth-to-space store.  `d`: that Conv2d(Cin -> 32 (zero padded), k3,
+ * s1, p1) with weight row (phase*C + c) = W_t[:, c, phase_h + 2(2-u), phase_w + 2(2-v)] (zero where the index exceeds 4) and
+ * bias row (phase*C + c) = bias[c]; y_nchw: [B][y_ctot][2 Hi][2 Wi], channels y_coff .. y_coff+C-1 are written. */
+int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed, const float* bias, float* y_nchw, int C,
+                            int y_ctot, int y_coff, const masic_conv_desc_t* d, void* stream);
+
 /* First analysis layer g_a_conv1 + g_a_gdn1 (MASIC.py:515-516, :563-564) in one kernel: Conv2d(3 -> 128, k5, s2, p2) on
  * channels in_coff..in_coff+2 of a float32 NCHW tensor, GDN, result in F16K [B][8][Ho*Wo][16]. */
 size_t masic_conv_a_packed_bytes(void);

@@ -59,6 +59,7 @@ struct F16kArgs {
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
     const uint4* gdn_img;         // GDN epilogue: gamma^ fragments (gdn.hip: gdn_pack_f16k_kernel), then beta^[128] floats
     int gdn_inverse;
+    int d2s;                      // > 0: channels are (phase 2x2, d2s channels); y32 is [B][out_ctot][2Ho][2Wo] (depth-to-space store)
     int in_c16tot, in_c16off, Cin16;
     int Hi, Wi, Cout, Ho, Wo;
     int out_ctot, out_coff;       // channel view of the output (NCHW: channels; F16K: channels, multiples of 16)
@@ -171,8 +172,10 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
 // patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks); GDN: (inverse) GDN over the 128
 // output channels fused into the epilogue.  Output: float32 NCHW if a.y32 else F16K.
-template <int KS, int T, int D, int PSP, int L, bool GDN>
+// NM: 32-channel accumulator tiles per wave -- 4 (a 128-channel block) or 1 (layers with <= 32 output channels).
+template <int KS, int T, int D, int PSP, int L, bool GDN, int NM>
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
+    static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
     constexpr int WST = T * KS * 4096;           // bytes per step of weights
@@ -269,9 +272,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
     // wave w owns all 128 output channels of pixel sub-tile w (4 accumulator tiles): the GDN epilogue needs every channel
     // of a pixel, and this way it finds them in the wave's own registers
-    f32x16 acc[4];
+    f32x16 acc[NM];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
 
@@ -327,13 +330,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         for (int tt = 0; tt < T; ++tt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 af[4];
+                bf16x8 af[NM];
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl + tv[tt] + (cb + ks * gpk * 1024))));
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < NM; ++m)
                     af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m], 0, 0, 0);
+                for (int m = 0; m < NM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m], 0, 0, 0);
             }
         }
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     if (a.bias != nullptr) {
         const float* bp = a.bias + m0 + 4 * h;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NM; ++m) {
             if (m0 + m * 32 < a.Cout) {
                 float bv[16];
 #pragma unroll
@@ -381,11 +384,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     }
     if (!GDN) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = apply_act(acc[m][e], a.act) * gv;
     }
-    if (GDN) {
+    if constexpr (GDN) {
         // The 64 KiB fragment image is shared by the 8 waves through LDS (the weight ring is free now): one DMA, one barrier.
         static_assert(NWS * WST == 65536, "the gamma image takes the place of the weight ring");
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
@@ -402,12 +405,21 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         gdn_in_registers(acc, lds + lane * 16, bt, a.gdn_inverse);
     }
     // stores: one 64-bit base per lane, 32-bit channel offsets
-    if (pok) {
+    if (pok && a.d2s > 0) {
+        // depth-to-space: channel (phase, c) of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of channel c
+        float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff) * (4 * oplane) + (size_t)(2 * oh) * (2 * a.Wo) + 2 * ow;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = 4 * h + (e & 3) + 8 * (e >> 2);
+            const int ph = co / a.d2s, cc = co - ph * a.d2s;
+            if (co < 4 * a.d2s) yb[(size_t)cc * (4 * oplane) + (size_t)(ph >> 1) * (2 * a.Wo) + (ph & 1)] = acc[0][e];
+        }
+    } else if (pok) {
         if (a.y32 != nullptr) {
             float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * oplane + opix;
             const unsigned op = (unsigned)oplane;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < NM; ++m)
                 if (m0 + m * 32 < a.Cout) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[m][e];
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + (cg0 >> 4)) * oplane + opix) * 16 + (cg0 & 15);
             const unsigned op16 = (unsigned)oplane * 16;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < NM; ++m)
                 if (m0 + m * 32 < a.Cout) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -603,7 +615,7 @@ constexpr int F16K_D = 3;
 
 F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     F16kCfg c{};
-    if (d.Cout < 64 || d.Cout % 32 != 0 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    if (d.Cout < 32 || d.Cout % 32 != 0 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
     int span_h = 0, span_w = 0, min_taps = 1 << 30, max_taps = 0;
     for (int p = 0; p < nphase; ++p) {
         span_h = span_h > g[p].nth ? span_h : g[p].nth;
@@ -695,6 +707,12 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
     return masic_launch_status("conv_f16k_pack_weight");
 }
 
+namespace {
+int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
+                const masic_conv_desc_t* d, void* stream);
+}
+
 extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                                        const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
                                        const masic_conv_desc_t* d, void* stream);
@@ -707,10 +725,29 @@ extern "C" int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, con
 extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                                        const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
                                        const masic_conv_desc_t* d, void* stream) {
+    return f16k_launch(x_f16k, w_packed, bias, gate, gdn_packed, gdn_inverse, 0, y_nchw, y_f16k, d, stream);
+}
+
+// A stride-2 transposed convolution to few channels (g_s_conv4: 128 -> 3, MASIC.py:550, :598) run as its equivalent
+// stride-1 3x3 convolution to (4 phases x C) channels with a depth-to-space store: `d` describes that equivalent
+// Conv2d (Cout = 32, weights re-laid out by the caller), y_nchw is [B][out_ctot][2 Ho][2 Wo], channels out_coff..out_coff+C-1.
+extern "C" int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed, const float* bias, float* y_nchw, int C,
+                                       int y_ctot, int y_coff, const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(d && C > 0 && 4 * C <= 32 && d->Cout == 32 && d->stride == 1 && !d->transposed, MASIC_ERR_UNSUPPORTED,
+                  "conv_f16k_d2s: needs a stride-1 convolution to 32 (padded) channels and C <= 8");
+    MASIC_REQUIRE(y_coff >= 0 && y_coff + C <= y_ctot, MASIC_ERR_SHAPE, "conv_f16k_d2s: output channel view out of range");
+    return f16k_launch(x_f16k, w_packed, bias, nullptr, nullptr, 0, C | (y_ctot << 8) | (y_coff << 20), y_nchw, nullptr, d, stream);
+}
+
+namespace {
+int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
+                const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
+                const masic_conv_desc_t* d, void* stream) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     MASIC_REQUIRE(x_f16k && w_packed && ((y_nchw != nullptr) != (y_f16k != nullptr)), MASIC_ERR_ARG,
                   "conv_f16k_fwd: need input, weights and exactly one output");
+    MASIC_REQUIRE(d->Cout > 32 || d->KH * d->KW > 1, MASIC_ERR_UNSUPPORTED, "conv_f16k: no 1x1 configuration");
     ConvGeom g[4];
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
@@ -723,8 +760,8 @@ extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed,
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, gdn_inverse, d->in_ctot / 16, d->in_coff / 16, c.Cin16,
-               d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d->out_ctot, d->out_coff,
+               (const uint4*)gdn_packed, gdn_inverse, d2s & 0xff, d->in_ctot / 16, d->in_coff / 16, c.Cin16,
+               d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : d->out_ctot, d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
                c.PH, c.PW, c.PWh, c.NPIXp, c.PB,
@@ -732,9 +769,9 @@ extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed,
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
-#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV)                                                                         \
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV)                                                                         \
     do {                                                                                                             \
-        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV>;                                                       \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV, NMV>;                                                       \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -743,15 +780,17 @@ extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed,
         hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
     } while (0)
     if (c.KS == 1) {
-        if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true);
-        else F16K_LAUNCH(1, 4, 6, 1, false);
+        if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4);
+        else F16K_LAUNCH(1, 4, 6, 1, false, 4);
     } else {
-        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true);
-        else F16K_LAUNCH(2, 2, 3, 2, false);
+        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true, 4);
+        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 3, 2, false, 1);
+        else F16K_LAUNCH(2, 2, 3, 2, false, 4);
     }
 #undef F16K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");
 }
+}  // namespace
 
 // First analysis layer: Conv2d(3 -> 128, k5, s2, p2) + GDN -> F16K (conv_a_gdn_f16k above).  x: float32 NCHW channel view.
 extern "C" size_t masic_conv_a_packed_bytes(void) { return 20480; }

@@ -117,6 +117,25 @@ class _PackedWeightMixin:
             self.__dict__["_packed_conv_a_cache"] = cache
         return cache[1]
 
+    def run_f16k_d2s(self, x16, B, Hi, Wi, out=None, out_coff=0):
+        """Inference-only, ConvTranspose2d(Cin -> C <= 8, k5, s2) on an F16K input: run as the equivalent stride-1 3x3 convolution
+        to 4C channels with a depth-to-space store (masic_conv_f16k_d2s_fwd). Returns float32 NCHW [B, C, 2Hi, 2Wi]."""
+        if not self.transposed_conv or self._geometry() != (5, 5, 2, 2):
+            raise RuntimeError("masic_amd: run_f16k_d2s is for ConvTranspose2d(k=5, s=2, p=2)")
+        desc = ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, 3, 3, 1, 1, prec=PREC_BF16)
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device), B, Hi, Wi, None if self.bias is None else self.bias._version)
+        cache = self.__dict__.get("_packed_d2s_cache")
+        if cache is None or cache[0] != key:
+            wc, bc = ops.deconv_s2_as_conv_weight(w.detach(), None if self.bias is None else self.bias.detach())
+            cache = (key, ops.pack_conv_f16k_weight(wc, desc), bc)
+            self.__dict__["_packed_d2s_cache"] = cache
+        return ops.conv2d_f16k_d2s(x16, cache[1], cache[2], desc, self.out_channels, out=out, out_coff=out_coff)
+
+    def d2s_supported(self, B, Hi, Wi):
+        return (self.transposed_conv and self._geometry() == (5, 5, 2, 2) and self.out_channels <= 8 and self.in_channels % 32 == 0
+                and ops.conv_f16k_supported(ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, 3, 3, 1, 1, prec=PREC_BF16)))
+
     def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0, gdn=None):
         """Inference-only: y = act(conv(x) + bias) on an F16K input buffer. Returns (y, Ho, Wo) with y an F16K buffer of
         ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate).

@@ -592,3 +592,35 @@ def conv_a_gdn_f16k(x, packed, bias, gdn, in_coff=0):
     y = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
     check(lib.masic_conv_a_gdn_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), int(gdn[1]), _p(y), B, H, W, ctot, in_coff, _stream()), "conv_a_gdn_fwd")
     return y, Ho, Wo
+
+
+def deconv_s2_as_conv_weight(weight, bias):
+    """ConvTranspose2d(Cin -> C, k5, s2, p2, output_padding 1) as the equivalent Conv2d(Cin -> 4C, k3, s1, p1) followed by a
+    2x2 depth-to-space: row (phase*C + c) = W_t[:, c, ph + 2(2-u), pw + 2(2-v)], zero where that index exceeds 4; rows padded
+    to 32.  Returns (weight [32, Cin, 3, 3], bias [32])."""
+    Cin, C, KH, KW = weight.shape
+    if (KH, KW) != (5, 5) or 4 * C > 32:
+        raise RuntimeError("masic_amd.deconv_s2_as_conv_weight: needs a 5x5 kernel and at most 8 output channels")
+    w = torch.zeros((32, Cin, 3, 3), dtype=torch.float32, device=weight.device)
+    b = torch.zeros(32, dtype=torch.float32, device=weight.device)
+    for ph in range(2):
+        for pw in range(2):
+            r0 = (ph * 2 + pw) * C
+            if bias is not None:
+                b[r0:r0 + C] = bias
+            for u in range(3):
+                for v in range(3):
+                    kh, kw = ph + 2 * (2 - u), pw + 2 * (2 - v)
+                    if kh <= 4 and kw <= 4:
+                        w[r0:r0 + C, :, u, v] = weight[:, :, kh, kw].t()
+    return w, b
+
+
+def conv2d_f16k_d2s(x16, packed, bias32, desc, C, out=None, out_coff=0):
+    """The depth-to-space form of a stride-2 transposed convolution (see deconv_s2_as_conv_weight) on an F16K input;
+    returns float32 NCHW [B, C, 2Hi, 2Wi] (or writes channels out_coff.. of `out`)."""
+    if out is None:
+        out = torch.empty((desc.B, C, 2 * desc.Hi, 2 * desc.Wi), dtype=torch.float32, device=x16.device)
+    check(lib.masic_conv_f16k_d2s_fwd(_p(x16), _p(packed), _p(bias32), _p(out), C, out.shape[1], out_coff, ctypes.byref(desc), _stream()),
+          "conv_f16k_d2s_fwd")
+    return out

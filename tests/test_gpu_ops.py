@@ -381,3 +381,40 @@ def test_conv_f16k_fused_gdn(Cin, H, W, tr, inverse):
     t = _rand(B, C, H, W, seed=9, scale=3.0)
     g16 = ops.gdn_f16k(t.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse)
     assert_close(ops.f16k_to_nchw(g16, B, C, H, W), O.gdn(t, beta, gamma, inverse=inverse), "gdn -> f16k", rtol=2.0 ** -8)
+
+
+@pytest.mark.parametrize("B,H,W,ctot,coff,inverse", [(1, 64, 64, 3, 0, False), (2, 40, 72, 6, 3, True), (1, 37, 51, 3, 0, False)])
+def test_first_analysis_layer_fused(B, H, W, ctot, coff, inverse):
+    """g_a_conv1 + g_a_gdn1 in one persistent kernel (Conv2d(3->128, k5, s2) + GDN -> F16K), odd sizes and a channel view."""
+    ops = _ops()
+    from masic_amd import synth
+    x = _rand(B, ctot, H, W, seed=1)
+    w = _rand(128, 3, 5, 5, seed=2, scale=75 ** -0.5)
+    b = _rand(128, seed=3, scale=0.1)
+    rs = np.random.RandomState(3)
+    beta = synth.synth_tensor("g.beta", (128,), rs)
+    gamma = synth.synth_tensor("g.gamma", (128, 128), rs)
+    q = lambda t: t.bfloat16().float()
+    ref = O.gdn(F.conv2d(q(x[:, coff:coff + 3]), q(w), b, stride=2, padding=2), beta, gamma, inverse=inverse)
+    gp = ops.pack_gdn_f16k(beta.to(DEV), gamma.to(DEV))
+    y16, Ho, Wo = ops.conv_a_gdn_f16k(x.to(DEV), ops.pack_conv_a_weight(w.to(DEV)), b.to(DEV), (gp, inverse), in_coff=coff)
+    assert (Ho, Wo) == tuple(ref.shape[-2:])
+    assert_close(ops.f16k_to_nchw(y16, B, 128, Ho, Wo), ref, "conv_a + gdn -> f16k", rtol=2.0 ** -8)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 16, 24, 3), (2, 37, 50, 3), (1, 8, 8, 8)])
+def test_last_synthesis_layer_depth_to_space(B, H, W, C):
+    """g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2) as a 3x3 convolution to 4C channels with a depth-to-space store."""
+    ops = _ops()
+    from masic_amd._lib import PREC_BF16
+    x = _rand(B, 128, H, W, seed=1)
+    w = _rand(128, C, 5, 5, seed=2, scale=(4.0 / (128 * 25)) ** 0.5)
+    b = _rand(C, seed=3)
+    q = lambda t: t.bfloat16().float()
+    ref = F.conv_transpose2d(q(x), q(w), b, stride=2, padding=2, output_padding=1)
+    wc, bc = ops.deconv_s2_as_conv_weight(w.to(DEV), b.to(DEV))
+    d = ops.make_conv_desc(B, 128, H, W, 32, 3, 3, 1, 1, prec=PREC_BF16)
+    out = torch.full((B, C + 2, 2 * H, 2 * W), 5.0, device=DEV)
+    ops.conv2d_f16k_d2s(ops.nchw_to_f16k(x.to(DEV)), ops.pack_conv_f16k_weight(wc, d), bc, d, C, out=out, out_coff=1)
+    assert_close(out[:, 1:1 + C], ref, "deconv as conv + depth-to-space", rtol=2e-5)
+    assert torch.all(out[:, 0] == 5.0) and torch.all(out[:, 1 + C:] == 5.0)
