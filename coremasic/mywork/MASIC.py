@@ -98,6 +98,17 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """Two extra HIP streams per device for independent branches of the forward (captured into graphs like any other work)."""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE_STREAMS[key]
+
+
 def _bf16_inference(*tensors):
     """True when the forward runs with bf16 operands and nothing needs a gradient: the F16K chains apply."""
     from masic_amd import nn as _mnn
@@ -172,9 +183,23 @@ class _GmmHeads(nn.Module):
         if _mnn.get_precision() == "bf16" and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
             B, _, H, W = x.shape
             xf = _hip.nchw_to_f16k(x)        # converted once, read by the three stacks
-            return (self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU)),
-                    self._branch_f16k(self.gmm_means, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)),
-                    self._branch_f16k(self.gmm_weights, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)))
+            # the three stacks are independent and each of their GEMMs fills about one wave of workgroups: run them on
+            # three HIP streams so that their tails overlap
+            cur = torch.cuda.current_stream()
+            side = _side_streams(x.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            outs = [self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU))]
+            for st, (seq, acts) in zip(side, ((self.gmm_means, (_LEAKY, _LEAKY, _NONE)), (self.gmm_weights, (_LEAKY, _LEAKY, _NONE)))):
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    outs.append(self._branch_f16k(seq, xf, B, H, W, acts))
+                    done = torch.cuda.Event()
+                    done.record(st)
+                cur.wait_event(done)
+            for t in outs[1:] + [xf]:
+                t.record_stream(cur)
+            return tuple(outs)
         sigma = self._branch(self.gmm_sigma, x, (_RELU, _RELU, _RELU))
         means = self._branch(self.gmm_means, x, (_LEAKY, _LEAKY, _NONE))
         logits = self._branch(self.gmm_weights, x, (_LEAKY, _LEAKY, _NONE))
