@@ -26,12 +26,36 @@
 // Epilogue: bias + activation, then either float32 NCHW (channel view of a concat buffer, optional gate) or F16K bf16
 // for the next layer.
 #include "common.h"
-#include "conv_geom.h"
 #include <type_traits>
+#include "conv_geom.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// LDS reads / waits the compiler does not see (see the K loop of conv_f16k)
+template <int OFF>
+__device__ __forceinline__ void ds_read128(v4u& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -185,6 +209,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int dummy_off = PATCH0 + NB * a.PB;    // 1 KiB sink for unused DMA slots, then the tap table
     const int table_off = dummy_off + 1024;
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;   // LDS byte address of lds[0]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,28 +342,37 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 dma_buf16(rx, lds + (pdst[k + u] >= 0 ? pb + pdst[k + u] : dummy_off), goff[k + u], xsoff);
             }
         }
-        int tv[T];
-        if (T == 4) {
-            const int4 q = *reinterpret_cast<const int4*>(lds + table_off + t * 16);
-            tv[0] = q.x; tv[1] = q.y; tv[2 % T] = q.z; tv[3 % T] = q.w;
-        } else {
-            const int2 q = *reinterpret_cast<const int2*>(lds + table_off + t * 8);
-            tv[0] = q.x; tv[1 % T] = q.y;
-        }
-        const unsigned char* wst = lds + (al + cslot);
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 af[NM];
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (bl + tv[tt] + (cb + ks * gpk * 1024))));
-#pragma unroll
-                for (int m = 0; m < NM; ++m)
-                    af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wst + (tt * KS + ks) * 4096 + m * 512));
-#pragma unroll
-                for (int m = 0; m < NM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m], 0, 0, 0);
-            }
-        }
+        // LDS reads of the K loop go through inline asm with hand-counted lgkmcnt: for a compiler-visible ds_read hipcc puts
+        // `s_waitcnt vmcnt(0)` in front (the DMA in flight might alias it), which would drain the prefetch queue every step.
+        // The fragments of k-step i+1 are requested before the MFMAs of k-step i are issued.
+        v4u tvv;
+        if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 16) : "memory");
+        else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv)::"memory");
+        const unsigned wst = ldsb + al + cslot;
+        const unsigned pbase = ldsb + bl + cb;
+        v4u af[2][NM], bfr[2];
+        auto request = [&](auto ic, auto bc) {
+            constexpr int i = decltype(ic)::value, buf = decltype(bc)::value, tt = i / KS, ks = i % KS;
+            const unsigned baddr = pbase + tvv[tt] + ks * gpk * 1024;
+            ds_read128<0>(bfr[buf], baddr);
+            static_for<0, NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                ds_read128<i * 4096 + m * 512>(af[buf][m], wst);
+            });
+        };
+        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, T * KS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, buf = i & 1;
+            if constexpr (i + 1 < T * KS) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+            constexpr int pending = i + 1 < T * KS ? NM + 1 : 0;          // LDS returns in order: what was requested for i+1 may stay out
+            if constexpr (NM == 4) lgkm_wait<pending>(bfr[buf], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
+            else lgkm_wait<pending>(bfr[buf], af[buf][0]);
+            static_for<0, NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
+            });
+        });
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
         // weight waves: the slab group of the next step has landed, the D-1 groups after it stay in flight.
         // patch waves: at the end of a chunk the next chunk's patch has landed, the L-1 chunks after it stay in flight.
