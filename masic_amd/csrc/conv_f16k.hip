@@ -91,6 +91,7 @@ struct F16kArgs {
     int TW, TWlog, SR, TH, tiles_w, ntiles;
     int PH, PW, PWh, NPIXp;       // patch rows / row length (pixels), ceil(PW/2), records per k-half plane of the LDS image (x32)
     int PB;                       // bytes per patch buffer
+    unsigned mg_PW, mg_PWh, mg_gpk;   // ceil(2^32 / d): x / d == __umulhi(x, magic) for the small x, d of the patch maps
     unsigned phase_off[4];        // byte offset of each phase's slab streams
     unsigned stream_bytes[4];     // bytes of one (phase, co-block) slab stream
     GeomParams q;
@@ -98,7 +99,7 @@ struct F16kArgs {
 };
 
 #ifndef F16K_ABLATE
-#define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers
+#define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers, 3 no fragment reads, 4 a quarter of the MFMAs
 #endif
 constexpr int MAXTAPS = 32;   // tap table entries (taps of a phase padded to a multiple of T)
 
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
             const int I = k * 4 + wq;
-            const int ks = I / gpk, grp = I - ks * gpk;
+            const int ks = (int)__umulhi((unsigned)I, a.mg_gpk), grp = I - ks * gpk;
             const int q = grp * 64 + lane;
             const int hh = q >= a.NPIXp ? 1 : 0, pp = q - hh * a.NPIXp;
             int pr, pc;
@@ -264,11 +265,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             if (g.is == 2) {
                 const int half = a.PH * a.PWh;
                 const int par = pp >= half ? 1 : 0, rem = pp - par * half;
-                pr = rem / a.PWh;
+                pr = (int)__umulhi((unsigned)rem, a.mg_PWh);
                 pc = 2 * (rem - pr * a.PWh) + par;
                 ok = ok && pp < 2 * half && pc < a.PW;
             } else {
-                pr = pp / a.PW;
+                pr = (int)__umulhi((unsigned)pp, a.mg_PW);
                 pc = pp - pr * a.PW;
                 ok = ok && pp < a.PH * a.PW;
             }
@@ -361,16 +362,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 ds_read128<i * 4096 + m * 512>(af[buf][m], wst);
             });
         };
-        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if (F16K_ABLATE != 3) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, T * KS>([&](auto ic) {
             constexpr int i = decltype(ic)::value, buf = i & 1;
-            if constexpr (i + 1 < T * KS) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+            if constexpr (i + 1 < T * KS && F16K_ABLATE != 3) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
             constexpr int pending = i + 1 < T * KS ? NM + 1 : 0;          // LDS returns in order: what was requested for i+1 may stay out
             if constexpr (NM == 4) lgkm_wait<pending>(bfr[buf], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
             else lgkm_wait<pending>(bfr[buf], af[buf][0]);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
+                if (F16K_ABLATE != 4 || m == 0)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
             });
         });
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         if (F16K_ABLATE != 2) __builtin_amdgcn_s_barrier();
     };
 
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = 0; c < (F16K_ABLATE == 5 ? 0 : nchunks); ++c) {
         step(std::integral_constant<int, 0>{}, 0, false);
         step(std::integral_constant<int, 1>{}, 1, SPC == 2);
         for (int t = 2; t < SPC; ++t) step(std::integral_constant<int, -1>{}, t, t + 1 == SPC);
@@ -799,6 +801,8 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
                c.PH, c.PW, c.PWh, c.NPIXp, c.PB,
+               (unsigned)((0x100000000ull + c.PW - 1) / c.PW), (unsigned)((0x100000000ull + c.PWh - 1) / c.PWh),
+               (unsigned)((0x100000000ull + c.NPIXp / 32 - 1) / (c.NPIXp / 32)),
                {c.phase_off[0], c.phase_off[1], c.phase_off[2], c.phase_off[3]},
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
