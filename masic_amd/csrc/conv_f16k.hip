@@ -712,8 +712,9 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
-    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s>", F16K_D, gdn ? "true" : "false");
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s>", F16K_D, gdn ? "true" : "false");
+    const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
+    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s, 4>", F16K_D, gdn ? "true" : "false");
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s, %d>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
 }
 
