@@ -1,28 +1,46 @@
 """HIP-graph replay of the inference forward.
 
-An eval-mode `HSIC.forward` is ~130 dependent launches of 20-300 us each; issued eagerly from Python the host side
-costs about a tenth of the step.  Everything in it is capturable -- kernels go to torch's current stream, outputs
-come from torch's caching allocator (graph-private pool during capture), weight packs are cached per weight version --
-except the host-side float32 evaluation of the 3x3 sampling matrices (masic_amd/homography.py), which therefore runs
-before each replay and is copied into static device tensors together with the images.
+An eval-mode `HSIC.forward` is ~110 dependent launches of 5-300 us on three streams; issued eagerly from Python the host
+side costs ~15 % of the step.  Everything in it is capturable -- kernels go to torch's current stream, outputs come from
+torch's caching allocator (graph-private pool during capture), weight packs are cached per weight version, the side
+streams fork and join through events -- except the host-side float32 evaluation of the 3x3 sampling matrices
+(masic_amd/homography.py).  That step is pipelined with the device: the homography is fetched on a copy stream (or
+passed as a CPU tensor), the chain runs on the host while the previous replay is still executing, and the results are
+uploaded on the copy stream; the main stream only waits for that upload before copying them into the graph's static
+buffers and replaying.
 """
 import torch
 
-from .homography import warp_matrices
+from .homography import warp_matrices_host
 
 
 class GraphedHSIC:
-    """Callable with the signature of `HSIC.forward`; outputs are static tensors that the next call overwrites."""
+    """Callable with the signature of `HSIC.forward`; outputs are static tensors that the next call overwrites.
+    `h_matrix` may be a CPU tensor; if it is a device tensor it must already be complete when the call is made (it is read
+    on a separate copy stream so that the read does not wait for the previous replay)."""
 
     def __init__(self, net, x1, x2, h_matrix, warmup=2):
         if net.training:
             raise RuntimeError("GraphedHSIC captures the eval-mode forward")
         self.net = net
-        self.x1, self.x2, self.h = x1.clone(), x2.clone(), h_matrix.clone()
+        dev = x1.device
+        self.x1, self.x2 = x1.clone(), x2.clone()
         H, W = x1.shape[-2:]
         self.hw = (H, W)
-        mf, mb = warp_matrices(self.h, self.hw, self.hw, want_inverse=True)
-        self.mf, self.mb = mf.clone(), mb.clone()
+        B = x1.shape[0]
+        self.h = torch.zeros((B, 3, 3), dtype=torch.float32, device=dev)
+        self.mf = torch.zeros((B, 3, 3), dtype=torch.float32, device=dev)
+        self.mb = torch.zeros((B, 3, 3), dtype=torch.float32, device=dev)
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.h_pinned = torch.empty((B, 3, 3), dtype=torch.float32).pin_memory()
+        self.m_pinned = torch.empty((2, B, 3, 3), dtype=torch.float32).pin_memory()
+        self.m_stage = [torch.empty((2, B, 3, 3), dtype=torch.float32, device=dev) for _ in range(2)]   # double-buffered upload
+        self.stage_free = [torch.cuda.Event(), torch.cuda.Event()]     # main stream has consumed stage buffer p
+        for ev in self.stage_free:
+            ev.record(torch.cuda.current_stream())
+        self.parity = 0
+        self._prepare(h_matrix)
+        torch.cuda.current_stream().synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -33,9 +51,38 @@ class GraphedHSIC:
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = net(self.x1, self.x2, self.h, warp_matrices=(self.mf, self.mb))
 
+    def _prepare(self, h_matrix):
+        """Host chain for this call's homography and its upload; the main stream is made to wait for the upload only."""
+        cs = self.copy_stream
+        if h_matrix.is_cuda:
+            with torch.cuda.stream(cs):
+                self.h_pinned.copy_(h_matrix.detach().to(torch.float32), non_blocking=True)
+            cs.synchronize()
+            m = self.h_pinned
+        else:
+            m = h_matrix.detach().to(torch.float32)
+        mf, mb = warp_matrices_host(m, self.hw, self.hw, want_inverse=True)
+        self.m_pinned[0].copy_(mf)
+        self.m_pinned[1].copy_(mb)
+        p = self.parity
+        self.parity ^= 1
+        stage = self.m_stage[p]
+        cs.wait_event(self.stage_free[p])                 # the call before last has copied this stage buffer out (bounds the host's lead)
+        with torch.cuda.stream(cs):
+            stage.copy_(self.m_pinned, non_blocking=True)
+            up = torch.cuda.Event()
+            up.record(cs)
+        cs.synchronize()                                  # the pinned buffers are reused by the next call
+        cur = torch.cuda.current_stream()
+        cur.wait_event(up)
+        self.mf.copy_(stage[0])
+        self.mb.copy_(stage[1])
+        self.stage_free[p].record(cur)
+        # self.h is only passed through: with precomputed sampling matrices the forward never reads the homography itself
+
     def __call__(self, x1, x2, h_matrix):
-        mf, mb = warp_matrices(h_matrix, self.hw, self.hw, want_inverse=True)    # host float32 chain (sync on h_matrix only)
-        self.x1.copy_(x1); self.x2.copy_(x2); self.h.copy_(h_matrix)
-        self.mf.copy_(mf); self.mb.copy_(mb)
+        self._prepare(h_matrix)
+        self.x1.copy_(x1)
+        self.x2.copy_(x2)
         self.graph.replay()
         return self.out

@@ -35,13 +35,17 @@ def warp_matrices(h_matrix, src_hw, dst_hw, want_inverse=False):
         return fwd, back
     if not h_matrix.is_cuda:
         raise RuntimeError("masic_amd: h_matrix must be a CUDA (HIP) tensor -- the MI355X path has no CPU fallback")
-    m = h_matrix.detach().to("cpu", torch.float32)
+    fwd, back = warp_matrices_host(h_matrix.detach().to("cpu", torch.float32), src_hw, dst_hw, want_inverse)
+    return fwd.to(h_matrix.device), (back.to(h_matrix.device) if want_inverse else None)
+
+
+def warp_matrices_host(m, src_hw, dst_hw, want_inverse=False):
+    """The float32 chain itself on a CPU tensor [B,3,3]; returns CPU tensors (callers that pipeline the host step with
+    device work -- masic_amd/graph.py -- do their own transfers)."""
     n_src = _normal_transform_pixel(*src_hw)
     n_dst = _normal_transform_pixel(*dst_hw)
 
     def chain(mat):
         return torch.inverse(n_dst @ (mat @ torch.inverse(n_src))).contiguous()
 
-    fwd = chain(m).to(h_matrix.device)
-    back = chain(torch.inverse(m)).to(h_matrix.device) if want_inverse else None
-    return fwd, back
+    return chain(m), (chain(torch.inverse(m)) if want_inverse else None)
