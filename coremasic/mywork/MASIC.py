@@ -576,22 +576,14 @@ class HSIC(CompressionModel):
         masks and gates; only warp(x1_hat) -> y1_warp does -- and the hyper transforms are chains of small, latency-bound
         kernels: issued on side streams they fill the machine while the other view's large convolutions run.
           main : left view ............................... decoder1 -> warp -> encoder1(x1_hat_warp) -> join -> heads2 -> decoder2
-          A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> (gates) -> h_s2_up, ctx2
-          B    : masks -> mask2weights ;  ctx1 once y1 exists"""
+          A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, ctx2
+          B    : ctx1 once y1 exists"""
         M = self.M
         B, _, H, W = x1.shape
         cur = torch.cuda.current_stream()
         sA, sB = _side_streams(x1.device)
         start = torch.cuda.Event()
         start.record(cur)
-
-        sB.wait_event(start)
-        with torch.cuda.stream(sB):
-            x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
-            x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
-            gates = self.mask2weights_unit(x1_mask_R)                                # [B,3,h,w]
-            ev_gates = torch.cuda.Event()
-            ev_gates.record(sB)
 
         sA.wait_event(start)
         with torch.cuda.stream(sA):
@@ -603,7 +595,11 @@ class HSIC(CompressionModel):
             z2_hat, z2_lik = self.entropy_bottleneck2(z2)
             h, w = y2.shape[-2:]
             cat2 = torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)   # params2*g0 | ctx2*g1 | y1_warp_hat*g2
-            sA.wait_event(ev_gates)
+            # masks and gates: a chain of tiny kernels first needed here; at the head of the forward it would only delay the
+            # analysis transforms
+            x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+            x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
+            gates = self.mask2weights_unit(x1_mask_R)                                # [B,3,h,w]
             self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
             self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
             ev_right = torch.cuda.Event()
@@ -633,7 +629,6 @@ class HSIC(CompressionModel):
         cur.wait_event(ev_right)
         for t in (x1_mask_R, x1_mask_L, gates, y2, z2_hat, z2_lik, cat2):
             t.record_stream(cur)
-        gates.record_stream(sA)
         _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
         s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
         y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
