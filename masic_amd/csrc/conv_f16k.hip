@@ -66,6 +66,25 @@ __device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
 
 __device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
 
+// F16K store of the 32 channels of accumulator tile `t` (lane (j, h) holds channels 4h + 8q + i, q, i < 4, of pixel j):
+// the two halves of the wave swap their middle quarters (v_permlane32_swap) so that lane (j, h) ends up with the 8
+// consecutive channels 8h .. 8h+7 of each 16-channel record and writes it with one 16-byte store -- the wave writes
+// whole 32-byte records (full sectors; 1 KiB contiguous when the pixels are adjacent) instead of scattered 8-byte pieces.
+// rec: address of the lane's pixel in the first of the two records, + 8h elements; rec_stride: elements between records.
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi);
+__device__ __forceinline__ void store_f16k_tile(const f32x16& t, unsigned short* rec, unsigned rec_stride) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned a0 = pack2bf(t[8 * r + 0], t[8 * r + 1]), a1 = pack2bf(t[8 * r + 2], t[8 * r + 3]);   // channels 4h .. 4h+3
+        const unsigned b0 = pack2bf(t[8 * r + 4], t[8 * r + 5]), b1 = pack2bf(t[8 * r + 6], t[8 * r + 7]);   // channels 8 + 4h ..
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        uint4 st;
+        st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
+        *reinterpret_cast<uint4*>(rec + (size_t)r * rec_stride) = st;
+    }
+}
+
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v;
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int phase = rest % a.nphase;
     const int tile = (rest / a.nphase) * 8 + xcd;
     if (tile >= a.ntiles) return;
+    if (F16K_ABLATE == 6) return;                 // launch cost only
     const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
     const int b = blockIdx.z;
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
@@ -323,6 +343,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if (F16K_ABLATE == 7) return;                 // launch + prologue (setup, first DMA, wait)
     int cslot = 0, pslot = (D % NWS) * WST;                   // byte offsets of the consumer / producer ring slots
     int cb = PATCH0, pb = PATCH0 + (L % NB) * a.PB;           // byte offsets of the patch buffer of chunk c / of chunk c+L
     int xsoff = L * (KS * plane_bytes);                       // patch producer: byte offset of chunk c+L in the input
@@ -383,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         if (F16K_ABLATE != 2) __builtin_amdgcn_s_barrier();
     };
 
-    for (int c = 0; c < (F16K_ABLATE == 5 ? 0 : nchunks); ++c) {
+    for (int c = 0; c < (F16K_ABLATE == 5 || F16K_ABLATE == 8 ? 0 : nchunks); ++c) {
         step(std::integral_constant<int, 0>{}, 0, false);
         step(std::integral_constant<int, 1>{}, 1, SPC == 2);
         for (int t = 2; t < SPC; ++t) step(std::integral_constant<int, -1>{}, t, t + 1 == SPC);
@@ -440,6 +461,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         __syncthreads();
         gdn_in_registers(acc, lds + lane * 16, bt, a.gdn_inverse);
     }
+    if (F16K_ABLATE == 8) return;                 // everything but the K loop and the stores
     // stores: one 64-bit base per lane, 32-bit channel offsets
     if (pok && a.d2s > 0) {
         // depth-to-space: channel (phase, c) of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of channel c
@@ -461,23 +483,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                     for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[m][e];
                 }
         } else {
-            // record of channels cg .. cg+3, cg = out_coff + m0 + 32m + 8q + 4h: 16-channel block cg >> 4, offset cg & 15
-            const int cg0 = a.out_coff + m0 + 4 * h;
-            unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + (cg0 >> 4)) * oplane + opix) * 16 + (cg0 & 15);
+            // tile m = records 2m, 2m+1 of this 128-channel block (out_coff and m0 are multiples of 16)
+            const int c16 = (a.out_coff + m0) >> 4;
+            unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
             const unsigned op16 = (unsigned)oplane * 16;
 #pragma unroll
             for (int m = 0; m < NM; ++m)
-                if (m0 + m * 32 < a.Cout) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 st;
-                        st.x = pack2bf(acc[m][4 * q], acc[m][4 * q + 1]);
-                        st.y = pack2bf(acc[m][4 * q + 2], acc[m][4 * q + 3]);
-                        // + 8q channels: (cg0 & 15) + 8q may cross into the next 16-channel block
-                        const int cq = (cg0 & 15) + m * 32 + 8 * q;
-                        *reinterpret_cast<uint2*>(yb + (unsigned)(cq >> 4) * op16 + ((cq & 15) - (cg0 & 15))) = st;
-                    }
-                }
+                if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
         }
     }
 }
@@ -620,17 +632,10 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
             if (oh < a.Ho && ow < a.Wo) {
-                unsigned short* yb = a.y16 + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 4 * h;
+                unsigned short* yb = a.y16 + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 8 * h;
                 const unsigned op16 = (unsigned)oplane * 16;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 st;
-                        st.x = pack2bf(acc[m][4 * q], acc[m][4 * q + 1]);
-                        st.y = pack2bf(acc[m][4 * q + 2], acc[m][4 * q + 3]);
-                        *reinterpret_cast<uint2*>(yb + (unsigned)(2 * m + (q >> 1)) * op16 + 8 * (q & 1)) = st;
-                    }
+                for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
             }
         }
         if (next < a.ntiles) stash(buf ^ 1);
