@@ -126,8 +126,9 @@ int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const floa
 
 /* The last synthesis layer g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2) (MASIC.py:550, :598) as its equivalent stride-1
  * 3x3 convolution to (2x2 phases) x C channels with a depth-to-space store.  `d`: that Conv2d(Cin -> 32 (zero padded), k3,
- * s1, p1) with weight row (phase*C + c) = W_t[:, c, phase_h + 2(2-u), phase_w + 2(2-v)] (zero where the index exceeds 4) and
- * bias row (phase*C + c) = bias[c]; y_nchw: [B][y_ctot][2 Hi][2 Wi], channels y_coff .. y_coff+C-1 are written. */
+ * s1, p1) with weight row (4c + phase) = W_t[:, c, phase_h + 2(2-u), phase_w + 2(2-v)] (zero where the index exceeds 4;
+ * phase = 2 phase_h + phase_w) and bias row (4c + phase) = bias[c]; y_nchw: [B][y_ctot][2 Hi][2 Wi], channels
+ * y_coff .. y_coff+C-1 are written. */
 int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed, const float* bias, float* y_nchw, int C,
                             int y_ctot, int y_coff, const masic_conv_desc_t* d, void* stream);
 

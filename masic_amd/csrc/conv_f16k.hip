@@ -102,7 +102,7 @@ struct F16kArgs {
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
     const uint4* gdn_img;         // GDN epilogue: gamma^ fragments (gdn.hip: gdn_pack_f16k_kernel), then beta^[128] floats
     int gdn_inverse;
-    int d2s;                      // > 0: channels are (phase 2x2, d2s channels); y32 is [B][out_ctot][2Ho][2Wo] (depth-to-space store)
+    int d2s;                      // > 0: channel 4c + phase (2x2 phases, c < d2s); y32 is [B][out_ctot][2Ho][2Wo] (depth-to-space store)
     int in_c16tot, in_c16off, Cin16;
     int Hi, Wi, Cout, Ho, Wo;
     int out_ctot, out_coff;       // channel view of the output (NCHW: channels; F16K: channels, multiples of 16)
@@ -464,13 +464,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     if (F16K_ABLATE == 8) return;                 // everything but the K loop and the stores
     // stores: one 64-bit base per lane, 32-bit channel offsets
     if (pok && a.d2s > 0) {
-        // depth-to-space: channel (phase, c) of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of channel c
+        // depth-to-space: channel 4c + phase of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of
+        // channel c.  With that channel order a lane holds whole 2x2 output blocks (channel c = h + 2q in registers 4q..4q+3):
+        // two 8-byte stores per block, 256 contiguous bytes per row and half-wave.
         float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff) * (4 * oplane) + (size_t)(2 * oh) * (2 * a.Wo) + 2 * ow;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = 4 * h + (e & 3) + 8 * (e >> 2);
-            const int ph = co / a.d2s, cc = co - ph * a.d2s;
-            if (co < 4 * a.d2s) yb[(size_t)cc * (4 * oplane) + (size_t)(ph >> 1) * (2 * a.Wo) + (ph & 1)] = acc[0][e];
+        for (int q = 0; q < 4; ++q) {
+            const int cc = h + 2 * q;
+            if (cc < a.d2s) {
+                float* yc = yb + (size_t)cc * (4 * oplane);
+                *reinterpret_cast<float2*>(yc) = make_float2(acc[0][4 * q], acc[0][4 * q + 1]);
+                *reinterpret_cast<float2*>(yc + 2 * a.Wo) = make_float2(acc[0][4 * q + 2], acc[0][4 * q + 3]);
+            }
         }
     } else if (pok) {
         if (a.y32 != nullptr) {

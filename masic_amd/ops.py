@@ -596,8 +596,8 @@ def conv_a_gdn_f16k(x, packed, bias, gdn, in_coff=0):
 
 def deconv_s2_as_conv_weight(weight, bias):
     """ConvTranspose2d(Cin -> C, k5, s2, p2, output_padding 1) as the equivalent Conv2d(Cin -> 4C, k3, s1, p1) followed by a
-    2x2 depth-to-space: row (phase*C + c) = W_t[:, c, ph + 2(2-u), pw + 2(2-v)], zero where that index exceeds 4; rows padded
-    to 32.  Returns (weight [32, Cin, 3, 3], bias [32])."""
+    2x2 depth-to-space: row (4c + phase) = W_t[:, c, ph + 2(2-u), pw + 2(2-v)] with phase = 2 ph + pw, zero where that index
+    exceeds 4; rows padded to 32.  Returns (weight [32, Cin, 3, 3], bias [32])."""
     Cin, C, KH, KW = weight.shape
     if (KH, KW) != (5, 5) or 4 * C > 32:
         raise RuntimeError("masic_amd.deconv_s2_as_conv_weight: needs a 5x5 kernel and at most 8 output channels")
@@ -605,14 +605,14 @@ def deconv_s2_as_conv_weight(weight, bias):
     b = torch.zeros(32, dtype=torch.float32, device=weight.device)
     for ph in range(2):
         for pw in range(2):
-            r0 = (ph * 2 + pw) * C
+            rows = slice(ph * 2 + pw, 4 * C, 4)
             if bias is not None:
-                b[r0:r0 + C] = bias
+                b[rows] = bias
             for u in range(3):
                 for v in range(3):
                     kh, kw = ph + 2 * (2 - u), pw + 2 * (2 - v)
                     if kh <= 4 and kw <= 4:
-                        w[r0:r0 + C, :, u, v] = weight[:, :, kh, kw].t()
+                        w[rows, :, u, v] = weight[:, :, kh, kw].t()
     return w, b
 
 
