@@ -53,6 +53,10 @@ __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e, v4u& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
@@ -172,8 +176,8 @@ __device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned cha
 // error ~2^-16 of a term).  k-step s covers channels 32(s>>1) + 16(s&1) + 8(c>>2) + 4hh + (c&3), c = 0..7 -- exactly the
 // 8 accumulator registers acc[s>>1][8(s&1) + c] the lane already holds for its pixel, so the B operand needs no data
 // movement; the gamma^ fragments lie in LDS pre-arranged in that order (gdn.hip: gdn_pack_f16k_kernel).
-// gimg: LDS address of the fragment image + lane * 16;  bt: beta^ of the lane's channels.
-__device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigned char* gimg, const float (&bt)[4][16], int inverse) {
+// gimg: LDS address of the fragment image + lane * 16;  bet: LDS address of beta^[128] + 4h (read late: no registers held).
+__device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigned char* gimg, const float* bet, int inverse) {
     f32x16 nrm[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -200,26 +204,30 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
         }
     }
     // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway
-    if (inverse) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_sqrtf(nrm[m][e] + bt[m][e]);
-    } else {
+        for (int q = 0; q < 4; ++q) {
+            const float4 be = *reinterpret_cast<const float4*>(bet + m * 32 + 8 * q);
+            const float bq[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_rsqf(nrm[m][e] + bt[m][e]);
-    }
+            for (int i = 0; i < 4; ++i) {
+                const float nv = nrm[m][4 * q + i] + bq[i];
+                acc[m][4 * q + i] *= inverse ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+            }
+        }
 }
 
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
 // patch wave per step during the first 2 steps of a chunk, L patch look-ahead (chunks); GDN: (inverse) GDN over the 128
 // output channels fused into the epilogue.  Output: float32 NCHW if a.y32 else F16K.
 // NM: 32-channel accumulator tiles per wave -- 4 (a 128-channel block) or 1 (layers with <= 32 output channels).
-template <int KS, int T, int D, int PSP, int L, bool GDN, int NM>
+// NP: 32-pixel sub-tiles per wave (tile = 256 NP pixels): larger tiles for the large stride-1-walk layers, whose
+// per-workgroup fixed cost (launch, first DMA, epilogue) would otherwise rival their K loop.
+template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP>
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
+    static_assert(NM + NP == 2 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 5 and 6 fragments per k-step");
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
     constexpr int WST = T * KS * 4096;           // bytes per step of weights
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int gpk = a.NPIXp >> 5;                             // DMA wave-instructions per 16-channel plane of the patch (2*NPIXp/64)
     const int plane_bytes = a.Hi * a.Wi * 32;                 // bytes per 16-channel plane of the input
     int SPC;                                                  // steps per chunk
-    int bl;                                                   // lane part of the B-fragment address
+    int bl[NP];                                               // lane part of the B-fragment addresses
     int goff[NPI];                                            // patch waves: byte offset of this lane's record in a chunk
 
     // Buffer resources: out-of-range offsets read as zero, so padding pixels (voffset = huge), chunks past the last one and
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         }
         const int PWe = g.is == 2 ? a.PWh : a.PW;             // row pitch (records) of the LDS patch image
         const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
-        bl = (h * a.NPIXp + ((wave * a.SR + jr) * g.is) * PWe + jc) * 16;
+#pragma unroll
+        for (int n = 0; n < NP; ++n) bl[n] = (h * a.NPIXp + (((wave * NP + n) * a.SR + jr) * g.is) * PWe + jc) * 16;
         // tap table: byte offset of each tap's record inside the LDS patch image (padding taps alias tap 0; their weights are zero)
         if (tid < MAXTAPS) {
             const int tap = tid < g.ntaps ? tid : 0;
@@ -318,11 +327,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
     // wave w owns all 128 output channels of pixel sub-tile w (4 accumulator tiles): the GDN epilogue needs every channel
     // of a pixel, and this way it finds them in the wave's own registers
-    f32x16 acc[NM];
+    f32x16 acc[NP][NM];
 #pragma unroll
-    for (int m = 0; m < NM; ++m)
+    for (int n = 0; n < NP; ++n)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][m][e] = 0.0f;
 
     // ---- prologue: weight slab groups of the first D steps, the first L patch chunks
     int wsoff = 0;                                            // weight producer: byte offset of the next slab group in the stream
@@ -372,12 +383,14 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv)::"memory");
         const unsigned wst = ldsb + al + cslot;
-        const unsigned pbase = ldsb + bl + cb;
-        v4u af[2][NM], bfr[2];
+        v4u af[2][NM], bfr[2][NP];
         auto request = [&](auto ic, auto bc) {
             constexpr int i = decltype(ic)::value, buf = decltype(bc)::value, tt = i / KS, ks = i % KS;
-            const unsigned baddr = pbase + tvv[tt] + ks * gpk * 1024;
-            ds_read128<0>(bfr[buf], baddr);
+            const unsigned toff = ldsb + cb + tvv[tt] + ks * gpk * 1024;
+            static_for<0, NP>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                ds_read128<0>(bfr[buf][n], toff + bl[n]);
+            });
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 ds_read128<i * 4096 + m * 512>(af[buf][m], wst);
@@ -387,13 +400,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         static_for<0, T * KS>([&](auto ic) {
             constexpr int i = decltype(ic)::value, buf = i & 1;
             if constexpr (i + 1 < T * KS && F16K_ABLATE != 3) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
-            constexpr int pending = i + 1 < T * KS ? NM + 1 : 0;          // LDS returns in order: what was requested for i+1 may stay out
-            if constexpr (NM == 4) lgkm_wait<pending>(bfr[buf], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
-            else lgkm_wait<pending>(bfr[buf], af[buf][0]);
+            constexpr int pending = i + 1 < T * KS ? NM + NP : 0;         // LDS returns in order: what was requested for i+1 may stay out
+            if constexpr (NM == 4 && NP == 1) lgkm_wait<pending>(bfr[buf][0], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
+            else if constexpr (NM == 4 && NP == 2) lgkm_wait<pending>(bfr[buf][0], bfr[buf][1], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
+            else if constexpr (NM == 1 && NP == 4) lgkm_wait<pending>(bfr[buf][0], bfr[buf][1], bfr[buf][2], bfr[buf][3], af[buf][0]);
+            else lgkm_wait<pending>(bfr[buf][0], af[buf][0]);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                if (F16K_ABLATE != 4 || m == 0)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
+                static_for<0, NP>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if (F16K_ABLATE != 4 || m == 0)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf][n]), acc[n][m], 0, 0, 0);
+                });
             });
         });
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
@@ -419,12 +437,6 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int m0 = blockIdx.y * 128;
     const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
     const size_t oplane = (size_t)a.Ho * a.Wo;
-    const int r = r0 + wave * a.SR + jr, c = c0 + jc;
-    const bool pok = r < g.Hp && c < g.Wp;
-    const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
-    const size_t opix = (size_t)oh * a.Wo + ow;
-    float gv = 1.0f;
-    if (!GDN && a.y32 != nullptr && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
     // bias, then (inverse) GDN or the activation.  Cout is a multiple of 32, so a 32-channel block is valid or not as a whole.
     if (a.bias != nullptr) {
         const float* bp = a.bias + m0 + 4 * h;
@@ -435,66 +447,74 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][e] += bv[e];
+                for (int n = 0; n < NP; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[n][m][e] += bv[e];
             }
         }
     }
-    if (!GDN) {
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][e] = apply_act(acc[m][e], a.act) * gv;
-    }
     if constexpr (GDN) {
-        // The 64 KiB fragment image is shared by the 8 waves through LDS (the weight ring is free now): one DMA, one barrier.
-        static_assert(NWS * WST == 65536, "the gamma image takes the place of the weight ring");
+        // The 64 KiB fragment image (+ beta^) is shared by the 8 waves through LDS (ring and patch buffers are free now): one
+        // DMA, one barrier.
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
 #pragma unroll
         for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
-        const float* bet = reinterpret_cast<const float*>(a.gdn_img + 4 * 8 * 2 * 64);
-        float bt[4][16];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) bt[m][e] = bet[m * 32 + 4 * h + (e & 3) + 8 * (e >> 2)];
+        if (wave == 0) dma_buf16(rg, lds + 65536, lane * 16, 65536);          // 512 bytes of beta^; lanes >= 32 read past the end: zeros
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        gdn_in_registers(acc, lds + lane * 16, bt, a.gdn_inverse);
     }
-    if (F16K_ABLATE == 8) return;                 // everything but the K loop and the stores
-    // stores: one 64-bit base per lane, 32-bit channel offsets
-    if (pok && a.d2s > 0) {
-        // depth-to-space: channel 4c + phase of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of
-        // channel c.  With that channel order a lane holds whole 2x2 output blocks (channel c = h + 2q in registers 4q..4q+3):
-        // two 8-byte stores per block, 256 contiguous bytes per row and half-wave.
-        float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff) * (4 * oplane) + (size_t)(2 * oh) * (2 * a.Wo) + 2 * ow;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cc = h + 2 * q;
-            if (cc < a.d2s) {
-                float* yc = yb + (size_t)cc * (4 * oplane);
-                *reinterpret_cast<float2*>(yc) = make_float2(acc[0][4 * q], acc[0][4 * q + 1]);
-                *reinterpret_cast<float2*>(yc + 2 * a.Wo) = make_float2(acc[0][4 * q + 2], acc[0][4 * q + 3]);
-            }
-        }
-    } else if (pok) {
-        if (a.y32 != nullptr) {
-            float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * oplane + opix;
-            const unsigned op = (unsigned)oplane;
-#pragma unroll
-            for (int m = 0; m < NM; ++m)
-                if (m0 + m * 32 < a.Cout) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[m][e];
-                }
+    for (int n = 0; n < NP; ++n) {
+        if (NP > 1) __builtin_amdgcn_sched_barrier(0);      // one sub-tile's epilogue at a time (register pressure)
+        const int r = r0 + (wave * NP + n) * a.SR + jr, c = c0 + jc;
+        const bool pok = r < g.Hp && c < g.Wp;
+        const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+        const size_t opix = (size_t)oh * a.Wo + ow;
+        if constexpr (GDN) {
+            gdn_in_registers(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse);
         } else {
-            // tile m = records 2m, 2m+1 of this 128-channel block (out_coff and m0 are multiples of 16)
-            const int c16 = (a.out_coff + m0) >> 4;
-            unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
-            const unsigned op16 = (unsigned)oplane * 16;
+            float gv = 1.0f;
+            if (a.y32 != nullptr && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
 #pragma unroll
             for (int m = 0; m < NM; ++m)
-                if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[n][m][e] = apply_act(acc[n][m][e], a.act) * gv;
+        }
+        if (F16K_ABLATE == 8) continue;               // everything but the K loop and the stores
+        // stores: one 64-bit base per lane, 32-bit channel offsets
+        if (pok && a.d2s > 0) {
+            // depth-to-space: channel 4c + phase of the equivalent stride-1 convolution -> pixel (2r + phase/2, 2c + phase%2) of
+            // channel c.  With that channel order a lane holds whole 2x2 output blocks (channel c = h + 2q in registers 4q..4q+3):
+            // two 8-byte stores per block, 256 contiguous bytes per row and half-wave.
+            float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff) * (4 * oplane) + (size_t)(2 * oh) * (2 * a.Wo) + 2 * ow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cc = h + 2 * q;
+                if (cc < a.d2s) {
+                    float* yc = yb + (size_t)cc * (4 * oplane);
+                    *reinterpret_cast<float2*>(yc) = make_float2(acc[n][0][4 * q], acc[n][0][4 * q + 1]);
+                    *reinterpret_cast<float2*>(yc + 2 * a.Wo) = make_float2(acc[n][0][4 * q + 2], acc[n][0][4 * q + 3]);
+                }
+            }
+        } else if (pok) {
+            if (a.y32 != nullptr) {
+                float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * oplane + opix;
+                const unsigned op = (unsigned)oplane;
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+                    if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[n][m][e];
+                    }
+            } else {
+                // tile m = records 2m, 2m+1 of this 128-channel block (out_coff and m0 are multiples of 16)
+                const int c16 = (a.out_coff + m0) >> 4;
+                unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
+                const unsigned op16 = (unsigned)oplane * 16;
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+                    if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[n][m], yb + (size_t)(2 * m) * op16, op16);
+            }
         }
     }
 }
@@ -622,17 +642,14 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
             }
         }
         // ---- bias, GDN, F16K store
-        float bt[4][16];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *reinterpret_cast<const float4*>(vec + m * 32 + 8 * q + 4 * h);
-                const float4 be = *reinterpret_cast<const float4*>(vec + 128 + m * 32 + 8 * q + 4 * h);
                 acc[m][4 * q] += bv.x; acc[m][4 * q + 1] += bv.y; acc[m][4 * q + 2] += bv.z; acc[m][4 * q + 3] += bv.w;
-                bt[m][4 * q] = be.x; bt[m][4 * q + 1] = be.y; bt[m][4 * q + 2] = be.z; bt[m][4 * q + 3] = be.w;
             }
-        gdn_in_registers(acc, gimg, bt, a.gdn_inverse);
+        gdn_in_registers(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse);
         {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
 
 struct F16kCfg {
     int ok;
-    int KS, T, L;                 // template selection: strided conv <1,4,D,6,1>, stride-1 walk <2,2,D,3,2>
+    int KS, T, L, NP;             // template selection: strided conv <1,4,D,6,1>, stride-1 walk <2,2,D,3,2>, large stride-1 walk <1,2,D,*,2> with NP > 1
     int TW, TWlog, SR, TH, PH, PW, PWh, NPIXp, PB;
     int Cin16, ncb;
     unsigned phase_off[4], stream_bytes[4];
@@ -669,10 +686,17 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         min_taps = min_taps < g[p].ntaps ? min_taps : g[p].ntaps;
         max_taps = max_taps > g[p].ntaps ? max_taps : g[p].ntaps;
     }
-    const int is = g[0].is, Wp = g[0].Wp;
+    const int is = g[0].is, Wp = g[0].Wp, Hp = g[0].Hp;
     int NPI;
+    c.NP = 1;
     if (is == 2) { c.KS = 1; c.T = 4; NPI = 12; c.L = 1; }    // strided conv: big patch, 16-channel chunks, 4 taps per step
     else { c.KS = 2; c.T = 2; NPI = 6; c.L = 2; }             // stride-1 walk (transposed phases, 3x3, masked): 32-channel chunks
+    // large stride-1-walk layers: 512- (128-channel blocks) or 1024-pixel tiles (<= 32 channels), 16-channel chunks
+    if (is == 1 && Wp >= 32) {
+        const int np = d.Cout <= 32 ? 4 : 2;
+        const long tiles = (long)ceil_div(Wp, 32) * ceil_div(Hp, 8 * np) * nphase * d.B * ceil_div(d.Cout, 128);
+        if (tiles >= 512 && ceil_div(min_taps, 2) >= 2) { c.NP = np; c.KS = 1; c.T = 2; c.L = 2; NPI = np == 4 ? 10 : 6; }
+    }
     if (round_up(max_taps, c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
     c.Cin16 = d.Cin / 16;
     if (c.Cin16 % c.KS != 0) return c;                        // whole chunks only
@@ -680,7 +704,7 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     c.TWlog = 0;
     while ((1 << c.TWlog) < c.TW) ++c.TWlog;
     c.SR = 32 / c.TW;
-    c.TH = c.SR * 8;
+    c.TH = c.SR * 8 * c.NP;
     c.PH = (c.TH - 1) * is + span_h;
     c.PW = (c.TW - 1) * is + span_w;
     c.PWh = (c.PW + 1) / 2;
@@ -700,7 +724,7 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     if (off >= (1u << 31)) return c;
     c.packed_bytes = off;
     c.lds_bytes = (size_t)(F16K_D + 1) * c.T * c.KS * 4096 + (size_t)(c.L + 1) * c.PB + 1024 + MAXTAPS * 4;
-    if (c.lds_bytes > 160 * 1024) return c;
+    if (c.lds_bytes > 160 * 1024 || c.lds_bytes < 65536 + 2048) return c;       // (the fused GDN parks its 64 KiB image + beta^ at offset 0)
     c.ok = 1;
     return c;
 }
@@ -723,8 +747,9 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
-    if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s, 4>", F16K_D, gdn ? "true" : "false");
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s, %d>", F16K_D, gdn ? "true" : "false", nm);
+    if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
+    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s, 4, 1>", F16K_D, gdn ? "true" : "false");
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
 }
 
@@ -818,9 +843,9 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
-#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV)                                                                         \
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV, NPV)                                                                         \
     do {                                                                                                             \
-        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV, NMV>;                                                       \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV, NMV, NPV>;                                                     \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -828,13 +853,19 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         }                                                                                                            \
         hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
     } while (0)
-    if (c.KS == 1) {
-        if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4);
-        else F16K_LAUNCH(1, 4, 6, 1, false, 4);
+    MASIC_REQUIRE(c.NP == 1 || (d->Cout <= 32) == (c.NP == 4), MASIC_ERR_UNSUPPORTED, "conv_f16k: tile configuration");
+    if (c.NP == 4) {
+        F16K_LAUNCH(1, 2, 5, 2, false, 1, 4);
+    } else if (c.NP == 2) {
+        if (gdn_packed) F16K_LAUNCH(1, 2, 3, 2, true, 4, 2);
+        else F16K_LAUNCH(1, 2, 3, 2, false, 4, 2);
+    } else if (c.KS == 1) {
+        if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4, 1);
+        else F16K_LAUNCH(1, 4, 6, 1, false, 4, 1);
     } else {
-        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true, 4);
-        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 3, 2, false, 1);
-        else F16K_LAUNCH(2, 2, 3, 2, false, 4);
+        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true, 4, 1);
+        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 3, 2, false, 1, 1);
+        else F16K_LAUNCH(2, 2, 3, 2, false, 4, 1);
     }
 #undef F16K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");
