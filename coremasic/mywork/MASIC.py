@@ -570,42 +570,40 @@ class HSIC(CompressionModel):
             "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
         }
 
-    def _forward_eval(self, x1, x2, m_fwd, m_back):
-        """Eval-mode forward (no noise draws, so the order of the branches is free) on three HIP streams.  Most of the right
-        view does not depend on the left one -- analysis of (warp(x1), x2), its hyper transforms and context model, the
-        masks and gates; only warp(x1_hat) -> y1_warp does -- and the hyper transforms are chains of small, latency-bound
-        kernels: issued on side streams they fill the machine while the other view's large convolutions run.
-          main : left view ............................... decoder1 -> warp -> encoder1(x1_hat_warp) -> join -> heads2 -> decoder2
-          A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, ctx2
-          B    : ctx1 once y1 exists"""
+    # ---- eval-mode forward in three segments (no noise draws, so the order of the branches is free).  Most of the right view
+    # does not depend on the left one -- analysis of (warp(x1), x2), its hyper transforms and context model, the masks and
+    # gates; only warp(x1_hat) -> y1_warp does -- and the hyper transforms are chains of small, latency-bound kernels: on a
+    # side stream they fill the machine while the other view's large convolutions run.
+    #   main : encoder1 -> h_a1, EB1, h_s1_up (ctx1 on stream B) -> heads1 -> decoder1 -> warp -> encoder1(x1_hat_warp)
+    #          -> [join] quantize into cat2 -> heads2 -> decoder2
+    #   A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, ctx2
+    # masic_amd/graph.py captures the segments as three HIP graphs (A; main up to the join; the tail) so that A and the main
+    # chain start together on their own streams.
+    def _eval_right_branch(self, x1, x2, m_fwd, m_back):
+        M = self.M
+        B, _, H, W = x1.shape
+        pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
+        _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
+        _hip.copy_view(x2, pair, 3)
+        y2 = self.encoder2.forward_pair(pair)
+        z2 = self._h_a2(y2)
+        z2_hat, z2_lik = self.entropy_bottleneck2(z2)
+        h, w = y2.shape[-2:]
+        cat2 = torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)       # params2*g0 | ctx2*g1 | y1_warp_hat*g2
+        # masks and gates: a chain of tiny kernels first needed here; at the head of the forward it would only delay the
+        # analysis transform
+        x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
+        gates = self.mask2weights_unit(x1_mask_R)                                    # [B,3,h,w]
+        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
+        self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
+        return {"y2": y2, "z2_hat": z2_hat, "z2_lik": z2_lik, "cat2": cat2, "gates": gates, "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L}
+
+    def _eval_left_main(self, x1, m_fwd):
         M = self.M
         B, _, H, W = x1.shape
         cur = torch.cuda.current_stream()
-        sA, sB = _side_streams(x1.device)
-        start = torch.cuda.Event()
-        start.record(cur)
-
-        sA.wait_event(start)
-        with torch.cuda.stream(sA):
-            pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)       # x1_warp | x2
-            _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
-            _hip.copy_view(x2, pair, 3)
-            y2 = self.encoder2.forward_pair(pair)
-            z2 = self._h_a2(y2)
-            z2_hat, z2_lik = self.entropy_bottleneck2(z2)
-            h, w = y2.shape[-2:]
-            cat2 = torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)   # params2*g0 | ctx2*g1 | y1_warp_hat*g2
-            # masks and gates: a chain of tiny kernels first needed here; at the head of the forward it would only delay the
-            # analysis transforms
-            x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
-            x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
-            gates = self.mask2weights_unit(x1_mask_R)                                # [B,3,h,w]
-            self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
-            self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
-            ev_right = torch.cuda.Event()
-            ev_right.record(sA)
-
-        # ---- left view (main stream; its context model on B)
+        sB = _side_streams(x1.device)[1]
         y1 = self.encoder1.latent(x1)
         cat1 = torch.empty((B, 4 * M) + tuple(y1.shape[-2:]), dtype=x1.dtype, device=x1.device)   # params1 | ctx_params1
         ev_y1 = torch.cuda.Event()
@@ -622,22 +620,39 @@ class HSIC(CompressionModel):
         s1, m1, l1 = self._h_s1_same_resolution.heads(cat1)
         y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
         x1_hat = self.decoder1.reconstruct(y1_hat)
-
-        # ---- the one left -> right dependency, then the right view's tail
         x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
-        y1_warp = self.encoder1.latent(x1_hat_warp)
-        cur.wait_event(ev_right)
-        for t in (x1_mask_R, x1_mask_L, gates, y2, z2_hat, z2_lik, cat2):
-            t.record_stream(cur)
-        _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+        y1_warp = self.encoder1.latent(x1_hat_warp)                                  # the one left -> right dependency
+        return {"x1_hat": x1_hat, "y1_hat": y1_hat, "z1_hat": z1_hat, "y1_lik": y1_lik, "z1_lik": z1_lik,
+                "x1_hat_warp": x1_hat_warp, "y1_warp": y1_warp}
+
+    def _eval_tail(self, left, right):
+        M = self.M
+        cat2, gates, y2 = right["cat2"], right["gates"], right["y2"]
+        _hip.quantize(left["y1_warp"], "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
         s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
         y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
-        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        x2_hat = self.decoder2(y2_hat, left["x1_hat_warp"])
         return {
-            "x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "z1_hat": z1_hat,
-            "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L,
-            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
+            "x1_hat": left["x1_hat"], "x2_hat": x2_hat, "y1_hat": left["y1_hat"], "z1_hat": left["z1_hat"],
+            "x1_mask_R": right["x1_mask_R"], "x1_mask_L": right["x1_mask_L"],
+            "likelihoods": {"y1": left["y1_lik"], "y2": y2_lik, "z1": left["z1_lik"], "z2": right["z2_lik"]},
         }
+
+    def _forward_eval(self, x1, x2, m_fwd, m_back):
+        cur = torch.cuda.current_stream()
+        sA = _side_streams(x1.device)[0]
+        start = torch.cuda.Event()
+        start.record(cur)
+        sA.wait_event(start)
+        with torch.cuda.stream(sA):
+            right = self._eval_right_branch(x1, x2, m_fwd, m_back)
+            ev_right = torch.cuda.Event()
+            ev_right.record(sA)
+        left = self._eval_left_main(x1, m_fwd)
+        cur.wait_event(ev_right)
+        for t in right.values():
+            t.record_stream(cur)
+        return self._eval_tail(left, right)
 
     def latents(self, x1, x2, h_matrix):
         """Unquantised latents (y1, y2, z1, z2) -- the inputs of the int32 symbol streams that feed the
