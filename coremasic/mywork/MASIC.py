@@ -117,6 +117,25 @@ def _bf16_inference(*tensors):
     return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
 
 
+def _f16k_chain(convs, acts, x, in_op=0, out=None, out_coff=0, gate=None, gate_c=0):
+    """A chain of convolutions on the float32 NCHW tensor `x` with the activations between them in F16K bf16
+    (conv_f16k.hip); |x| / round(x) is applied while converting the input. The last layer writes float32 NCHW (a channel
+    view of `out`, optionally gated). None if a layer shape has no F16K configuration."""
+    B, C, H, W = x.shape
+    sizes = [(H, W)]
+    for cv in convs:
+        if not cv.f16k_supported(B, *sizes[-1]):
+            return None
+        d = cv._desc_f16k(B, *sizes[-1])
+        sizes.append((d.Ho, d.Wo))
+    t = _hip.nchw_to_f16k(x, in_op=in_op)
+    last = len(convs) - 1
+    for i, (cv, act) in enumerate(zip(convs, acts)):
+        if i == last:
+            return cv.run_f16k(t, B, *sizes[i], act=act, want_nchw=out is None, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)[0]
+        t = cv.run_f16k(t, B, *sizes[i], act=act)[0]
+
+
 def _gdn_f16k(gdn, x):
     return _hip.gdn_f16k(x, gdn.beta.detach(), gdn.gamma.detach(), inverse=gdn.inverse, beta_min=gdn.beta_min)
 
@@ -158,6 +177,10 @@ class encode_hyper(nn.Module):
 
     def forward(self, y):
         s = self.encode_hyper
+        if _bf16_inference(y, s[0].weight):
+            z = _f16k_chain((s[0], s[2], s[4]), (_RELU, _RELU, _NONE), y, in_op=_hip.INOP_ABS)
+            if z is not None:
+                return z
         t = s[0].run(y, in_op=_hip.INOP_ABS, act=_RELU)
         t = s[2].run(t, act=_RELU)
         return s[4].run(t)
@@ -455,9 +478,22 @@ class HSIC(CompressionModel):
         return self.gaussian1._standardized_cumulative(inputs)
 
     def _hyper_up(self, seq, z_hat, out, out_coff, gate=None, gate_c=0):
+        if _bf16_inference(z_hat, seq[0].weight):
+            r = _f16k_chain((seq[0], seq[2], seq[4]), (_LEAKY, _LEAKY, _NONE), z_hat, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+            if r is not None:
+                return r
         t = seq[0].run(z_hat, act=_LEAKY)
         t = seq[2].run(t, act=_LEAKY)
         return seq[4].run(t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+
+    def _context(self, ctx, y, out, out_coff, gate=None, gate_c=0):
+        """Eval-mode context model: masked conv of round(y) into a slice of the concat buffer (optionally gated)."""
+        if _bf16_inference(y, ctx.weight):
+            ctx.zero_masked_taps()
+            r = _f16k_chain((ctx,), (_NONE,), y, in_op=_hip.INOP_ROUND, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+            if r is not None:
+                return r
+        return ctx.run(y, in_op=_hip.INOP_ROUND, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
 
     def _needs_graph(self):
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder1.parameters())
@@ -596,7 +632,7 @@ class HSIC(CompressionModel):
         x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
         gates = self.mask2weights_unit(x1_mask_R)                                    # [B,3,h,w]
         self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
-        self.context_prediction2.run(y2, in_op=_hip.INOP_ROUND, out=cat2, out_coff=2 * M, gate=gates, gate_c=1)
+        self._context(self.context_prediction2, y2, cat2, 2 * M, gates, 1)
         return {"y2": y2, "z2_hat": z2_hat, "z2_lik": z2_lik, "cat2": cat2, "gates": gates, "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L}
 
     def _eval_left_main(self, x1, m_fwd):
@@ -610,7 +646,7 @@ class HSIC(CompressionModel):
         ev_y1.record(cur)
         sB.wait_event(ev_y1)
         with torch.cuda.stream(sB):
-            self.context_prediction1.run(y1, in_op=_hip.INOP_ROUND, out=cat1, out_coff=2 * M)
+            self._context(self.context_prediction1, y1, cat1, 2 * M)
             ev_ctx1 = torch.cuda.Event()
             ev_ctx1.record(sB)
         z1 = self._h_a1(y1)

@@ -95,6 +95,9 @@ int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const float* bias,
  * `transposed` = 1 packs a ConvTranspose2d(k=1) weight [Cin,Cout] (the first two layers of the y1 stacks, :339-342). */
 size_t masic_f16k_bytes(int B, int C, int HW);
 int masic_nchw_to_f16k(const float* x, void* y, int B, int C, int HW, int ctot, int coff, void* stream);
+/* the same with |x| / round(x) applied on the way (MASIC_INOP_*): the inputs of the hyper-analysis transform (MASIC.py:184)
+ * and of the context model in eval mode (:770, :812) */
+int masic_nchw_to_f16k_op(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int in_op, void* stream);
 size_t masic_gemm1x1_packed_bytes(int Cin, int Cout);
 int masic_gemm1x1_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream);
 int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,

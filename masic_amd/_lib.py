@@ -39,6 +39,7 @@ SIGNATURES = {
     "masic_conv2d_fwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_f16k_bytes": (c_size_t, [c_int, c_int, c_int]),
     "masic_nchw_to_f16k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_nchw_to_f16k_op": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv_f16k_supported": (c_int, [_P]),
     "masic_conv_f16k_kernel_name": (c_int, [_P, c_int, ctypes.c_char_p, c_size_t]),
     "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),

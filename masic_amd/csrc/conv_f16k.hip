@@ -690,7 +690,7 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     int NPI;
     c.NP = 1;
     if (is == 2) { c.KS = 1; c.T = 4; NPI = 12; c.L = 1; }    // strided conv: big patch, 16-channel chunks, 4 taps per step
-    else { c.KS = 2; c.T = 2; NPI = 6; c.L = 2; }             // stride-1 walk (transposed phases, 3x3, masked): 32-channel chunks
+    else { c.KS = 2; c.T = 2; NPI = 8; c.L = 2; }             // stride-1 walk (transposed phases, 3x3, 5x5 s1, masked): 32-channel chunks
     // large stride-1-walk layers: 512- (128-channel blocks) or 1024-pixel tiles (<= 32 channels), 16-channel chunks
     if (is == 1 && Wp >= 32) {
         const int np = d.Cout <= 32 ? 4 : 2;
@@ -749,7 +749,7 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
     if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
     else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s, 4, 1>", F16K_D, gdn ? "true" : "false");
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 3, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
 }
 
@@ -863,9 +863,9 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4, 1);
         else F16K_LAUNCH(1, 4, 6, 1, false, 4, 1);
     } else {
-        if (gdn_packed) F16K_LAUNCH(2, 2, 3, 2, true, 4, 1);
-        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 3, 2, false, 1, 1);
-        else F16K_LAUNCH(2, 2, 3, 2, false, 4, 1);
+        if (gdn_packed) F16K_LAUNCH(2, 2, 4, 2, true, 4, 1);
+        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 4, 2, false, 1, 1);
+        else F16K_LAUNCH(2, 2, 4, 2, false, 4, 1);
     }
 #undef F16K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");

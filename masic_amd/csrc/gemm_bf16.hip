@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 
 // float32 NCHW (channel view) -> F16K bf16
 __global__ __launch_bounds__(256) void nchw_to_f16k_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
-                                                           int C, int Cpad, int HW, int ctot, int coff) {
+                                                           int C, int Cpad, int HW, int ctot, int coff, int op) {
     // one thread per (pixel, 8-channel half record): 8 coalesced plane reads, one 16-byte write
     const int b = blockIdx.z, c8 = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void nchw_to_f16k_kernel(const float* __restri
     for (int i = 0; i < 8; ++i) {
         const int c = c8 * 8 + i;
         const float t = xb[(size_t)(c < C ? c : C - 1) * HW];
-        v[i] = c < C ? t : 0.0f;
+        v[i] = c < C ? apply_inop(t, op) : 0.0f;
     }
     uint4 q;
     q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
@@ -192,12 +192,16 @@ __global__ void pack_gemm_weight_kernel(const float* __restrict__ w, unsigned sh
 
 extern "C" size_t masic_f16k_bytes(int B, int C, int HW) { return (size_t)B * round_up(C, 16) * HW * sizeof(unsigned short); }
 
+extern "C" int masic_nchw_to_f16k_op(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int in_op, void* stream);
 extern "C" int masic_nchw_to_f16k(const float* x, void* y, int B, int C, int HW, int ctot, int coff, void* stream) {
+    return masic_nchw_to_f16k_op(x, y, B, C, HW, ctot, coff, MASIC_INOP_NONE, stream);
+}
+extern "C" int masic_nchw_to_f16k_op(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int in_op, void* stream) {
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "nchw_to_f16k: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "nchw_to_f16k: view out of range");
     const int Cpad = round_up(C, 16);
     hipLaunchKernelGGL(nchw_to_f16k_kernel, dim3(ceil_div(HW, 256), Cpad / 8, B), dim3(256), 0, (hipStream_t)stream,
-                       x, (unsigned short*)y, C, Cpad, HW, ctot, coff);
+                       x, (unsigned short*)y, C, Cpad, HW, ctot, coff, in_op);
     return masic_launch_status("nchw_to_f16k");
 }
 

@@ -476,13 +476,13 @@ def warp_perspective_bwd(g_dst, minv_norm, src_shape):
 
 
 # --------------------------------------------------------------------------------------------- bf16 1x1 GEMM stacks
-def nchw_to_f16k(x, C=None, coff=0):
-    """float32 NCHW (channel view) -> F16K bf16 [B][ceil16(C)/16][HW][16] (include/masic_hip.h)."""
+def nchw_to_f16k(x, C=None, coff=0, in_op=INOP_NONE):
+    """float32 NCHW (channel view) -> F16K bf16 [B][ceil16(C)/16][HW][16] (include/masic_hip.h); in_op: |x| / round(x) on the way."""
     _dev(x, "x")
     B, ctot, H, W = x.shape
     C = ctot if C is None else C
     y = torch.empty(lib.masic_f16k_bytes(B, C, H * W) // 2, dtype=torch.int16, device=x.device)
-    check(lib.masic_nchw_to_f16k(_p(x), _p(y), B, C, H * W, ctot, coff, _stream()), "nchw_to_f16k")
+    check(lib.masic_nchw_to_f16k_op(_p(x), _p(y), B, C, H * W, ctot, coff, int(in_op), _stream()), "nchw_to_f16k")
     return y
 
 
