@@ -75,6 +75,15 @@ def run_gdn(name, B, Cin, H, W, k, s, transposed=False, inverse=False, reps=0):
     print(msg, flush=True)
 
 big = len(sys.argv) > 1 and sys.argv[1] == "big"
+if len(sys.argv) > 1 and sys.argv[1] == "hyper":
+    run("h_a1 conv5s1 192->128 32^2", 8, 192, 32, 32, 128, 5, 1, act=ops.ACT_RELU, reps=20)
+    run("h_a2 conv5s2 128->128 32^2", 8, 128, 32, 32, 128, 5, 2, act=ops.ACT_RELU, reps=20)
+    run("h_a3 conv5s2 128->128 16^2", 8, 128, 16, 16, 128, 5, 2, reps=20)
+    run("h_s1 deconv 128->192 8^2", 8, 128, 8, 8, 192, 5, 2, transposed=True, act=ops.ACT_LEAKY, reps=20)
+    run("h_s2 deconv 192->288 16^2", 8, 192, 16, 16, 288, 5, 2, transposed=True, act=ops.ACT_LEAKY, reps=20)
+    run("h_s3 conv3 288->384 32^2", 8, 288, 32, 32, 384, 3, 1, reps=20)
+    run("ctx masked5 192->384 32^2", 8, 192, 32, 32, 384, 5, 1, masked=True, reps=20)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":      # timing only (results of ablated builds are garbage)
     run("B  conv5s2 128->128 256^2", 8, 128, 256, 256, 128, 5, 2, reps=10)
     run("B' deconv 128->128 128^2", 8, 128, 128, 128, 128, 5, 2, transposed=True, reps=10)
