@@ -28,6 +28,6 @@ def available_entropy_coders():
     return _available_entropy_coders
 
 
-from compressai import ops, layers, models, entropy_models, datasets  # noqa: E402,F401
+from compressai import ops, layers, models, entropy_models, datasets, ans, _CXX  # noqa: E402,F401
 
 __version__ = "1.2.0b3.masic_amd"

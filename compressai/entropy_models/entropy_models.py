@@ -2,8 +2,10 @@
 compressai/entropy_models/entropy_models.py:56-866).
 
 On the hot path: `EntropyBottleneck.forward/loss`, `_quantize`, and
-`GaussianMixtureConditional(_gf).forward`.  Bitstream methods (`update`, `compress`, `decompress`)
-belong to the rANS row of SURVEY.md section 8(f) and raise until that row is built.
+`GaussianMixtureConditional(_gf).forward`.  Bitstream side: `EntropyBottleneck.update / compress /
+decompress` and the generic `EntropyModel.compress / decompress` run on the host-side rANS coder of libmasic_hip.so
+(masic_amd/csrc/rans.hip), byte-exact with the reference's `compressai.ans`; symbols come from the HIP `symbols` kernel.
+The Gaussian-conditional tables (`update_scale_table`) belong to HSIC.compress, row 8(f)-1: next.
 Parameter / buffer names are the reference's, so state dicts interchange (248 tensors for HSIC).
 """
 import numpy as np
@@ -13,7 +15,14 @@ import torch.nn as nn
 from compressai.ops import LowerBound
 from masic_amd import ops as _hip
 
-_NEXT = "bitstream coding (rANS tables / compress / decompress) is the 'next' row 8(f)-2 of SURVEY.md; not built yet"
+from masic_amd import rans as _rans
+
+_NEXT = "Gaussian-conditional coding tables belong to HSIC.compress / decompress, the 'next' row 8(f)-1 of SURVEY.md; not built yet"
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """reference entropy_models.py:50-53"""
+    return torch.from_numpy(_rans.pmf_to_quantized_cdf(pmf.detach().cpu().numpy(), precision).astype(np.int32))
 
 
 class EntropyModel(nn.Module):
@@ -70,11 +79,65 @@ class EntropyModel(nn.Module):
             return inputs.type_as(means) + means
         return inputs.float()
 
-    def compress(self, *args, **kwargs):
-        raise NotImplementedError(_NEXT)
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        """reference :136-142"""
+        cdf = torch.zeros((len(pmf_length), int(max_length) + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[:pmf_length[i]], tail_mass[i]), dim=0)
+            _cdf = pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+            cdf[i, :_cdf.size(0)] = _cdf
+        return cdf
 
-    def decompress(self, *args, **kwargs):
-        raise NotImplementedError(_NEXT)
+    def _check_tables(self):
+        """reference :144-163"""
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if self._quantized_cdf.dim() != 2:
+            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
+        if self._offset.numel() == 0:
+            raise ValueError("Uninitialized offsets. Run update() first")
+        if self._offset.dim() != 1:
+            raise ValueError(f"Invalid offsets size {self._offset.size()}")
+        if self._cdf_length.numel() == 0:
+            raise ValueError("Uninitialized CDF lengths. Run update() first")
+        if self._cdf_length.dim() != 1:
+            raise ValueError(f"Invalid offsets size {self._cdf_length.size()}")
+
+    def _host_tables(self):
+        return (self._quantized_cdf.cpu().numpy().astype(np.int32), self._cdf_length.cpu().numpy().astype(np.int32),
+                self._offset.cpu().numpy().astype(np.int32))
+
+    def compress(self, inputs, indexes, means=None):
+        """Symbols on the device (HIP kernel), one rANS stream per batch element on the host (reference :165-196)."""
+        if inputs.dim() != 4:
+            raise ValueError("Invalid `inputs` size. Expected a 4-D tensor.")
+        if inputs.size() != indexes.size():
+            raise ValueError("`inputs` and `indexes` should have the same size.")
+        self._check_tables()
+        symbols = self._quantize(inputs, "symbols", means).cpu().numpy()
+        idx = indexes.cpu().numpy().astype(np.int32)
+        tables = self._host_tables()
+        return [_rans.encode_with_indexes(symbols[i], idx[i], *tables) for i in range(symbols.shape[0])]
+
+    def decompress(self, strings, indexes, means=None):
+        """reference :199-239"""
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError("Invalid `strings` parameter type.")
+        if not len(strings) == indexes.size(0):
+            raise ValueError("Invalid strings or indexes parameters")
+        if indexes.dim() != 4:
+            raise ValueError("Invalid `indexes` size. Expected a 4-D tensor.")
+        self._check_tables()
+        if means is not None:
+            if means.size()[:-2] != indexes.size()[:-2]:
+                raise ValueError("Invalid means or indexes parameters")
+            if means.size() != indexes.size() and (means.size(2) != 1 or means.size(3) != 1):
+                raise ValueError("Invalid means parameters")
+        idx = indexes.cpu().numpy().astype(np.int32)
+        tables = self._host_tables()
+        values = np.stack([_rans.decode_with_indexes(s, idx[i], *tables).reshape(idx[i].shape) for i, s in enumerate(strings)])
+        outputs = torch.from_numpy(values).to(self._quantized_cdf.device)
+        return self._dequantize(outputs, means)
 
 
 class EntropyBottleneck(EntropyModel):
@@ -138,8 +201,51 @@ class EntropyBottleneck(EntropyModel):
         N, C, H, W = size
         return torch.arange(C).view(1, -1, 1, 1).int().repeat(N, 1, H, W)
 
+    def _logits_cumulative_host(self, inputs):
+        """The cumulative nets on [C, 1, L] sample points (reference :350-371), evaluated with float32 torch ops on the host:
+        `update` runs once per trained model, and byte-compatible streams need the reference's CPU arithmetic bit for bit."""
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(torch.nn.functional.softplus(self._matrices[i].detach().cpu()), logits)
+            logits = logits + self._biases[i].detach().cpu()
+            if i < len(self._factors):
+                logits = logits + torch.tanh(self._factors[i].detach().cpu()) * torch.tanh(logits)
+        return logits
+
     def update(self, force=False):
-        raise NotImplementedError(_NEXT)
+        """Per-channel integer offsets and quantised CDF tables from the learned densities (reference :302-343)."""
+        if self._offset.numel() > 0 and not force:
+            return
+        q = self.quantiles.detach().cpu()
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = pmf_length.max()
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative_host(samples - 0.5)
+        upper = self._logits_cumulative_host(samples + 0.5)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        dev = self.quantiles.device
+        self._offset = (-minima).to(dev)
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+
+    def compress(self, x):
+        """reference :419-422"""
+        indexes = self._build_indexes(x.size())
+        medians = self._medians().detach().view(1, -1, 1, 1)
+        return super().compress(x, indexes, medians)
+
+    def decompress(self, strings, size):
+        """reference :424-429"""
+        output_size = (len(strings), self._quantized_cdf.size(0), size[0], size[1])
+        indexes = self._build_indexes(output_size)
+        medians = self._medians().detach().view(1, -1, 1, 1)
+        return super().decompress(strings, indexes, medians)
 
 
 class _GaussianBase(EntropyModel):

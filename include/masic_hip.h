@@ -286,6 +286,22 @@ int masic_entropy_bottleneck_auxloss_bwd(const float* params, const float* quant
 int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,
                                int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Host-side entropy coding (no device work).  Bit-exact replacements of the reference's pybind11
+ * extensions: compressai/cpp_exts/ops/ops.cpp:41-106 (pmf_to_quantized_cdf) and compressai/cpp_exts/rans/
+ * rans_interface.cpp:108-283 (RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes: rANS with a 64-bit
+ * state, 32-bit renormalisation, 16-bit probabilities, 4-bit bypass digits for symbols outside a table).
+ *   cdfs: ncdfs rows of cdf_stride int32; row i holds cdf_sizes[i] entries 0 = c[0] < ... < c[size-1] = 65536; its last
+ *   symbol (size-2) is the escape.  A coded value is symbols[k] - offsets[indexes[k]].
+ *   masic_rans_encode_bound(n) bytes always suffice for n symbols; *out_len receives the stream length. */
+int masic_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf /* n + 1 */);
+size_t masic_rans_encode_bound(int nsymbols);
+int masic_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int n, const int32_t* cdfs, int cdf_stride,
+                                   const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, uint8_t* out, size_t out_cap,
+                                   size_t* out_len);
+int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32_t* indexes, int n, const int32_t* cdfs,
+                                   int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ SIGNATURES = {
     "masic_conv_f16k_pack_weight": (c_int, [_P, _P, _P, _P]),
     "masic_conv_f16k_fwd": (c_int, [_P] * 8),
     "masic_conv_f16k_d2s_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "masic_pmf_to_quantized_cdf": (c_int, [_P, c_int, c_int, _P]),
+    "masic_rans_encode_bound": (c_size_t, [c_int]),
+    "masic_rans_encode_with_indexes": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "masic_rans_decode_with_indexes": (c_int, [_P, c_size_t, _P, c_int, _P, c_int, _P, _P, c_int, _P]),
     "masic_conv_a_packed_bytes": (c_size_t, []),
     "masic_conv_a_pack_weight": (c_int, [_P, _P, _P]),
     "masic_conv_a_gdn_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -1,0 +1,97 @@
+"""Host-side entropy coder against golden vectors produced by the reference's own pybind11 extensions
+and EntropyBottleneck (tests/golden/make_rans_goldens.py).  No GPU needed: the coder is host code of libmasic_hip.so."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rans_vectors.npz"))
+
+
+def _rans():
+    from masic_amd import rans
+    return rans
+
+
+def test_pmf_to_quantized_cdf_matches_reference():
+    rans = _rans()
+    n = 0
+    for key in G.files:
+        if not key.startswith("pmf"):
+            continue
+        prec = int(key[3:5])
+        cdf = rans.pmf_to_quantized_cdf(G[key], prec)
+        ref = G["cdf" + key[3:]]
+        assert cdf.tolist() == ref.tolist(), key
+        assert cdf[0] == 0 and cdf[-1] == 1 << prec and np.all(np.diff(cdf.astype(np.int64)) > 0)
+        n += 1
+    assert n >= 10
+    with pytest.raises(RuntimeError):
+        rans.pmf_to_quantized_cdf([0.5, float("nan")], 16)
+    with pytest.raises(RuntimeError):
+        rans.pmf_to_quantized_cdf([0.0, 0.0], 16)
+
+
+@pytest.mark.parametrize("case", ["short", "mid", "long", "escapes"])
+def test_rans_streams_byte_exact_and_round_trip(case):
+    rans = _rans()
+    tab, sizes, offs = G["tables"], G["sizes"], G["offsets"]
+    sym, idx, ref = G["sym_" + case], G["idx_" + case], G["enc_" + case].tobytes()
+    enc = rans.encode_with_indexes(sym, idx, tab, sizes, offs)
+    assert enc == ref, f"{case}: stream differs from the reference's ({len(enc)} vs {len(ref)} bytes)"
+    assert rans.decode_with_indexes(ref, idx, tab, sizes, offs).tolist() == sym.tolist()
+    # ragged list-of-lists tables (the reference's calling convention) give the same stream
+    rows = [tab[i, :sizes[i]].tolist() for i in range(len(sizes))]
+    assert rans.encode_with_indexes(sym.tolist(), idx.tolist(), rows, sizes.tolist(), offs.tolist()) == ref
+
+
+def test_rans_edge_cases_and_errors():
+    rans = _rans()
+    tab, sizes, offs = G["tables"], G["sizes"], G["offsets"]
+    empty = rans.encode_with_indexes([], [], tab, sizes, offs)
+    assert len(empty) == 8 and rans.decode_with_indexes(empty, [], tab, sizes, offs).size == 0      # just the flushed state
+    extreme = np.array([2 ** 30, -(2 ** 30), 0], dtype=np.int32)
+    idx = np.array([0, 1, 2], dtype=np.int32)
+    assert rans.decode_with_indexes(rans.encode_with_indexes(extreme, idx, tab, sizes, offs), idx, tab, sizes, offs).tolist() == extreme.tolist()
+    with pytest.raises(RuntimeError):
+        rans.encode_with_indexes([1], [len(sizes)], tab, sizes, offs)                               # table index out of range
+    bad = tab.copy(); bad[0, 1] = bad[0, 0]
+    with pytest.raises(RuntimeError):
+        rans.encode_with_indexes([1], [0], bad, sizes, offs)                                        # not strictly increasing
+    enc = rans.encode_with_indexes(G["sym_mid"], G["idx_mid"], tab, sizes, offs)
+    with pytest.raises(RuntimeError):
+        rans.decode_with_indexes(enc[:16], G["idx_mid"], tab, sizes, offs)                          # truncated stream
+
+
+def test_compressai_ans_and_cxx_shims():
+    from compressai import _CXX, ans
+    tab, sizes, offs = G["tables"], G["sizes"], G["offsets"]
+    rows = [tab[i, :sizes[i]].tolist() for i in range(len(sizes))]
+    sym, idx = G["sym_short"].tolist(), G["idx_short"].tolist()
+    enc = ans.RansEncoder().encode_with_indexes(sym, idx, rows, sizes.tolist(), offs.tolist())
+    assert enc == G["enc_short"].tobytes()
+    assert ans.RansDecoder().decode_with_indexes(enc, idx, rows, sizes.tolist(), offs.tolist()) == sym
+    b = ans.BufferedRansEncoder()
+    b.encode_with_indexes(sym[:3], idx[:3], rows, sizes.tolist(), offs.tolist())
+    b.encode_with_indexes(sym[3:], idx[3:], rows, sizes.tolist(), offs.tolist())
+    assert b.flush() == enc
+    assert _CXX.pmf_to_quantized_cdf(G["pmf16_1"].tolist(), 16) == G["cdf16_1"].tolist()
+
+
+def test_entropy_bottleneck_update_tables_match_reference():
+    """EntropyBottleneck.update(): offsets, lengths and quantised CDFs of the reference for the same parameters (host arithmetic)."""
+    import torch
+    from compressai.entropy_models import EntropyBottleneck
+    eb = EntropyBottleneck(12)
+    sd = {k[len("eb_state/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("eb_state/")}
+    for k in ("_offset", "_quantized_cdf", "_cdf_length"):
+        ref = sd.pop(k)
+        eb_ref = ref
+        setattr(eb, "_ref" + k, eb_ref)
+    eb.load_state_dict(sd, strict=False)
+    eb.update(force=True)
+    assert torch.equal(eb._offset.cpu(), eb._ref_offset)
+    assert torch.equal(eb._cdf_length.cpu(), eb._ref_cdf_length)
+    assert torch.equal(eb._quantized_cdf.cpu(), eb._ref_quantized_cdf)
+    eb.update()                                           # second call is a no-op (reference :305-306)
+    assert torch.equal(eb._quantized_cdf.cpu(), eb._ref_quantized_cdf)

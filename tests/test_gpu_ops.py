@@ -418,3 +418,27 @@ def test_last_synthesis_layer_depth_to_space(B, H, W, C):
     ops.conv2d_f16k_d2s(ops.nchw_to_f16k(x.to(DEV)), ops.pack_conv_f16k_weight(wc, d), bc, d, C, out=out, out_coff=1)
     assert_close(out[:, 1:1 + C], ref, "deconv as conv + depth-to-space", rtol=2e-5)
     assert torch.all(out[:, 0] == 5.0) and torch.all(out[:, 1 + C:] == 5.0)
+
+
+def test_entropy_bottleneck_compress_decompress_vs_reference_streams():
+    """EntropyBottleneck.compress: symbols by the HIP kernel, rANS on the host -- byte-identical to the streams the reference
+    produced for the same parameters and input (tests/golden/rans_vectors.npz); decompress returns the reference's tensor."""
+    import os
+    from compressai.entropy_models import EntropyBottleneck
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rans_vectors.npz"))
+    eb = EntropyBottleneck(12)
+    sd = {k[len("eb_state/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("eb_state/")}
+    for k in ("_offset", "_quantized_cdf", "_cdf_length"):
+        sd.pop(k)
+    eb.load_state_dict(sd, strict=False)
+    eb = eb.to(DEV)
+    with pytest.raises(ValueError):
+        eb.compress(torch.from_numpy(G["eb_x"]).to(DEV))              # tables not built yet (reference :144-146)
+    eb.update()
+    x = torch.from_numpy(G["eb_x"]).to(DEV)
+    strings = eb.compress(x)
+    assert [bytes(s) for s in strings] == [G["eb_string_0"].tobytes(), G["eb_string_1"].tobytes()]
+    xh = torch.cat([eb.decompress([s], x.shape[-2:]) for s in strings])
+    assert torch.equal(xh.cpu(), torch.from_numpy(G["eb_xhat"]))
+    with pytest.raises(ValueError):
+        eb.decompress(strings, x.shape[-2:])                          # the reference's one-stream-at-a-time shape check (:221-224)
