@@ -291,3 +291,48 @@ def test_independent_en_batch_and_ragged_vs_oracle():
         out = net(xa.to(DEV), xb.to(DEV), hm.to(DEV))
     for k in ("x1_hat", "x2_hat"):
         assert_close(out[k], ref[k], "cqe2:" + k)
+
+
+def test_bf16_operand_path_config1_accuracy_streams_and_graph():
+    """The bf16-operand forward (F16K chains, fused GDN, three streams) on BASELINE config 1 against the CPU oracle: what
+    bf16 operands cost in codec terms is bounded (rate within 1 %, PSNR within 0.05 dB, reconstruction within 3 %% of
+    the value range, masks -- a float32 warp -- within 1e-4), and a HIP-graph replay equals the eager launch bit for bit."""
+    import MASIC
+    from masic_amd import nn as mnn, synth
+    from masic_amd.graph import GraphedHSIC
+    from masic_amd.loss import rate_distortion
+    dg = json.load(open(os.path.join(GOLDEN, "hsic_c1_digest.json")))
+    N, M, K = dg["NMK"]
+    B, H, W = dg["BHW"]
+    sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=dg["seed"])
+    net = _model(N, M, K, sd).eval()
+    x1, x2, hm = (t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=dg["seed"]))
+    ref = O.hsic_forward(sd, x1.cpu(), x2.cpu(), hm.cpu(), K=K, keep=True)
+    mnn.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            out = net(x1, x2, hm)
+            sym = net.symbol_streams(x1, x2, hm)
+            loss = rate_distortion(out, x1, x2, dg["lmbda"])
+            graphed = GraphedHSIC(net, x1, x2, hm)
+            rep = graphed(x1, x2, hm)
+            torch.cuda.synchronize()
+            for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat"):
+                assert torch.equal(rep[k], out[k]), k
+            for k in out["likelihoods"]:
+                assert torch.equal(rep["likelihoods"][k], out["likelihoods"][k]), k
+    finally:
+        mnn.set_precision("f32")
+    for k in ("x1_mask_R", "x1_mask_L"):
+        assert_close(out[k], ref[k], "bf16:" + k, 1e-4)
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], ref[k], "bf16:" + k, 3e-2)
+    assert abs(float(loss["bpp_loss"]) / dg["loss"]["bpp_loss"] - 1.0) < 1e-2
+    for k in ("psnr1", "psnr2"):
+        assert abs(float(loss[k]) - dg["loss"][k]) < 0.05, (k, float(loss[k]), dg["loss"][k])
+    osym = O.symbols(ref["_aux"], sd)
+    total = sum(v.numel() for v in osym.values())
+    bad = sum(int((sym[k].cpu() != osym[k]).sum()) for k in osym)
+    assert max(int((sym[k].cpu().to(torch.int64) - osym[k].to(torch.int64)).abs().max()) for k in osym) <= 1
+    print(f"bf16 config1: {bad}/{total} symbols differ from the float32 reference ({100.0 * bad / total:.2f} %)")
+    assert bad <= 0.06 * total
