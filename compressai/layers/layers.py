@@ -31,7 +31,12 @@ class MaskedConv2d(Conv2d):
         self.register_buffer("mask", mask)
 
     def zero_masked_taps(self):
-        _hip.mul_inplace(self.weight.data, self.mask)
+        """The reference multiplies weight.data by the mask in place on every forward (layers.py:77); once a weight version is
+        masked the product is idempotent, so it is skipped until the parameter changes (optimizer step, load_state_dict)."""
+        key = (self.weight._version, self.weight.data_ptr())
+        if self.__dict__.get("_masked_version") != key:
+            _hip.mul_inplace(self.weight.data, self.mask)
+            self.__dict__["_masked_version"] = (self.weight._version, self.weight.data_ptr())
 
     def run(self, x, **kw):
         self.zero_masked_taps()

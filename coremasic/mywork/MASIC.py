@@ -136,6 +136,18 @@ def _f16k_chain(convs, acts, x, in_op=0, out=None, out_coff=0, gate=None, gate_c
         t = cv.run_f16k(t, B, *sizes[i], act=act)[0]
 
 
+def _pair_conv(conv, xa, xb, gdn_in=None, gdn_out=None):
+    """The 6 -> 3 k5 s1 (transposed) convolution of encoder2 / decoder2 on two 3-channel sources with the neighbouring
+    3-channel GDN fused (masic_conv5s1_pair_fwd); float32 arithmetic in the order of the separate kernels."""
+    B, _, H, W = xa.shape
+    desc = conv._desc((B, 6, H, W))
+    def g(m):
+        return None if m is None else (m.beta.detach(), m.gamma.detach().contiguous(), m.inverse)
+    bm = (gdn_in or gdn_out).beta_min if (gdn_in or gdn_out) is not None else 1e-6
+    return _hip.conv5s1_pair(xa, xb, conv.packed_weight(desc), None if conv.bias is None else conv.bias.detach(),
+                             gdn_in=g(gdn_in), gdn_out=g(gdn_out), beta_min=bm)
+
+
 def _gdn_f16k(gdn, x):
     return _hip.gdn_f16k(x, gdn.beta.detach(), gdn.gamma.detach(), inverse=gdn.inverse, beta_min=gdn.beta_min)
 
@@ -387,11 +399,20 @@ class Encoder2(nn.Module):
         self.g_a_conv4 = conv(N, M)
 
     def forward(self, x1_warp, x2):
+        if not (torch.is_grad_enabled() and (x1_warp.requires_grad or x2.requires_grad or self.pre_conv.weight.requires_grad)):
+            return self.forward_views(x1_warp, x2)
         return self.forward_pair(_ag.cat(x1_warp, x2))
 
+    def forward_views(self, x1_warp, x2):
+        """Inference: pre_conv on [x1_warp | x2] read from the two tensors (no torch.cat) with pre_gdn in its epilogue."""
+        t = _pair_conv(self.pre_conv, x1_warp.contiguous(), x2.contiguous(), gdn_out=self.pre_gdn)
+        return self._analysis(t)
+
     def forward_pair(self, pair):
-        t = self.pre_gdn(self.pre_conv(pair))
-        if _bf16_inference(pair, self.g_a_conv1.weight):
+        return self._analysis(self.pre_gdn(self.pre_conv(pair)))
+
+    def _analysis(self, t):
+        if _bf16_inference(t, self.g_a_conv1.weight):
             y = _analysis_f16k((self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
                                (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), t)
             if y is not None:
@@ -424,6 +445,9 @@ class Decoder2(nn.Module):
             t = self.g_s_gdn2(self.g_s_conv2(t))
             t = self.g_s_gdn3(self.g_s_conv3(t))
             t = self.g_s_conv4(t)
+        if not (torch.is_grad_enabled() and (t.requires_grad or x1_hat_warp.requires_grad or self.after_conv.weight.requires_grad)):
+            # inference: after_gdn applied while after_conv stages its first source; [t | x1_hat_warp] read in place
+            return _pair_conv(self.after_conv, t.contiguous(), x1_hat_warp.contiguous(), gdn_in=self.after_gdn)
         t = self.after_gdn(t)
         return self.after_conv(_ag.cat(t, x1_hat_warp))
 
@@ -576,10 +600,7 @@ class HSIC(CompressionModel):
         x1_hat = self.decoder1.reconstruct(y1_hat)
 
         # ---- right view
-        pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
-        _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
-        _hip.copy_view(x2, pair, 3)
-        y2 = self.encoder2.forward_pair(pair)
+        y2 = self.encoder2.forward_views(_hip.warp_perspective(x1, m_fwd, (H, W)), x2)
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
 

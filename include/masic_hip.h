@@ -127,6 +127,15 @@ int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const floa
                             const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k,
                             const masic_conv_desc_t* d, void* stream);
 
+/* encoder2.pre_conv + pre_gdn (MASIC.py:559-560, :574-576) and decoder2.after_gdn + torch.cat + after_conv (:599-600,
+ * :617-621) as one launch each: Conv2d / ConvTranspose2d(6 -> 3, k5, s1, p2) on channels [xa(3) | xb(3)] of two float32
+ * tensors, optional 3-channel (I)GDN on xa while it is staged (gin_*: stored beta[3], gamma[3,3]) and / or on the result
+ * (gout_*).  w_packed: masic_conv_pack_weight of that layer.  Same float32 operation order as the separate kernels. */
+int masic_conv5s1_pair_fwd(const float* xa, const float* xb, const float* w_packed, const float* bias,
+                           const float* gin_beta, const float* gin_gamma, int gin_inverse,
+                           const float* gout_beta, const float* gout_gamma, int gout_inverse, double beta_min,
+                           float* y, int B, int H, int W, void* stream);
+
 /* The last synthesis layer g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2) (MASIC.py:550, :598) as its equivalent stride-1
  * 3x3 convolution to (2x2 phases) x C channels with a depth-to-space store.  `d`: that Conv2d(Cin -> 32 (zero padded), k3,
  * s1, p1) with weight row (4c + phase) = W_t[:, c, phase_h + 2(2-u), phase_w + 2(2-v)] (zero where the index exceeds 4;

@@ -806,7 +806,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
 struct Conv5s1Args {
     const float* x; const float* bias; const float* gate; const float* res1; float* y;
     int Cin, H, W, in_ctot, in_coff, Cout, out_ctot, out_coff, act, tiles_w, gate_ctot, gate_c;
+    // fused form of encoder2.pre_conv + pre_gdn and decoder2.after_gdn + cat + after_conv (MASIC.py:574-576, :617-621):
+    const float* xb;          // second source: channels split .. Cin-1 come from xb[B][Cin-split][H][W] (no torch.cat)
+    int split;                // channels taken from x (0: everything from x)
+    const float* gin_beta; const float* gin_gamma; int gin_inverse;      // 3-channel (I)GDN applied to x's channels on load
+    const float* gout_beta; const float* gout_gamma; int gout_inverse;   // 3-channel (I)GDN applied to the output
+    float beta_bound, gamma_bound, pedestal;
 };
+
+// y_i = x_i * (beta^_i + sum_j gamma^_ij x_j^2)^(-1/2 or +1/2) over 3 channels, same operation order as gdn_generic
+__device__ __forceinline__ void gdn3(float (&v)[3], const float* beta, const float* gamma, int inverse, float bb, float gb, float ped) {
+    float sq[3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sq[k] = __fmul_rn(v[k], v[k]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float bv = fmaxf(beta[i], bb);
+        float n = __fsub_rn(__fmul_rn(bv, bv), ped);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g = fmaxf(gamma[i * 3 + k], gb);
+            s = fmaf(__fsub_rn(__fmul_rn(g, g), ped), sq[k], s);
+        }
+        n += s;
+        const float r = sqrtf(n);
+        o[i] = inverse ? v[i] * r : v[i] * (1.0f / r);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = o[i];
+}
 
 __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const float* __restrict__ wpk) {
     constexpr int T = 16, LW = T + 4, PLANE = LW * LW, PSZ = 448;       // 400 floats per channel -> 7 DMA groups
@@ -819,15 +848,26 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
     const int oy = tile_y * T + ty, ox = tile_x * T + tx;
     const size_t plane = (size_t)a.H * a.W;
     const float* xb = a.x + ((size_t)b * a.in_ctot + a.in_coff) * plane;
+    const int split = a.xb != nullptr ? a.split : a.Cin;
+    const float* xb2 = a.xb != nullptr ? a.xb + (size_t)b * (a.Cin - split) * plane : nullptr;
     for (int cg = wave; cg < a.Cin * 7; cg += 4) {
         const int ci = cg / 7, g = cg - ci * 7;
         const int e = g * 64 + lane;
         const int pr = e / LW, pc = e - pr * LW;
         const int ih = tile_y * T - 2 + pr, iw = tile_x * T - 2 + pc;
         const bool ok = e < PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        if (e < PLANE) dma4(ok ? xb + (size_t)ci * plane + (size_t)ih * a.W + iw : g_zero_word, lds + ci * PSZ + g * 64);
+        const float* src = ci < split ? xb + (size_t)ci * plane : xb2 + (size_t)(ci - split) * plane;
+        if (e < PLANE) dma4(ok ? src + (size_t)ih * a.W + iw : g_zero_word, lds + ci * PSZ + g * 64);
     }
     __syncthreads();
+    if (a.gin_beta != nullptr) {            // (I)GDN of the first three channels, per staged pixel (zero padding stays zero)
+        for (int e = tid; e < PLANE; e += 256) {
+            float v[3] = {lds[e], lds[PSZ + e], lds[2 * PSZ + e]};
+            gdn3(v, a.gin_beta, a.gin_gamma, a.gin_inverse, a.beta_bound, a.gamma_bound, a.pedestal);
+            lds[e] = v[0]; lds[PSZ + e] = v[1]; lds[2 * PSZ + e] = v[2];
+        }
+        __syncthreads();
+    }
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const float* base = lds + ty * LW + tx;
     for (int ci = 0; ci < a.Cin; ++ci) {
@@ -845,6 +885,13 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
     if (oy >= a.H || ox >= a.W) return;
     const size_t opix = (size_t)oy * a.W + ox;
     const float gv = a.gate ? a.gate[((size_t)b * a.gate_ctot + a.gate_c) * plane + opix] : 1.0f;
+    if (a.gout_beta != nullptr) {           // 3-channel (I)GDN of the result (no activation / gate / residual in this form)
+        float v[3] = {acc[0] + (a.bias ? a.bias[0] : 0.0f), acc[1] + (a.bias ? a.bias[1] : 0.0f), acc[2] + (a.bias ? a.bias[2] : 0.0f)};
+        gdn3(v, a.gout_beta, a.gout_gamma, a.gout_inverse, a.beta_bound, a.gamma_bound, a.pedestal);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) a.y[((size_t)b * a.out_ctot + a.out_coff + o) * plane + opix] = v[o];
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         if (o >= a.Cout) break;
@@ -975,7 +1022,7 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
     if (c.direct == 3) {
         MASIC_REQUIRE(res2 == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: two residuals on the small 5x5 path");
         Conv5s1Args a{x, bias, gate, res1, y, d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff, d->Cout, d->out_ctot, d->out_coff,
-                      d->act, ceil_div(d->Wi, 16), d->gate_ctot, d->gate_c};
+                      d->act, ceil_div(d->Wi, 16), d->gate_ctot, d->gate_c, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0.0f, 0.0f, 0.0f};
         hipLaunchKernelGGL(conv5s1_small, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
                            (const float*)w_packed);
         return masic_launch_status("conv2d_fwd");
@@ -1045,4 +1092,23 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
 #undef IGEMM_LAUNCH
     }
     return masic_launch_status("conv2d_fwd");
+}
+
+// encoder2.pre_conv + pre_gdn and decoder2.after_gdn + cat + after_conv (MASIC.py:559-560, :574-576, :599-600, :617-621) as one
+// launch each: Conv2d / ConvTranspose2d(6 -> 3, k5, s1, p2) whose six input channels come from two 3-channel tensors (no
+// concat buffer), with an optional 3-channel (I)GDN on the first source while it is staged and / or on the result.
+extern "C" int masic_conv5s1_pair_fwd(const float* xa, const float* xb, const float* w_packed, const float* bias,
+                                      const float* gin_beta, const float* gin_gamma, int gin_inverse,
+                                      const float* gout_beta, const float* gout_gamma, int gout_inverse, double beta_min,
+                                      float* y, int B, int H, int W, void* stream) {
+    MASIC_REQUIRE(xa && xb && w_packed && y, MASIC_ERR_ARG, "conv5s1_pair_fwd: null pointer");
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0, MASIC_ERR_SHAPE, "conv5s1_pair_fwd: non-positive dimension");
+    MASIC_REQUIRE((gin_beta == nullptr) == (gin_gamma == nullptr) && (gout_beta == nullptr) == (gout_gamma == nullptr), MASIC_ERR_ARG,
+                  "conv5s1_pair_fwd: a GDN needs both beta and gamma");
+    const double ped = 0x1p-36;
+    Conv5s1Args a{xa, bias, nullptr, nullptr, y, 6, H, W, 3, 0, 3, 3, 0, MASIC_ACT_NONE, ceil_div(W, 16), 0, 0,
+                  xb, 3, gin_beta, gin_gamma, gin_inverse, gout_beta, gout_gamma, gout_inverse,
+                  (float)__builtin_sqrt(beta_min + ped), (float)__builtin_sqrt(ped), (float)ped};
+    hipLaunchKernelGGL(conv5s1_small, dim3(ceil_div(W, 16) * ceil_div(H, 16), B), dim3(256), 0, (hipStream_t)stream, a, (const float*)w_packed);
+    return masic_launch_status("conv5s1_pair_fwd");
 }

@@ -624,3 +624,18 @@ def conv2d_f16k_d2s(x16, packed, bias32, desc, C, out=None, out_coff=0):
     check(lib.masic_conv_f16k_d2s_fwd(_p(x16), _p(packed), _p(bias32), _p(out), C, out.shape[1], out_coff, ctypes.byref(desc), _stream()),
           "conv_f16k_d2s_fwd")
     return out
+
+
+def conv5s1_pair(xa, xb, packed, bias, gdn_in=None, gdn_out=None, beta_min=1e-6):
+    """Conv2d / ConvTranspose2d(6 -> 3, k5, s1, p2) on [xa | xb] (3 + 3 channels, no concat buffer) with an optional 3-channel
+    (I)GDN on xa while staging (gdn_in = (beta, gamma, inverse)) and / or on the result (gdn_out)."""
+    _dev(xa, "xa"); _dev(xb, "xb")
+    if xa.shape != xb.shape or xa.shape[1] != 3:
+        raise RuntimeError("masic_amd.conv5s1_pair: both sources must be [B, 3, H, W]")
+    B, _, H, W = xa.shape
+    y = torch.empty((B, 3, H, W), dtype=torch.float32, device=xa.device)
+    gi = (None, None, 0) if gdn_in is None else gdn_in
+    go = (None, None, 0) if gdn_out is None else gdn_out
+    check(lib.masic_conv5s1_pair_fwd(_p(xa), _p(xb), _p(packed), _p(bias), _p(gi[0]), _p(gi[1]), int(gi[2]), _p(go[0]), _p(go[1]), int(go[2]),
+                                     float(beta_min), _p(y), B, H, W, _stream()), "conv5s1_pair_fwd")
+    return y

@@ -442,3 +442,26 @@ def test_entropy_bottleneck_compress_decompress_vs_reference_streams():
     assert torch.equal(xh.cpu(), torch.from_numpy(G["eb_xhat"]))
     with pytest.raises(ValueError):
         eb.decompress(strings, x.shape[-2:])                          # the reference's one-stream-at-a-time shape check (:221-224)
+
+
+@pytest.mark.parametrize("transposed,where", [(False, "out"), (True, "in"), (False, "none")])
+def test_conv5s1_pair_with_fused_gdn3(transposed, where):
+    """encoder2.pre_conv + pre_gdn / decoder2.after_gdn + cat + after_conv as one launch on two 3-channel sources."""
+    ops = _ops()
+    from masic_amd import synth
+    B, H, W = 2, 37, 53
+    xa, xb = _rand(B, 3, H, W, seed=1), _rand(B, 3, H, W, seed=2)
+    w = _rand(*((6, 3, 5, 5) if transposed else (3, 6, 5, 5)), seed=3, scale=0.1)
+    b = _rand(3, seed=4, scale=0.1)
+    rs = np.random.RandomState(5)
+    beta, gamma = synth.synth_tensor("g.beta", (3,), rs), synth.synth_tensor("g.gamma", (3, 3), rs)
+    inv = transposed
+    src = O.gdn(xa, beta, gamma, inverse=inv) if where == "in" else xa
+    ref = _oracle_conv(torch.cat((src, xb), 1), w, b, 5, 1, transposed, False, 0, 0)
+    if where == "out":
+        ref = O.gdn(ref, beta, gamma, inverse=inv)
+    d = ops.make_conv_desc(B, 6, H, W, 3, 5, 5, 1, 2, transposed=transposed)
+    g = (beta.to(DEV), gamma.to(DEV), inv)
+    y = ops.conv5s1_pair(xa.to(DEV), xb.to(DEV), ops.pack_conv_weight(w.to(DEV), d), b.to(DEV),
+                         gdn_in=g if where == "in" else None, gdn_out=g if where == "out" else None)
+    assert_close(y, ref, f"conv5s1_pair gdn {where}")
