@@ -208,10 +208,16 @@ class _GmmHeads(nn.Module):
 
     def _branch_f16k(self, seq, xf, B, H, W, acts):
         """The same three layers as bf16 GEMMs; activations between them stay in the F16K layout on the device."""
-        t = _hip.gemm1x1_bf16(xf, seq[0].packed_gemm_weight(), seq[0].bias.detach(), B, seq[0].in_channels, seq[0].out_channels, H, W, acts[0])
-        t = _hip.gemm1x1_bf16(t, seq[2].packed_gemm_weight(), seq[2].bias.detach(), B, seq[2].in_channels, seq[2].out_channels, H, W, acts[1])
-        return _hip.gemm1x1_bf16(t, seq[4].packed_gemm_weight(), seq[4].bias.detach(), B, seq[4].in_channels, seq[4].out_channels, H, W,
-                                 acts[2], want_nchw=True)
+        t = xf
+        for i, (layer, act) in enumerate(zip((seq[0], seq[2], seq[4]), acts)):
+            last = i == 2
+            if layer.in_channels % 16 == 0 and layer.out_channels % 32 == 0:          # both operands staged by DMA
+                t = _hip.gemm_f16k(t, layer.packed_gemm_dma_weight(), layer.bias.detach(), B, layer.in_channels, layer.out_channels,
+                                   H, W, act, want_nchw=last)
+            else:                                                                      # register-streamed kernel (any width)
+                t = _hip.gemm1x1_bf16(t, layer.packed_gemm_weight(), layer.bias.detach(), B, layer.in_channels, layer.out_channels,
+                                      H, W, act, want_nchw=last)
+        return t
 
     def heads(self, x):
         from masic_amd import nn as _mnn

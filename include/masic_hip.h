@@ -103,6 +103,13 @@ int masic_gemm1x1_pack_weight(const float* w, void* wp, int Cin, int Cout, int t
 int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
                            int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
 
+/* The same 1x1 layers with both operands staged by DMA (masic_amd/csrc/conv_f16k.hip: gemm_f16k), Cin % 16 == 0 and
+ * Cout % 32 == 0; own weight pack (per 128-channel block, 64-channel chunks in LDS-image order). */
+size_t masic_gemm_f16k_packed_bytes(int Cin, int Cout);
+int masic_gemm_f16k_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream);
+int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
+                        int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * The same convolutions (nn.Conv2d / nn.ConvTranspose2d / MaskedConv2d of MASIC.py:510-622, :170-187, :690-700) with
  * the input -- and optionally the output -- in F16K: the bf16-operand forward keeps the 128/192-channel activations of

@@ -40,6 +40,9 @@ SIGNATURES = {
     "masic_f16k_bytes": (c_size_t, [c_int, c_int, c_int]),
     "masic_nchw_to_f16k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_nchw_to_f16k_op": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_gemm_f16k_packed_bytes": (c_size_t, [c_int, c_int]),
+    "masic_gemm_f16k_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "masic_gemm_f16k_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "masic_conv_f16k_supported": (c_int, [_P]),
     "masic_conv_f16k_kernel_name": (c_int, [_P, c_int, ctypes.c_char_p, c_size_t]),
     "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),

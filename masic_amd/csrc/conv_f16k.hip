@@ -896,3 +896,196 @@ extern "C" int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const 
     hipLaunchKernelGGL(conv_a_gdn_f16k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, (hipStream_t)stream, a);
     return masic_launch_status("conv_a_gdn_fwd");
 }
+
+// ------------------------------------------------------------------------------------------ 1x1 layers as DMA-staged GEMMs
+// The nine 1x1 (transposed) convolutions of each GMM head (MASIC.py:330-468) with the K-loop machinery of conv_f16k: the
+// register-streamed kernel of gemm_bf16.hip waits an L2 round trip every other k-step; here both operands are staged by
+// buffer_load ... lds three 64-channel chunks deep, with counted vmcnt and inline-asm LDS reads.
+//   tile 128 co x 256 px, 8 waves, wave w = all 128 co of pixels 32w .. 32w+31 (4 accumulator tiles)
+//   stage (48 KiB) = weights [k16 4][hh][co 128][8] (16 KiB, a linear copy of the packed stream) | activations [k16 4][hh][px 256][8]
+//   waves 0-3 fetch the weights (4 wave-instructions per chunk each), waves 4-7 the activations (8 each)
+namespace {
+
+struct GemmF16kArgs {
+    const unsigned short* x;      // F16K [B][Cin16][HW][16]
+    const unsigned short* w;      // per 128-co block: [chunk][k16 4][hh][co 128][8]
+    const float* bias;
+    unsigned short* y16;          // F16K [B][out_ctot/16][HW][16] or null
+    float* y32;                   // float32 NCHW view or null
+    int Cin16, nchunks, Cout, HW, out_ctot, out_coff, act;
+};
+
+__global__ void pack_gemm_f16k_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int nk16,
+                                      int ncb, int transposed) {
+    // [co block][k16][hh][co 128][8]: chunks of any KC consecutive k16 blocks are contiguous
+    const int nchunks = nk16;
+    const size_t total = (size_t)ncb * nk16 * 2048;                          // bf16 elements
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = (int)(r & 7); r >>= 3;
+        const int co = (int)(r & 127); r >>= 7;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int k16 = (int)(r % nchunks);
+        const int cb = (int)(r / nchunks);
+        const int ci = k16 * 16 + hh * 8 + e, cog = cb * 128 + co;
+        float v = 0.0f;
+        if (ci < Cin && cog < Cout) v = transposed ? w[(size_t)ci * Cout + cog] : w[(size_t)cog * Cin + ci];
+        const __bf16 bv = (__bf16)v;
+        wp[i] = __builtin_bit_cast(unsigned short, bv);
+    }
+}
+
+// KC: 16-channel blocks per chunk.  KC = 2 keeps a stage at 24 KiB: two workgroups per CU, which is what a grid of
+// 288 workgroups (nine 128-channel blocks x 32 pixel tiles) on 256 CUs needs.
+template <int KC>
+__global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16kArgs a) {
+    constexpr int ACT0 = KC * 4096, STAGE = KC * 12288, NS = 3;
+    constexpr int WPW = KC, APW = 2 * KC;                                    // weight / activation DMA pieces per wave per chunk
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const bool wrole = wave < 4;
+    const int wq = wave & 3;
+    const int p0 = blockIdx.x * 256, m0 = blockIdx.y * 128, b = blockIdx.z;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)b * a.Cin16 * a.HW * 16), 0, a.Cin16 * a.HW * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + (size_t)blockIdx.y * a.nchunks * (KC * 2048)), 0, a.nchunks * (KC * 4096), 0x00020000);
+    // activation pieces of this wave: piece I = k*4 + wq, k < 8: k16 = I >> 3, hh = (I >> 2) & 1, pixel block = I & 3 = wq
+    const int px = wq * 64 + lane;
+    const int avoff = p0 + px < a.HW ? px * 32 : 0x7ffffff0;                  // + hh*16 per piece
+    auto issue = [&](int c, int stage) {
+        unsigned char* st = lds + stage * STAGE;
+        if (wrole) {
+#pragma unroll
+            for (int k = 0; k < WPW; ++k) dma_buf16(rw, st + (k * 4 + wq) * 1024, lane * 16, c * (KC * 4096) + (k * 4 + wq) * 1024);
+        } else {
+#pragma unroll
+            for (int k = 0; k < APW; ++k) {
+                const int k16 = k >> 1, hh = k & 1;                           // I = k*4 + wq -> (I >> 3, (I >> 2) & 1)
+                dma_buf16(rx, st + ACT0 + k16 * 8192 + hh * 4096 + wq * 1024, avoff + hh * 16, ((c * KC + k16) * a.HW + p0) * 32);
+            }
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+    issue(0, 0);
+    issue(1, 1);
+    if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned al = ldsb + (h * 128 + j) * 16, bl = ldsb + ACT0 + (h * 256 + wave * 32 + j) * 16;
+    int cs = 0, ps = 2;                                                      // consumer / producer stage
+    for (int c = 0; c < a.nchunks; ++c) {
+        issue(c + 2, ps);                                                     // past the end: reads as zeros into a free stage
+        ps = ps == NS - 1 ? 0 : ps + 1;
+        const unsigned wa = al + cs * STAGE, ba = bl + cs * STAGE;
+        v4u af[2][4], bfr[2];
+        auto request = [&](auto ic, auto bc) {
+            constexpr int i = decltype(ic)::value, buf = decltype(bc)::value;
+            ds_read128<i * 8192>(bfr[buf], ba);
+            static_for<0, 4>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                ds_read128<i * 4096 + m * 512>(af[buf][m], wa);
+            });
+        };
+        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, KC>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, buf = i & 1;
+            if constexpr (i + 1 < KC) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+            lgkm_wait<(i + 1 < KC ? 5 : 0)>(bfr[buf], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
+            static_for<0, 4>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
+            });
+        });
+        cs = cs == NS - 1 ? 0 : cs + 1;
+        if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");   // chunk c+1 has landed, chunk c+2 may stay in flight
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: bias + activation -> F16K or float32 NCHW view
+    if (a.bias != nullptr) {
+        const float* bp = a.bias + m0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) {
+                float bv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] += bv[e];
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = apply_act(acc[m][e], a.act);
+    const int p = p0 + wave * 32 + j;
+    if (p >= a.HW) return;
+    if (a.y32 != nullptr) {
+        float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * a.HW + p;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)a.HW] = acc[m][e];
+            }
+    } else {
+        const int c16 = (a.out_coff + m0) >> 4;
+        unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * a.HW + p) * 16 + 8 * h;
+        const unsigned op16 = (unsigned)a.HW * 16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t masic_gemm_f16k_packed_bytes(int Cin, int Cout) {
+    return (size_t)ceil_div(Cout, 128) * round_up(ceil_div(Cin, 16), 4) * 4096;
+}
+
+extern "C" int masic_gemm_f16k_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream) {
+    MASIC_REQUIRE(w && wp && Cin > 0 && Cout > 0, MASIC_ERR_ARG, "gemm_f16k_pack_weight: bad argument");
+    const int nchunks = round_up(ceil_div(Cin, 16), 4), ncb = ceil_div(Cout, 128);          // k16 blocks, padded to a multiple of 4
+    const size_t total = (size_t)ncb * nchunks * 2048;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_gemm_f16k_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wp, Cin, Cout, nchunks, ncb, transposed);
+    return masic_launch_status("gemm_f16k_pack_weight");
+}
+
+// y = act(W x + b), x in F16K with Cin a multiple of 16; output F16K (y_f16k: out_ctot channels, written at out_coff) or a
+// float32 NCHW channel view (y_nchw).  Cout must be a multiple of 32.
+extern "C" int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
+                                   int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream) {
+    MASIC_REQUIRE(x_f16k && w_packed && ((y_f16k != nullptr) != (y_nchw != nullptr)), MASIC_ERR_ARG, "gemm_f16k_fwd: need input, weights and exactly one output");
+    MASIC_REQUIRE(B > 0 && HW > 0 && Cin % 16 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED, "gemm_f16k_fwd: needs Cin %% 16 == 0 and Cout %% 32 == 0");
+    MASIC_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot && (y_nchw != nullptr || (out_ctot % 16 == 0 && out_coff % 16 == 0)), MASIC_ERR_SHAPE,
+                  "gemm_f16k_fwd: output channel view");
+    MASIC_REQUIRE((long)(Cin / 16) * HW * 32 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_f16k_fwd: activation plane too large for 32-bit offsets");
+    const int Cin16 = Cin / 16, nk16 = round_up(Cin16, 4);
+    dim3 grid(ceil_div(HW, 256), ceil_div(Cout, 128), B);
+    // two co-resident workgroups per CU (32-channel chunks) unless the grid is a whole number of single-workgroup rounds anyway
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    const bool kc2 = blocks % 256 != 0 || blocks < 256;
+    GemmF16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (unsigned short*)y_f16k, y_nchw,
+                   Cin16, nk16 / (kc2 ? 2 : 4), Cout, HW, out_ctot, out_coff, act};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_f16k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_f16k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (kc2) hipLaunchKernelGGL(gemm_f16k<2>, grid, dim3(512), 3 * 2 * 12288, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_f16k<4>, grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
+    return masic_launch_status("gemm_f16k_fwd");
+}

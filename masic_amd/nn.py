@@ -152,6 +152,16 @@ class _PackedWeightMixin:
                             gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
         return y, desc.Ho, desc.Wo
 
+    def packed_gemm_dma_weight(self):
+        """Per-128-channel-block k16-major pack of a 1x1 layer for the DMA-staged GEMM (conv_f16k.hip: gemm_f16k)."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        cache = self.__dict__.get("_packed_gemm_dma_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.pack_gemm_f16k_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))
+            self.__dict__["_packed_gemm_dma_cache"] = cache
+        return cache[1]
+
     def invalidate_packed_weight(self):
         self.__dict__.pop("_packed_cache", None)
 

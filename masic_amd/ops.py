@@ -639,3 +639,25 @@ def conv5s1_pair(xa, xb, packed, bias, gdn_in=None, gdn_out=None, beta_min=1e-6)
     check(lib.masic_conv5s1_pair_fwd(_p(xa), _p(xb), _p(packed), _p(bias), _p(gi[0]), _p(gi[1]), int(gi[2]), _p(go[0]), _p(go[1]), int(go[2]),
                                      float(beta_min), _p(y), B, H, W, _stream()), "conv5s1_pair_fwd")
     return y
+
+
+def pack_gemm_f16k_weight(weight, Cin, Cout, transposed):
+    _dev(weight, "weight")
+    wp = torch.empty(lib.masic_gemm_f16k_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_gemm_f16k_pack_weight(_p(weight), _p(wp), Cin, Cout, int(transposed), _stream()), "gemm_f16k_pack_weight")
+    return wp
+
+
+def gemm_f16k(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_coff=0, want_nchw=False):
+    """DMA-staged form of gemm1x1_bf16 (same arguments and results); needs Cin % 16 == 0 and Cout % 32 == 0."""
+    HW = H * W
+    y16 = y32 = None
+    if want_nchw or out_nchw is not None:
+        y32 = out_nchw if out_nchw is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_f16k.device)
+        out_ctot = y32.shape[1]
+    else:
+        out_ctot = (Cout + 15) // 16 * 16
+        y16 = torch.empty(B * out_ctot * HW, dtype=torch.int16, device=x_f16k.device)
+    check(lib.masic_gemm_f16k_fwd(_p(x_f16k), _p(wp), _p(bias), _p(y16), _p(y32), B, Cin, Cout, HW, out_ctot, out_coff, int(act), _stream()),
+          "gemm_f16k_fwd")
+    return y32 if y32 is not None else y16

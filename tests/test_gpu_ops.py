@@ -465,3 +465,29 @@ def test_conv5s1_pair_with_fused_gdn3(transposed, where):
     y = ops.conv5s1_pair(xa.to(DEV), xb.to(DEV), ops.pack_conv_weight(w.to(DEV), d), b.to(DEV),
                          gdn_in=g if where == "in" else None, gdn_out=g if where == "out" else None)
     assert_close(y, ref, f"conv5s1_pair gdn {where}")
+
+
+@pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W,tr", [(2, 768, 1152, 960, 16, 24, True), (1, 960, 1152, 768, 8, 12, False), (3, 64, 96, 32, 5, 7, False)])
+def test_gemm_f16k_dma_stack(B, Cin, Cmid, Cout, H, W, tr):
+    """The DMA-staged GEMM of the head layers (conv_f16k.hip: gemm_f16k, both chunk sizes): two chained layers against the
+    float32 oracle on bf16-rounded operands, and bit-identical to the register-streamed kernel."""
+    ops = _ops()
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    w0 = _rand(*((Cin, Cmid) if tr else (Cmid, Cin)), seed=2, scale=(2.0 / Cin) ** 0.5)
+    b0 = _rand(Cmid, seed=3, scale=0.1)
+    w1 = _rand(Cout, Cmid, seed=4, scale=(2.0 / Cmid) ** 0.5)
+    b1 = _rand(Cout, seed=5, scale=0.1)
+    q = lambda t: t.bfloat16().float()
+    w0c = (q(w0).t() if tr else q(w0)).reshape(Cmid, Cin, 1, 1)
+    mid = F.leaky_relu(F.conv2d(q(x), w0c, b0))
+    ref = F.relu(F.conv2d(q(mid), q(w1).reshape(Cout, Cmid, 1, 1), b1))
+    xf = ops.nchw_to_f16k(x.to(DEV))
+    t = ops.gemm_f16k(xf, ops.pack_gemm_f16k_weight(w0.to(DEV), Cin, Cmid, tr), b0.to(DEV), B, Cin, Cmid, H, W, ops.ACT_LEAKY)
+    y = ops.gemm_f16k(t, ops.pack_gemm_f16k_weight(w1.to(DEV), Cmid, Cout, False), b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, want_nchw=True)
+    assert_close(y, ref, "gemm_f16k stack", rtol=1e-3)
+    t0 = ops.gemm1x1_bf16(xf, ops.pack_gemm1x1_weight(w0.to(DEV), Cin, Cmid, tr), b0.to(DEV), B, Cin, Cmid, H, W, ops.ACT_LEAKY)
+    y0 = ops.gemm1x1_bf16(t0, ops.pack_gemm1x1_weight(w1.to(DEV), Cmid, Cout, False), b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, want_nchw=True)
+    assert torch.equal(y, y0), "same k order, same rounding: the two GEMM kernels must agree bit for bit"
+    out = torch.full((B, Cout + 40, H, W), 3.0, device=DEV)
+    ops.gemm_f16k(t, ops.pack_gemm_f16k_weight(w1.to(DEV), Cmid, Cout, False), b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, out_nchw=out, out_coff=8)
+    assert torch.equal(out[:, 8:8 + Cout], y) and torch.all(out[:, :8] == 3.0) and torch.all(out[:, 8 + Cout:] == 3.0)

@@ -13,4 +13,14 @@ for cin, cout in ((768, 1152), (1152, 768), (768, 960), (960, 1152), (1152, 960)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): ops.gemm1x1_bf16(xf, wp, b, B, cin, cout, H, W, ops.ACT_RELU)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
-    print(f"{cin}->{cout}: {dt * 1e6:6.1f} us  {2.0 * B * H * W * cin * cout / dt / 1e12:6.1f} TF")
+    ref = ops.gemm1x1_bf16(xf, wp, b, B, cin, cout, H, W, ops.ACT_RELU, want_nchw=True)
+    wp2 = ops.pack_gemm_f16k_weight(w, cin, cout, False)
+    y2 = ops.gemm_f16k(xf, wp2, b, B, cin, cout, H, W, ops.ACT_RELU, want_nchw=True)
+    err = float((y2 - ref).abs().max() / ref.abs().max())
+    y16a = ops.gemm1x1_bf16(xf, wp, b, B, cin, cout, H, W, ops.ACT_RELU); y16b = ops.gemm_f16k(xf, wp2, b, B, cin, cout, H, W, ops.ACT_RELU)
+    same16 = bool((y16a == y16b).float().mean() > 0.999)
+    for _ in range(3): ops.gemm_f16k(xf, wp2, b, B, cin, cout, H, W, ops.ACT_RELU)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): ops.gemm_f16k(xf, wp2, b, B, cin, cout, H, W, ops.ACT_RELU)
+    torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 50
+    print(f"{cin}->{cout}: register-streamed {dt * 1e6:6.1f} us {2.0 * B * H * W * cin * cout / dt / 1e12:6.1f} TF | dma {dt2 * 1e6:6.1f} us {2.0 * B * H * W * cin * cout / dt2 / 1e12:6.1f} TF | rel diff {err:.1e} f16k same {same16}")
