@@ -644,15 +644,12 @@ class HSIC(CompressionModel):
     #   main : encoder1 -> h_a1, EB1, h_s1_up (ctx1 on stream B) -> heads1 -> decoder1 -> warp -> encoder1(x1_hat_warp)
     #          -> [join] quantize into cat2 -> heads2 -> decoder2
     #   A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, ctx2
-    # masic_amd/graph.py captures the segments as three HIP graphs (A; main up to the join; the tail) so that A and the main
-    # chain start together on their own streams.
+    # (Split into functions so that a caller can capture or schedule the segments separately; masic_amd/graph.py captures
+    # _forward_eval as a whole -- three graphs on explicit streams measured the same.)
     def _eval_right_branch(self, x1, x2, m_fwd, m_back):
         M = self.M
         B, _, H, W = x1.shape
-        pair = torch.empty((B, 6, H, W), dtype=x1.dtype, device=x1.device)           # x1_warp | x2
-        _hip.warp_perspective(x1, m_fwd, (H, W), out=pair, out_coff=0)
-        _hip.copy_view(x2, pair, 3)
-        y2 = self.encoder2.forward_pair(pair)
+        y2 = self.encoder2.forward_views(_hip.warp_perspective(x1, m_fwd, (H, W)), x2)
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
         h, w = y2.shape[-2:]
