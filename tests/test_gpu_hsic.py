@@ -336,3 +336,46 @@ def test_bf16_operand_path_config1_accuracy_streams_and_graph():
     assert max(int((sym[k].cpu().to(torch.int64) - osym[k].to(torch.int64)).abs().max()) for k in osym) <= 1
     print(f"bf16 config1: {bad}/{total} symbols differ from the float32 reference ({100.0 * bad / total:.2f} %)")
     assert bad <= 0.06 * total
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 512, 512), (2, 512, 896)])
+def test_full_size_properties_bf16_vs_f32_paths(B, H, W):
+    """BASELINE config shapes (no CPU oracle at this size): size-independent properties -- the bf16-operand path is
+    deterministic, replays from a HIP graph bit for bit, keeps likelihoods in (0, 1] and masks in [0, 1], and stays within
+    fixed codec-level bounds of the float32 parity path (rate within 0.5 %, PSNR within 0.05 dB, symbols off by at most 1)."""
+    import MASIC
+    from masic_amd import nn as mnn, synth
+    from masic_amd.graph import GraphedHSIC
+    from masic_amd.loss import rate_distortion
+    N, M, K = 128, 192, 5
+    sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=100)
+    net = _model(N, M, K, sd).eval()
+    x1, x2, hm = (t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=100))
+    with torch.no_grad():
+        out_f = net(x1, x2, hm)
+        sym_f = net.symbol_streams(x1, x2, hm)
+        crit_f = rate_distortion(out_f, x1, x2, 0.01)
+        mnn.set_precision("bf16")
+        try:
+            out = net(x1, x2, hm)
+            again = net(x1, x2, hm)
+            sym = net.symbol_streams(x1, x2, hm)
+            crit = rate_distortion(out, x1, x2, 0.01)
+            rep = GraphedHSIC(net, x1, x2, hm)(x1, x2, hm)
+            torch.cuda.synchronize()
+            for k in ("x1_hat", "x2_hat", "y1_hat"):
+                assert torch.equal(out[k], again[k]) and torch.equal(out[k], rep[k]), k
+        finally:
+            mnn.set_precision("f32")
+    for k, v in out["likelihoods"].items():
+        assert float(v.min()) > 0.0 and float(v.max()) <= 1.0 + 1e-6, k
+    for k in ("x1_mask_R", "x1_mask_L"):
+        assert float(out[k].min()) >= 0.0 and float(out[k].max()) <= 1.0 + 1e-5
+        assert torch.equal(out[k], out_f[k])                       # the warp path is float32 in both
+    assert abs(float(crit["bpp_loss"]) / float(crit_f["bpp_loss"]) - 1.0) < 5e-3
+    for k in ("psnr1", "psnr2"):
+        assert abs(float(crit[k]) - float(crit_f[k])) < 0.05, (k, float(crit[k]), float(crit_f[k]))
+    total = sum(v.numel() for v in sym_f.values())
+    bad = sum(int((sym[k] != sym_f[k]).sum()) for k in sym_f)
+    assert max(int((sym[k].to(torch.int64) - sym_f[k].to(torch.int64)).abs().max()) for k in sym_f) <= 1
+    assert bad <= 0.06 * total, (bad, total)
