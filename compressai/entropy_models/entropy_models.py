@@ -172,8 +172,15 @@ class EntropyBottleneck(EntropyModel):
     def _table(self, differentiable=False):
         if differentiable:      # torch.cat is tracked: autograd routes the table gradient back to the 14 parameters
             return _hip.eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
-        return _hip.eb_param_table([m.detach() for m in self._matrices], [b.detach() for b in self._biases],
-                                   [f.detach() for f in self._factors])
+        # inference: the [C, 58] table only changes with the parameters -- rebuilt per parameter version, not per forward
+        params = list(self._matrices) + list(self._biases) + list(self._factors)
+        key = tuple((p._version, p.data_ptr()) for p in params)
+        cache = self.__dict__.get("_table_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, _hip.eb_param_table([m.detach() for m in self._matrices], [b.detach() for b in self._biases],
+                                              [f.detach() for f in self._factors]))
+            self.__dict__["_table_cache"] = cache
+        return cache[1]
 
     def loss(self):
         """sum |logits(quantiles) - target| with all density parameters detached (reference :345-348)."""
