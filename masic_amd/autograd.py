@@ -45,14 +45,14 @@ class ConvFn(Function):
         B, Cin, Hi, Wi = x.shape
         Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
         gx = gw = gb = None
+        from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
         if ctx.needs_input_grad[0]:
-            from . import nn as _mnn      # input gradients use the forward's operand precision; weight gradients stay f32
             d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
             if (d.Ho, d.Wo) != (Hi, Wi):
                 raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
             gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
         if ctx.needs_input_grad[1]:
-            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=PREC_F32)
+            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
             gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = ops.channel_sum(g)
@@ -95,7 +95,9 @@ class GdnFn(Function):
         d_t = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, transposed=True)
         u = ops.conv2d(t, ops.pack_conv_weight(w4, d_t), None, d_t)
         gx = ops.gdn_bwd_post(x, s, u) if ctx.needs_input_grad[0] else None
-        g_gam = ops.conv2d_wgrad(x2, t, d_f, (C, C, 1, 1)).view(C, C)
+        from . import nn as _mnn
+        d_w = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, prec=_mnn._PRECISION)
+        g_gam = ops.conv2d_wgrad(x2, t, d_w, (C, C, 1, 1)).view(C, C)
         g_bet = ops.channel_sum(t)
         g_gamma = ops.elementwise(ops.EW_REPARAM_BWD, g_gam, gamma.detach().contiguous(), g_bound)
         g_beta = ops.elementwise(ops.EW_REPARAM_BWD, g_bet, beta.detach().contiguous(), b_bound)

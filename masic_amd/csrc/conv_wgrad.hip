@@ -42,7 +42,20 @@ constexpr int PS = 65;    // P-tile channel pitch (64 pixels + 1)
 
 // 8 waves: wave = (wa: which 32 of the 64 a-channels, u: tap group [QT == 1] or 32-wide q sub-tile [QT == 4])
 //   T = KH*KW taps; QT q sub-tiles of 32 per block; each wave accumulates TPW taps of one 32a x 32q tile
-template <int QT, int TPW>
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive pixels of one channel from an LDS tile (stride `st` floats between pixels) as a bf16 MFMA fragment
+__device__ __forceinline__ wbf16x8 frag8(const float* p, int st) {
+    wbf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (__bf16)p[i * st];
+    return f;
+}
+
+// BF16: operands rounded to bf16 while they are read from the (float32) LDS tiles, v_mfma_f32_32x32x16_bf16 with
+// k = 16 consecutive pixels of a row (lane half h takes pixels 8h .. 8h+7), float32 accumulate -- the training step of the
+// bf16-operand mode; the float32 form (k = a pixel pair, exact products) is the parity path.
+template <int QT, int TPW, bool BF16>
 __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -112,6 +125,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
         float* cur = lds + (it & 1) * buf_sz;
         __syncthreads();                                   // this tile landed; everyone left the other buffer
         if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        if constexpr (BF16) {
+            const float* pa = cur + (wa * 32 + j) * PS;
+            const float* qa = cur + 64 * PS + (qsub * 32 + j) * a.QS;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int px = 16 * ks + 8 * h;             // this lane's 8 pixels: one row, columns cc .. cc+7
+                const int rr = px >> 5, cc = px & 31;
+                const wbf16x8 af = frag8(pa + px, 1);
+                const float* qrow = qa + (rr * a.s) * a.PWq + cc * a.s;
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+                    if (t_lo + k < t_hi) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, frag8(qrow + toff[k], a.s), acc[k], 0, 0, 0);
+            }
+            continue;
+        }
         const float* pa = cur + (wa * 32 + j) * PS + h;
         const float* qa = cur + 64 * PS + (qsub * 32 + j) * a.QS + h * a.s;
         for (int kk = 0; kk < 32; ++kk) {
@@ -149,7 +177,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
 // B operand enumerate (tap, q) pairs -- column n = t*CQ + q, T*CQ columns in all -- so a 5x5 kernel over 3 channels is
 // 75 columns = 3 MFMA column tiles instead of 25.  Wave = (which 32 a-channels, column-tile group); everything else
 // (pixel tiles, DMA double buffering, odd channel pitch, atomic reduction into [tap][a][q]) as above.
-template <int TPW>
+template <int TPW, bool BF16>
 __global__ __launch_bounds__(512) void conv_wgrad_packed_f32(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int buf_sz = 64 * PS + a.CQ * a.QS;
@@ -214,6 +242,28 @@ __global__ __launch_bounds__(512) void conv_wgrad_packed_f32(const WgradArgs a) 
         float* cur = lds + (it & 1) * buf_sz;
         __syncthreads();
         if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        if constexpr (BF16) {
+            const float* pa = cur + (wa * 32 + j) * PS;
+            const float* qa = cur + 64 * PS;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int px = 16 * ks + 8 * h;
+                const int rr = px >> 5, cc = px & 31;
+                const wbf16x8 af = frag8(pa + px, 1);
+                const float* qrow = qa + (rr * a.s) * a.PWq + cc * a.s;
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+                    if ((u + 4 * k) * 32 < NCOL) {
+                        wbf16x8 bf = frag8(qrow + coloff[k], a.s);
+                        if (colidx[k] < 0) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bf[i] = (__bf16)0.0f;
+                        }
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[k], 0, 0, 0);
+                    }
+            }
+            continue;
+        }
         const float* pa = cur + (wa * 32 + j) * PS + h;
         const float* qa = cur + 64 * PS + h * a.s;
         for (int kk = 0; kk < 32; ++kk) {
@@ -264,6 +314,7 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
     MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: stride %d", d->stride);
     MASIC_REQUIRE(d->in_coff >= 0 && d->in_coff + d->Cin <= d->in_ctot, MASIC_ERR_SHAPE, "conv2d_wgrad: input view out of range");
     hipStream_t st = (hipStream_t)stream;
+    const bool bf16 = d->prec == MASIC_PREC_BF16;      // operands rounded to bf16, float32 accumulate (training in the bf16-operand mode)
     WgradArgs a{};
     a.ws = (float*)workspace;
     a.B = d->B; a.s = d->stride; a.pad = d->pad; a.KH = d->KH;
@@ -297,8 +348,11 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         a.nsplit = nsplit < 1 ? 1 : nsplit;
         const size_t lds = (size_t)2 * (64 * PS + a.CQ * a.QS) * sizeof(float);
         dim3 grid(a_tiles, 1, a.nsplit);
-        if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_packed_f32<2>), grid, dim3(512), lds, st, a);
+        if (bf16) {
+            if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1, true>), grid, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_packed_f32<2, true>), grid, dim3(512), lds, st, a);
+        } else if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1, false>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_packed_f32<2, false>), grid, dim3(512), lds, st, a);
     } else {
         const int QT = Tt == 1 ? 4 : 1;                     // 1x1: four q sub-tiles per block; else four tap groups
         a.q_tiles = ceil_div(a.CQ, 32 * QT);
@@ -309,9 +363,13 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         const size_t lds = (size_t)2 * (64 * PS + 32 * QT * a.QS) * sizeof(float);
         MASIC_REQUIRE(lds <= 160 * 1024, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: tile does not fit LDS");
         dim3 grid(a_tiles * a.q_tiles, 1, a.nsplit);
-        if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1>), grid, dim3(512), lds, st, a);
-        else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_f32<1, 7>), grid, dim3(512), lds, st, a);
+        if (bf16) {
+            if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1, true>), grid, dim3(512), lds, st, a);
+            else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3, true>), grid, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_f32<1, 7, true>), grid, dim3(512), lds, st, a);
+        } else if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1, false>), grid, dim3(512), lds, st, a);
+        else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3, false>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_f32<1, 7, false>), grid, dim3(512), lds, st, a);
     }
     const int T = d->KH * d->KW, AQ = a.CA * a.CQ;
     const size_t total = (size_t)T * AQ;

@@ -75,6 +75,29 @@ def test_conv_backward(case):
     assert_close(mod.bias.grad, br.grad, name + ":db", GTOL)
 
 
+@pytest.mark.parametrize("case", CONV_BWD_CASES, ids=[c[0] for c in CONV_BWD_CASES])
+def test_conv_wgrad_bf16_operands(case):
+    """The bf16-operand weight gradient (training in the bf16 mode) == the float32 kernel run on bf16-rounded operands:
+    rounding happens once per operand and every product / the accumulation stay float32, so the two agree to float32
+    summation-order noise; against the unrounded float32 gradient the difference is bf16 rounding noise (<= 1e-2 of the peak)."""
+    from masic_amd import ops
+    from masic_amd._lib import PREC_BF16, PREC_F32
+    name, B, Cin, H, W, Cout, k, s, tr, masked, act = case
+    pad = k // 2
+    x = _rand(B, Cin, H, W, seed=11, scale=2.0).to(DEV)
+    d32 = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, pad, transposed=tr, prec=PREC_F32)
+    d16 = ops.make_conv_desc(B, Cin, H, W, Cout, k, k, s, pad, transposed=tr, prec=PREC_BF16)
+    dy = _rand(B, Cout, d32.Ho, d32.Wo, seed=12).to(DEV)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    got = ops.conv2d_wgrad(x, dy, d16, wshape)
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    want = ops.conv2d_wgrad(rnd(x), rnd(dy), d32, wshape)
+    full = ops.conv2d_wgrad(x, dy, d32, wshape)
+    peak = float(full.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * peak + 1e-6, name
+    assert float((got - full).abs().max()) <= 1e-2 * peak, name
+
+
 @pytest.mark.parametrize("C,H,W,inverse", [(128, 16, 32, False), (128, 8, 8, True), (3, 32, 48, False), (3, 24, 40, True), (16, 8, 12, False)])
 def test_gdn_backward(C, H, W, inverse):
     from compressai.layers import GDN

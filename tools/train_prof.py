@@ -1,5 +1,6 @@
 import sys, os, time, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'coremasic', 'mywork'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coremasic', 'mywork'))
 import MASIC
 from masic_amd import synth, nn as mnn
 from masic_amd.train import make_optimizers, train_step
