@@ -208,7 +208,7 @@ def main():
             tt = float(t.item())
         train_info = {"value": world * B * args.train_steps / tt, "unit": "stereo pairs/s", "steps": args.train_steps,
                       "ms_per_step": tt / args.train_steps * 1e3, "loss_after": float(crit["loss"]),
-                      "what": f"forward ({args.precision} operands) + RD loss + backward (f32)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
+                      "what": f"forward ({args.precision} operands) + RD loss + backward ({args.precision} operands, f32 accumulate)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                               " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146)"}
 
     if rank == 0:

@@ -287,6 +287,15 @@ int masic_softmax_k_bwd(const float* g, const float* y, float* gx, int B, int M,
  *   post: dx = s + 2 x u,  u = gamma^T t */
 int masic_gdn_bwd_pre(const float* x, const float* nrm, const float* g, float* s, float* t, size_t n, int inverse, void* stream);
 int masic_gdn_bwd_post(const float* x, const float* s, const float* u, float* dx, size_t n, void* stream);
+/* The whole GDN / inverse-GDN backward (gdn.py:77-92 under autograd, C = 128) in one pass over x and g = dL/dy, bf16
+ * operands on the matrix cores with float32 accumulation -- the training step of the bf16-operand mode; the pieces above
+ * remain the float32 parity path.  beta, gamma: the STORED tensors; g_beta [128], g_gamma [128][128]: gradients with
+ * respect to them (NonNegativeParametrizer + LowerBound rules, parametrizers.py:61-64, bound_ops.py:40-42, included).
+ * workspace: masic_gdn_bwd_fused_workspace_bytes() bytes of device memory. */
+size_t masic_gdn_bwd_fused_workspace_bytes(void);
+int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const float* gamma, float* gx,
+                        float* g_beta, float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse,
+                        double beta_min, void* stream);
 /* GaussianMixtureConditional_gf backward (entropy_models.py:808-858 + both LowerBound rules, bound_ops.py:40-42).
  * y_hat as returned by the forward; g_yhat may be NULL; weights_are_logits as in the forward. */
 int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,

@@ -75,13 +75,17 @@ class GdnFn(Function):
         x = _c(x)
         ctx.inverse, ctx.beta_min = inverse, beta_min
         ctx.save_for_backward(x, beta, gamma)
-        return ops.gdn(x, beta.detach(), gamma.detach(), inverse=inverse, beta_min=beta_min)
+        from . import nn as _mnn          # bf16 mode: the three-product bf16 split (float32-level accuracy at the HBM roofline)
+        return ops.gdn(x, beta.detach(), gamma.detach(), inverse=inverse, beta_min=beta_min, prec=_mnn._PRECISION)
 
     @staticmethod
     def backward(ctx, g):
         x, beta, gamma = ctx.saved_tensors
         g = _c(g)
         B, C, H, W = x.shape
+        from . import nn as _mnn
+        if C == 128 and _mnn._PRECISION != PREC_F32:       # bf16-operand mode: the whole backward in one kernel
+            return ops.gdn_bwd_fused(x, g, beta.detach(), gamma.detach(), ctx.inverse, ctx.beta_min) + (None, None)
         b_bound = float(torch.tensor((ctx.beta_min + PEDESTAL) ** 0.5, dtype=torch.float32))
         g_bound = float(torch.tensor(PEDESTAL ** 0.5, dtype=torch.float32))
         ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))
@@ -95,7 +99,6 @@ class GdnFn(Function):
         d_t = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, transposed=True)
         u = ops.conv2d(t, ops.pack_conv_weight(w4, d_t), None, d_t)
         gx = ops.gdn_bwd_post(x, s, u) if ctx.needs_input_grad[0] else None
-        from . import nn as _mnn
         d_w = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, prec=_mnn._PRECISION)
         g_gam = ops.conv2d_wgrad(x2, t, d_w, (C, C, 1, 1)).view(C, C)
         g_bet = ops.channel_sum(t)

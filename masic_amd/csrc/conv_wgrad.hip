@@ -290,6 +290,93 @@ __global__ __launch_bounds__(512) void conv_wgrad_packed_f32(const WgradArgs a) 
     }
 }
 
+// ---- 1x1 layers in the bf16-operand mode (the nine-layer entropy-parameter stacks: 18 weight gradients per step):
+// a plain GEMM dW[a][q] = sum_px P[a][px] Q[q][px] with k = pixel.  Workgroup (4 waves) = a 128 x 128 block of dW over a
+// strided share of the 64-pixel K tiles; wave = 64 x 64 (2 x 2 accumulators).  A thread fetches 16-byte runs (4 pixels of a
+// channel row) of the next K tile into registers while the current one is contracted, rounds them to bf16 and lays them
+// out [channel][64 px] in LDS with a 144-byte pitch (a ds_read_b128 of 16 channels x 8 pixels is conflict-free).
+// v_mfma_f32_32x32x16_bf16, float32 accumulate; the partial blocks are added into dW (zeroed first) with float atomics.
+struct Wgrad1x1Args {
+    const float* P; const float* Q; float* dw;
+    int CA, CQ, p_ctot, p_coff, q_ctot, q_coff, HW, ntk, nsplit, q_tiles;
+};
+
+constexpr int W1_PITCH = 144;
+
+__global__ __launch_bounds__(256) void conv_wgrad_1x1_bf16(const Wgrad1x1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * W1_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = w & 1, wq = w >> 1, j = lane & 31, h = lane >> 5;
+    const int a0 = (blockIdx.x / a.q_tiles) * 128, q0 = (blockIdx.x % a.q_tiles) * 128;
+    const int lr = tid >> 4, lc = tid & 15;                 // this thread's rows lr + 16 i, pixels 4 lc .. 4 lc + 3
+    const int tpi = a.HW >> 6;                              // K tiles per image
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][0][e] = 0.0f; acc[0][1][e] = 0.0f; acc[1][0][e] = 0.0f; acc[1][1][e] = 0.0f; }
+
+    float4 ra[8], rb[8];
+    auto fetch = [&](int kt) {
+        const int b = kt / tpi, px = (kt - b * tpi) * 64 + 4 * lc;
+        const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * a.HW + px;
+        const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * a.HW + px;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ca = a0 + lr + 16 * i, cq = q0 + lr + 16 * i;
+            ra[i] = ca < a.CA ? *reinterpret_cast<const float4*>(pb + (size_t)ca * a.HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = cq < a.CQ ? *reinterpret_cast<const float4*>(qb + (size_t)cq * a.HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16x4_t va, vb;
+            va[0] = (__bf16)ra[i].x; va[1] = (__bf16)ra[i].y; va[2] = (__bf16)ra[i].z; va[3] = (__bf16)ra[i].w;
+            vb[0] = (__bf16)rb[i].x; vb[1] = (__bf16)rb[i].y; vb[2] = (__bf16)rb[i].z; vb[3] = (__bf16)rb[i].w;
+            *reinterpret_cast<bf16x4_t*>(lds + (lr + 16 * i) * W1_PITCH + lc * 8) = va;
+            *reinterpret_cast<bf16x4_t*>(lds + 128 * W1_PITCH + (lr + 16 * i) * W1_PITCH + lc * 8) = vb;
+        }
+    };
+
+    int kt = blockIdx.z;
+    if (kt < a.ntk) fetch(kt);
+    const unsigned char* pa = lds + (64 * wa + j) * W1_PITCH + 16 * h;
+    const unsigned char* pq = lds + 128 * W1_PITCH + (64 * wq + j) * W1_PITCH + 16 * h;
+    for (; kt < a.ntk; kt += a.nsplit) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        stash();
+        __syncthreads();
+        if (kt + a.nsplit < a.ntk) fetch(kt + a.nsplit);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            wbf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = __builtin_bit_cast(wbf16x8, *reinterpret_cast<const uint4*>(pa + i * 32 * W1_PITCH + 32 * ks));
+                fb[i] = __builtin_bit_cast(wbf16x8, *reinterpret_cast<const uint4*>(pq + i * 32 * W1_PITCH + 32 * ks));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = q0 + 64 * wq + 32 * ni + j;
+            if (q >= a.CQ) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ai = a0 + 64 * wa + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (ai < a.CA) atomicAdd(a.dw + (size_t)ai * a.CQ + q, acc[mi][ni][e]);
+            }
+        }
+}
+
 // ws [T][CA][CQ] -> dw [CA][CQ][T]
 __global__ __launch_bounds__(256) void wgrad_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int AQ) {
     const size_t total = (size_t)T * AQ;
@@ -335,6 +422,23 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
     a.QG = ceil_div(a.QPIX, 64);
     a.QS = a.QPIX | 1;
     const size_t wbytes = masic_conv2d_wgrad_workspace_bytes(d);
+    if (bf16 && Tt == 1 && a.s == 1 && a.pad == 0 && (a.Hc * a.Wc) % 64 == 0) {
+        Wgrad1x1Args g{};
+        g.P = a.P; g.Q = a.Q; g.dw = dw; g.CA = a.CA; g.CQ = a.CQ;
+        g.p_ctot = a.p_ctot; g.p_coff = a.p_coff; g.q_ctot = a.q_ctot; g.q_coff = a.q_coff;
+        g.HW = a.Hc * a.Wc; g.ntk = a.B * (g.HW / 64);
+        g.q_tiles = ceil_div(a.CQ, 128);
+        const int base = ceil_div(a.CA, 128) * g.q_tiles;
+        int nsplit = ceil_div(512, base);
+        if (nsplit > g.ntk) nsplit = g.ntk;
+        g.nsplit = nsplit < 1 ? 1 : nsplit;
+        if (hipMemsetAsync(dw, 0, wbytes, st) != hipSuccess) {
+            masic_set_error("conv2d_wgrad: memset failed");
+            return MASIC_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(conv_wgrad_1x1_bf16, dim3(base, 1, g.nsplit), dim3(256), 0, st, g);
+        return masic_launch_status("conv2d_wgrad");
+    }
     if (hipMemsetAsync(workspace, 0, wbytes, st) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;

@@ -1,0 +1,259 @@
+// gdn_bwd.hip -- GDN / inverse-GDN backward for C = 128 in ONE kernel (gfx950), the training step's bf16-operand mode.
+//
+// compressai/layers/gdn.py:77-92 under autograd:  n = beta^ + gamma^ x^2,  y = x n^(-1/2)   (inverse: x n^(1/2)).  With g = dL/dy:
+//     s = g n^(-1/2)               t = dL/dn = -1/2 g x n^(-3/2)       (inverse: s = g n^(1/2), t = +1/2 g x n^(-1/2))
+//     u = gamma^T t                dx = s + 2 x u
+//     d gamma^[i][j] = sum_px t_i x_j^2           d beta^[i] = sum_px t_i
+// and the NonNegativeParametrizer rule (parametrizers.py:61-64, bound_ops.py:40-42) from gamma^/beta^ to the stored tensors.
+// The unfused float32 path (autograd.py: seven kernels, ~20 passes over the activation) stays the parity path; this kernel
+// reads x and g once and writes dx once.
+//
+// Everything is local to a pixel, so a wave owns 32 pixels x all 128 channels in MFMA accumulator layout (lane = pixel,
+// 16 channels per 32-channel block) loaded straight from NCHW (128-byte segments per channel row):
+//   n  = gamma^ x^2   : v_mfma_f32_32x32x16_bf16, B operand = x^2 from the lane's own registers (k-step s covers the channels
+//                       32(s>>1) + 16(s&1) + 8(c>>2) + 4h + (c&3) -- the 8 registers [s>>1][8(s&1)+c]), A = gamma^ fragments in LDS
+//   u  = gamma^T t    : the same with a transposed fragment image and B = t
+//   d gamma^ += t x^2^T: k = pixel.  The 4 waves of a workgroup write their t and x^2 (bf16) into [channel][128 px] LDS tiles
+//                       (pitch 272 B: a ds_read_b128 of 16 channels x 8 pixels is conflict-free); wave w then contracts
+//                       channels 32w..32w+31 of t against all 128 of x^2 -- 4 persistent accumulators; d beta^ is a fifth
+//                       with B = ones.
+// Workgroups are persistent (one per CU, 135 KiB of LDS); their partial d gamma^ / d beta^ go to a workspace and a second
+// kernel adds them in a fixed order and applies the parametrizer rule.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GB_NBLK = 256;                    // persistent workgroups (= partial slots)
+constexpr int GB_IMG = 32768;                   // one fragment image: [m 4][s 8][lane 64] x 16 B
+constexpr int GB_TP = 272;                      // LDS tile pitch in bytes: 128 px x 2 B + 16
+constexpr int GB_TILE = 128 * GB_TP;            // 34816
+constexpr int GB_LDS = 2 * GB_IMG + 2 * GB_TILE + 512;
+
+__device__ __forceinline__ int gb_chan(int s, int h, int c) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (c >> 2) + 4 * h + (c & 3); }
+
+// img[0]: A[m = i][k = j] = gamma^[i][j] (n = gamma^ x^2);  img[1]: A[m = j][k = i] = gamma^[i][j] (u = gamma^T t);  then beta^[128]
+__global__ __launch_bounds__(256) void gdn_bwd_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                           uint4* __restrict__ img, float beta_bound, float gamma_bound, float pedestal) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < 2 * 2048) {
+        const int which = idx >> 11, f = idx & 2047, l = f & 63, ms = f >> 6, m = ms >> 3, s = ms & 7, r = l & 31, hh = l >> 5;
+        gbf16x8 v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int row = 32 * m + r, ch = gb_chan(s, hh, c);
+            const float gr = fmaxf(which ? gamma[(size_t)ch * 128 + row] : gamma[(size_t)row * 128 + ch], gamma_bound);
+            v[c] = (__bf16)__fsub_rn(__fmul_rn(gr, gr), pedestal);
+        }
+        img[idx] = __builtin_bit_cast(uint4, v);
+    }
+    if (idx < 128) {
+        const float bv = fmaxf(beta[idx], beta_bound);
+        reinterpret_cast<float*>(img + 2 * 2048)[idx] = __fsub_rn(__fmul_rn(bv, bv), pedestal);
+    }
+}
+
+struct GdnBwdArgs {
+    const float* x; const float* g; float* gx;
+    const uint4* img;            // two fragment images + beta^
+    float* part;                 // [GB_NBLK][128*128 + 128]
+    long long npix;              // B * HW
+    int HW, ntiles, inverse;
+};
+
+__global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* tl = lds + 2 * GB_IMG;            // t tile   [128 ch][272 B]
+    unsigned char* xl = tl + GB_TILE;                // x^2 tile
+    const float* bet = reinterpret_cast<const float*>(xl + GB_TILE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < (2 * GB_IMG + 512) / 16; i += 256) {
+        const int dst = i < 2 * GB_IMG / 16 ? i * 16 : 2 * GB_IMG + 2 * GB_TILE + (i - 2 * GB_IMG / 16) * 16;
+        *reinterpret_cast<uint4*>(lds + dst) = a.img[i];
+    }
+    __syncthreads();
+
+    f32x16 dg[4], db;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dg[0][e] = 0.0f; dg[1][e] = 0.0f; dg[2][e] = 0.0f; dg[3][e] = 0.0f; db[e] = 0.0f; }
+    gbf16x8 ones;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
+
+    const unsigned char* gi0 = lds + lane * 16;
+    const unsigned char* gi1 = lds + GB_IMG + lane * 16;
+    const unsigned hw = (unsigned)a.HW;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long long p = (long long)tile * 128 + w * 32 + j;
+        const bool ok = p < a.npix;
+        const long long b = ok ? p / a.HW : 0;
+        const size_t base = (size_t)b * 128 * hw + (size_t)(ok ? p - b * a.HW : 0) + (size_t)(4 * h) * hw;
+        const float* xp = a.x + base;
+        const float* gp = a.g + base;
+        f32x16 xv[4], gv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned off = (unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw;
+                xv[m][e] = ok ? xp[off] : 0.0f;
+                gv[m][e] = ok ? gp[off] : 0.0f;
+            }
+
+        // ---- n = beta^ + gamma^ x^2; x^2 (bf16) also goes to its LDS tile
+        f32x16 nv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 be = *reinterpret_cast<const float4*>(bet + m * 32 + 8 * q + 4 * h);
+                nv[m][4 * q] = be.x; nv[m][4 * q + 1] = be.y; nv[m][4 * q + 2] = be.z; nv[m][4 * q + 3] = be.w;
+            }
+        __syncthreads();                                           // the previous tile's d gamma^ reads are done
+        unsigned char* xw = xl + (4 * h) * GB_TP + (w * 32 + j) * 2;
+        unsigned char* tw = tl + (4 * h) * GB_TP + (w * 32 + j) * 2;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            gbf16x8 bq;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float xe = xv[s >> 1][8 * (s & 1) + c];
+                bq[c] = (__bf16)__fmul_rn(xe, xe);
+                *reinterpret_cast<__bf16*>(xw + (32 * (s >> 1) + 16 * (s & 1) + 8 * (c >> 2) + (c & 3)) * GB_TP) = bq[c];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi0 + (m * 8 + s) * 1024));
+                nv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, nv[m], 0, 0, 0);
+            }
+        }
+        // ---- s (kept in nv) and t (kept in gv)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float r = __builtin_amdgcn_rsqf(nv[m][e]), gg = gv[m][e], gxr = gg * xv[m][e] * r;
+                if (a.inverse) { nv[m][e] = gg * __builtin_amdgcn_sqrtf(nv[m][e]); gv[m][e] = 0.5f * gxr; }
+                else { nv[m][e] = gg * r; gv[m][e] = -0.5f * gxr * r * r; }
+            }
+        // ---- u = gamma^T t; t (bf16) also goes to its LDS tile
+        f32x16 uv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) uv[m][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            gbf16x8 bq;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                bq[c] = (__bf16)gv[s >> 1][8 * (s & 1) + c];
+                *reinterpret_cast<__bf16*>(tw + (32 * (s >> 1) + 16 * (s & 1) + 8 * (c >> 2) + (c & 3)) * GB_TP) = bq[c];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi1 + (m * 8 + s) * 1024));
+                uv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[m], 0, 0, 0);
+            }
+        }
+        // ---- dx = s + 2 x u
+        if (ok) {
+            float* op = a.gx + base;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    op[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = fmaf(2.0f * xv[m][e], uv[m][e], nv[m][e]);
+        }
+        __syncthreads();                                           // both tiles complete
+        // ---- d gamma^[32w + .][.] += t x^2^T over the 128 pixels, d beta^ with B = ones
+        const unsigned char* ta = tl + (32 * w + j) * GB_TP + 16 * h;
+        const unsigned char* xb = xl + j * GB_TP + 16 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const gbf16x8 af = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(ta + 32 * ks));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const gbf16x8 bf = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(xb + m * 32 * GB_TP + 32 * ks));
+                dg[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, dg[m], 0, 0, 0);
+            }
+            db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, db, 0, 0, 0);
+        }
+    }
+
+    float* pp = a.part + (size_t)blockIdx.x * (128 * 128 + 128);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = 32 * w + (e & 3) + 8 * (e >> 2) + 4 * h;
+            pp[i * 128 + 32 * m + j] = dg[m][e];
+        }
+    if (j == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pp[128 * 128 + 32 * w + (e & 3) + 8 * (e >> 2) + 4 * h] = db[e];
+    }
+}
+
+// fixed-order sum of the partials + the parametrizer's backward rule (gradient passes where the stored value is above the
+// bound or the step would raise it): g = 2 max(p, bound) dL/dp^.  Block = 32 entries x 8 slices of the partial list.
+__global__ __launch_bounds__(256) void gdn_bwd_reduce_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ beta,
+                                                             const float* __restrict__ gamma, float* __restrict__ g_beta,
+                                                             float* __restrict__ g_gamma, float beta_bound, float gamma_bound) {
+    __shared__ float red[8][32];
+    const int l = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + l;                      // 128*128 + 128 is a multiple of 32
+    float s = 0.0f;
+    for (int k = sl; k < nblk; k += 8) s += part[(size_t)k * (128 * 128 + 128) + idx];
+    red[sl][l] = s;
+    __syncthreads();
+    if (sl != 0) return;
+    for (int k = 1; k < 8; ++k) s += red[k][l];
+    const bool isg = idx < 128 * 128;
+    const float p = isg ? gamma[idx] : beta[idx - 128 * 128], bound = isg ? gamma_bound : beta_bound;
+    const float gr = s * 2.0f * fmaxf(p, bound);
+    const float r = (p >= bound || gr < 0.0f) ? gr : 0.0f;
+    if (isg) g_gamma[idx] = r; else g_beta[idx - 128 * 128] = r;
+}
+
+}  // namespace
+
+extern "C" size_t masic_gdn_bwd_fused_workspace_bytes(void) {
+    return (size_t)2 * GB_IMG + 512 + (size_t)GB_NBLK * (128 * 128 + 128) * sizeof(float);
+}
+
+extern "C" int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const float* gamma, float* gx,
+                                   float* g_beta, float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse,
+                                   double beta_min, void* stream) {
+    MASIC_REQUIRE(x && g && beta && gamma && gx && g_beta && g_gamma && workspace, MASIC_ERR_ARG, "gdn_bwd_fused: null pointer");
+    MASIC_REQUIRE(C == 128, MASIC_ERR_UNSUPPORTED, "gdn_bwd_fused: C=%d (128 only; other widths use the unfused pieces)", C);
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W * 128 < (1ll << 31), MASIC_ERR_SHAPE, "gdn_bwd_fused: shape");
+    hipStream_t st = (hipStream_t)stream;
+    const double ped = 1.4551915228366852e-11;      // (2^-18)^2, parametrizers.py:47-56
+    const float pedestal = (float)ped, beta_bound = (float)__builtin_sqrt(beta_min + ped), gamma_bound = (float)__builtin_sqrt(ped);
+    uint4* img = (uint4*)workspace;
+    float* part = reinterpret_cast<float*>((unsigned char*)workspace + 2 * GB_IMG + 512);
+    hipLaunchKernelGGL(gdn_bwd_pack_kernel, dim3(16), dim3(256), 0, st, beta, gamma, img, beta_bound, gamma_bound, pedestal);
+    GdnBwdArgs a{};
+    a.x = x; a.g = g; a.gx = gx; a.img = img; a.part = part;
+    a.HW = H * W; a.npix = (long long)B * H * W; a.inverse = inverse;
+    a.ntiles = (int)((a.npix + 127) / 128);
+    const int nblk = a.ntiles < GB_NBLK ? a.ntiles : GB_NBLK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gdn_bwd_c128, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess) {
+            masic_set_error("gdn_bwd_fused: cannot reserve %d bytes of LDS", GB_LDS);
+            return MASIC_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gdn_bwd_c128, dim3(nblk), dim3(256), GB_LDS, st, a);
+    hipLaunchKernelGGL(gdn_bwd_reduce_kernel, dim3((128 * 128 + 128) / 32), dim3(256), 0, st, (const float*)part, nblk,
+                       beta, gamma, g_beta, g_gamma, beta_bound, gamma_bound);
+    return masic_launch_status("gdn_bwd_fused");
+}

@@ -421,6 +421,26 @@ def gdn_bwd_post(x, s, u):
     return dx
 
 
+_GDN_BWD_WS = {}
+
+
+def gdn_bwd_fused(x, g, beta, gamma, inverse=False, beta_min=1e-6):
+    """(dx, d beta, d gamma) of GDN / inverse GDN at C = 128 in one kernel (bf16 operands, float32 accumulate)."""
+    _dev(x, "x"); _dev(g, "g")
+    B, C, H, W = x.shape
+    if g.shape != x.shape or not (x.is_contiguous() and g.is_contiguous()):
+        raise RuntimeError("masic_amd.gdn_bwd_fused: x and g must be contiguous and of one shape")
+    ws = _GDN_BWD_WS.get(x.device)
+    if ws is None:
+        ws = _GDN_BWD_WS[x.device] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    gx = torch.empty_like(x)
+    g_beta = torch.empty(C, dtype=torch.float32, device=x.device)
+    g_gamma = torch.empty(C, C, dtype=torch.float32, device=x.device)
+    check(lib.masic_gdn_bwd_fused(_p(x), _p(g), _p(_dev(beta.contiguous())), _p(_dev(gamma.contiguous())), _p(gx), _p(g_beta),
+                                  _p(g_gamma), _p(ws), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_bwd_fused")
+    return gx, g_beta, g_gamma
+
+
 def conv2d_wgrad(x, dy, desc, weight_shape):
     _dev(x, "x"); _dev(dy, "dy")
     if tuple(dy.shape) != (desc.B, desc.Cout, desc.Ho, desc.Wo):

@@ -75,7 +75,14 @@ def test_conv_backward(case):
     assert_close(mod.bias.grad, br.grad, name + ":db", GTOL)
 
 
-@pytest.mark.parametrize("case", CONV_BWD_CASES, ids=[c[0] for c in CONV_BWD_CASES])
+WGRAD_BF16_CASES = CONV_BWD_CASES + [          # 1x1 layers with 64 | H W take the GEMM-shaped kernel
+    ("conv1x1_gemm",   2, 768, 16, 16, 960,  1, 1, False, False, 0),
+    ("deconv1x1_gemm", 2, 200, 8,  16, 1152, 1, 1, True,  False, 0),
+    ("conv1x1_gemm_r", 3, 72,  8,  8,  40,   1, 1, False, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_BF16_CASES, ids=[c[0] for c in WGRAD_BF16_CASES])
 def test_conv_wgrad_bf16_operands(case):
     """The bf16-operand weight gradient (training in the bf16 mode) == the float32 kernel run on bf16-rounded operands:
     rounding happens once per operand and every product / the accumulation stay float32, so the two agree to float32
@@ -124,6 +131,53 @@ def test_gdn_backward(C, H, W, inverse):
     assert_close(xd.grad, xr.grad, "gdn:dx", GTOL)
     assert_close(m.gamma.grad, gr.grad, "gdn:dgamma", GTOL)
     assert_close(m.beta.grad, br.grad, "gdn:dbeta", GTOL)
+
+
+@pytest.mark.parametrize("B,H,W,inverse", [(2, 16, 32, False), (2, 8, 8, True), (3, 5, 7, False), (2, 24, 40, True), (1, 64, 64, False)])
+def test_gdn_backward_fused_bf16(B, H, W, inverse):
+    """masic_gdn_bwd_fused (the bf16-operand training mode) against (1) a float32 emulation with the kernel's roundings --
+    gamma^, x^2 and t rounded to bf16 where they enter a contraction, everything else float32 -- tight, and (2) torch
+    autograd on the CPU oracle's GDN, at bf16 operand noise.  Ragged pixel counts (105 pixels: a partial tile whose 32-pixel
+    runs cross images) and stored parameters below their bound (the LowerBound rule) included."""
+    from masic_amd import ops, synth
+    C = 128
+    rs = np.random.RandomState(B * H + W)
+    beta = synth.synth_tensor("g.beta", (C,), rs)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs)
+    gamma[0, 1] = 1e-7
+    gamma[1, 0] = 1e-7
+    beta[0] = 1e-5
+    x = _rand(B, C, H, W, seed=10, scale=3.0)
+    go = _rand(B, C, H, W, seed=11)
+    gx, gb, gg = ops.gdn_bwd_fused(x.to(DEV), go.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inverse, beta_min=1e-6)
+    gx, gb, gg = gx.cpu(), gb.cpu(), gg.cpu()
+    # (2) autograd
+    xr, br, gr = x.clone().requires_grad_(True), beta.clone().requires_grad_(True), gamma.clone().requires_grad_(True)
+    O.gdn(xr, br, gr, inverse=inverse).backward(go)
+    # (1) emulation
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ped = torch.tensor(2.0 ** -36, dtype=torch.float32)
+    b_bound = torch.tensor((1e-6 + 2.0 ** -36) ** 0.5, dtype=torch.float32)
+    g_bound = torch.tensor((2.0 ** -36) ** 0.5, dtype=torch.float32)
+    bh = torch.maximum(beta, b_bound) ** 2 - ped
+    gh = rnd(torch.maximum(gamma, g_bound) ** 2 - ped)
+    xf = x.permute(1, 0, 2, 3).reshape(C, -1).double()
+    gf = go.permute(1, 0, 2, 3).reshape(C, -1).double()
+    x2 = rnd((xf * xf).float()).double()
+    n = bh.double()[:, None] + gh.double() @ x2
+    if inverse:
+        sv, tv = gf * n.sqrt(), 0.5 * gf * xf / n.sqrt()
+    else:
+        sv, tv = gf / n.sqrt(), -0.5 * gf * xf / (n * n.sqrt())
+    tb = rnd(tv.float()).double()
+    dx = (sv + 2.0 * xf * (gh.double().t() @ tb)).float().reshape(C, B, H, W).permute(1, 0, 2, 3)
+    dgh, dbh = (tb @ x2.t()).float(), tb.sum(1).float()
+    rule = lambda d, p, bound: torch.where((p >= bound) | (d * 2 * torch.maximum(p, bound) < 0), d * 2 * torch.maximum(p, bound), torch.zeros_like(d))
+    want = (dx, rule(dbh, beta, b_bound), rule(dgh, gamma, g_bound))
+    for name, got, emu, ref in zip(("dx", "dbeta", "dgamma"), (gx, gb, gg), want, (xr.grad, br.grad, gr.grad)):
+        peak = float(ref.abs().max())
+        assert float((got - emu).abs().max()) <= 2e-3 * peak, (name, "emulation", float((got - emu).abs().max()), peak)
+        assert float((got - ref).abs().max()) <= 3e-2 * peak, (name, "autograd", float((got - ref).abs().max()), peak)
 
 
 def test_entropy_bottleneck_backward_and_aux():
