@@ -16,6 +16,8 @@ There is no CPU path: tensors must live on an MI355X (`cuda`) device.
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (re-exported through `from MASIC import *`)
@@ -738,11 +740,140 @@ class HSIC(CompressionModel):
         med2 = self.entropy_bottleneck2.quantiles.detach()[:, 0, 1].contiguous()
         return {"y1": _hip.symbols(y1), "y2": _hip.symbols(y2), "z1": _hip.symbols(z1, med1), "z2": _hip.symbols(z2, med2)}
 
-    def compress(self, x1, x2, h_matrix, output_name, output_path="", device="cpu"):
-        raise NotImplementedError("HSIC.compress (range-coder bitstream, reference :855-1158) is row 8(f)-1 of SURVEY.md: next")
+    # ---- bitstream (reference :855-1408).  masic_amd/codec.py holds the wavefront coder; here the model
+    # side: which tensors condition the tables of each view, computed identically by compress and decompress.
+    def _codec_check(self, B):
+        if self.training:
+            raise RuntimeError("HSIC.compress/decompress: call .eval() first (the reference quantises with noise in training mode)")
+        if B != 1:
+            raise ValueError("HSIC.compress/decompress code one stereo pair per call (the reference codes batch element 0 only)")
 
-    def decompress(self, *args, **kwargs):
-        raise NotImplementedError("HSIC.decompress (reference :1161-1408) is row 8(f)-1 of SURVEY.md: next")
+    def _left_params_fn(self, z1_hat, h, w):
+        M = self.M
+        cat1 = torch.empty((1, 4 * M, h, w), dtype=torch.float32, device=z1_hat.device)      # params1 | ctx_params1
+        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0)
+
+        def params(y_hat):
+            self._context(self.context_prediction1, y_hat, cat1, 2 * M)
+            return self._h_s1_same_resolution.heads(cat1)
+        return params
+
+    def _right_params_fn(self, z2_hat, x1_hat, m_fwd, m_back, H, W, h, w):
+        """-> (params_fn, x1_hat_warp): everything of the right view's tables that the decoder knows before y2."""
+        M = self.M
+        dev = z2_hat.device
+        x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(1, H, W))
+        gates = self.mask2weights_unit(x1_mask_R)
+        cat2 = torch.empty((1, 5 * M, h, w), dtype=torch.float32, device=dev)               # params2*g0 | ctx2*g1 | y1_warp_hat*g2
+        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
+        x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))
+        _hip.quantize(self.encoder1.latent(x1_hat_warp), "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+
+        def params(y_hat):
+            self._context(self.context_prediction2, y_hat, cat2, 2 * M, gates, 1)
+            return self._h_s2_same_resolution.heads(cat2)
+        return params, x1_hat_warp
+
+    @staticmethod
+    def _channel_flags(y_hat):
+        """Reference :925-940: which channels hold a non-zero symbol (bit-packed into the header) and the alphabet half-width."""
+        a = y_hat[0].abs()
+        flags = (a.flatten(1).amax(1) > 0).cpu().numpy().astype(np.uint8)
+        return flags, max(int(a.max().item()), 1)
+
+    def compress(self, x1, x2, h_matrix, output_name, output_path="", device="cpu"):
+        """Writes <output_name>.npz (picture size, z1 / z2 strings, channel flags, minmax: the reference's header layout,
+        :916-948) and <output_name>.bin (the y1 / y2 streams, masic_amd/codec.py) under output_path.  `device` is accepted
+        for signature compatibility; tensors stay where x1 is."""
+        import os
+        from masic_amd import codec, nn as _mnn
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, _, H, W = x1.shape
+        self._codec_check(B)
+        M, K = self.M, self.K
+        with torch.no_grad():
+            m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+            # left view
+            y1 = self.encoder1.latent(x1)
+            z1 = self._h_a1(y1)
+            z1_strings = self.entropy_bottleneck1.compress(z1)
+            z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:])
+            y1_hat = _hip.quantize(y1, "dequantize")
+            h, w = y1.shape[-2:]
+            flag1, minmax1 = self._channel_flags(y1_hat)
+            chan1 = torch.from_numpy(np.flatnonzero(flag1).astype(np.int32)).to(x1.device)
+            bound1 = self.gaussian1._scale_bound_value
+            s_y1 = codec.encode_view(self._left_params_fn(z1_hat, h, w), y1_hat, M, K, chan1, minmax1, bound1)
+            x1_hat = self.decoder1.reconstruct(y1_hat)
+            # right view
+            y2 = self.encoder2.forward_views(_hip.warp_perspective(x1, m_fwd, (H, W)), x2)
+            z2 = self._h_a2(y2)
+            z2_strings = self.entropy_bottleneck2.compress(z2)
+            z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:])
+            y2_hat = _hip.quantize(y2, "dequantize")
+            flag2, minmax2 = self._channel_flags(y2_hat)
+            chan2 = torch.from_numpy(np.flatnonzero(flag2).astype(np.int32)).to(x1.device)
+            params2, x1_hat_warp = self._right_params_fn(z2_hat, x1_hat, m_fwd, m_back, H, W, h, w)
+            s_y2 = codec.encode_view(params2, y2_hat, M, K, chan2, minmax2, self.gaussian2._scale_bound_value)
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        for s_z in (z1_strings[0], z2_strings[0]):
+            if len(s_z) > 65535 or max(minmax1, minmax2) > 65535:
+                raise ValueError("HSIC.compress: the header stores string lengths and minmax as uint16 (reference :941-946)")
+        out1 = os.path.join(output_path, str(output_name) + ".npz")
+        with open(out1, "wb") as f:
+            f.write(np.array([H, W], dtype=np.uint16).tobytes())
+            for s_z, flag, mm in ((z1_strings[0], flag1, minmax1), (z2_strings[0], flag2, minmax2)):
+                f.write(np.array([len(s_z), mm], dtype=np.uint16).tobytes())
+                f.write(np.packbits(flag).tobytes())
+                f.write(s_z)
+        out2 = os.path.join(output_path, str(output_name) + ".bin")
+        with open(out2, "wb") as f:
+            f.write(codec.MAGIC + bytes([1 if _mnn.get_precision() == "bf16" else 0, 0, 0, 0]))
+            for s_y in (s_y1, s_y2):
+                f.write(np.array([len(s_y)], dtype=np.uint32).tobytes())
+                f.write(s_y)
+        nbytes = os.path.getsize(out1) + os.path.getsize(out2)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,
+                "bytes": nbytes, "bpp": nbytes * 8.0 / (H * W)}
+
+    def decompress(self, x1, x2, h_matrix, output_name, output_path="", device="cpu"):
+        """Reads the two files compress wrote.  x1 / x2 are not used for decoding (the reference only takes sizes from them,
+        :1308-1310) and may be None; tensors are created on the model's device."""
+        import os
+        from masic_amd import codec, nn as _mnn
+        self._codec_check(1)
+        M, K = self.M, self.K
+        dev = self.encoder1.g_a_conv1.weight.device
+        with open(os.path.join(output_path, str(output_name) + ".npz"), "rb") as f:
+            H, W = (int(v) for v in np.frombuffer(f.read(4), dtype=np.uint16))
+            views = []
+            for _ in range(2):
+                length, minmax = (int(v) for v in np.frombuffer(f.read(4), dtype=np.uint16))
+                flags = np.unpackbits(np.frombuffer(f.read(M // 8), dtype=np.uint8))
+                views.append((f.read(length), minmax, torch.from_numpy(np.flatnonzero(flags).astype(np.int32)).to(dev)))
+        with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
+            head = f.read(8)
+            if head[:4] != codec.MAGIC:
+                raise ValueError("HSIC.decompress: not a stream of this library (magic %r)" % head[:4])
+            if head[4] != (1 if _mnn.get_precision() == "bf16" else 0):
+                raise ValueError("HSIC.decompress: the stream was written in the %s operand mode; the coding tables depend on it "
+                                 "(masic_amd.nn.set_precision)" % ("bf16" if head[4] else "f32"))
+            streams = []
+            for _ in range(2):
+                n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])
+                streams.append(f.read(n))
+        h, w = H // 16, W // 16
+        with torch.no_grad():
+            m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+            z1_hat = self.entropy_bottleneck1.decompress([views[0][0]], (h // 4, w // 4))
+            z2_hat = self.entropy_bottleneck2.decompress([views[1][0]], (h // 4, w // 4))
+            y1_hat = codec.decode_view(self._left_params_fn(z1_hat, h, w), streams[0], (h, w), M, K, views[0][2], views[0][1],
+                                       self.gaussian1._scale_bound_value, dev)
+            x1_hat = self.decoder1.reconstruct(y1_hat)
+            params2, x1_hat_warp = self._right_params_fn(z2_hat, x1_hat, m_fwd, m_back, H, W, h, w)
+            y2_hat = codec.decode_view(params2, streams[1], (h, w), M, K, views[1][2], views[1][1], self.gaussian2._scale_bound_value, dev)
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat}
 
 
 # ------------------------------------------------------------------------------------------ CQE network

@@ -327,6 +327,29 @@ int masic_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexe
 int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32_t* indexes, int n, const int32_t* cdfs,
                                    int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols);
 
+/* ---- HSIC.compress / decompress (MASIC.py:855-1408), SURVEY.md 8(f)-1: the y1 / y2 streams.
+ * Per-symbol coding tables (MASIC.py:986-1044 in compress, :1262-1296 in decompress): the K-component Gaussian-mixture
+ * PMF of latent element (pixel pix[i], channel chan[j]) over the alphabet 0 .. 2*minmax, clipped to [2^-16, 1],
+ * renormalised to 2^16 and rounded (:1040-1043), the count total then forced to exactly 2^16 at the mode.  sigma / mu /
+ * logits: [K*M][HW] head outputs of ONE image (the reference codes batch element 0), logits before the softmax over K.
+ * Row r = i * nch + j.  starts (nullable): [npix*nch][2*minmax+1] u16 interval starts -- the decoder's view;
+ * y_hat + start_freq (nullable, together): the integer-valued latent [M][HW] and [npix*nch][2] (start, freq) of its
+ * symbols -- the encoder's view.  err_flag (device int, caller-zeroed): bit 0 = a table could not be normalised,
+ * bit 1 = a symbol outside the alphabet. */
+int masic_gmm_cdf_rows(const float* sigma, const float* mu, const float* logits, int M, int K, int HW,
+                       const int32_t* pix, int npix, const int32_t* chan, int nch, int minmax, float scale_bound,
+                       const float* y_hat, uint16_t* starts, int32_t* start_freq, int32_t* err_flag, void* stream);
+/* rANS with one table per symbol (host).  The reference drives the third-party `range_coder` package here
+ * (MASIC.py:958, :1044, :1221, :1296), which is not part of its tree: the byte stream of this container is this
+ * library's own (64-bit state, 32-bit renormalisation, 16-bit tables: the coder of the z streams above).
+ * start_freq: [n][2] intervals in coding order.  The decoder is incremental -- the tables of a wavefront of latent pixels
+ * exist only once the previous wavefront is decoded: open, decode_rows per wavefront (symbols[r] = index of the interval
+ * of row r that holds the coder's value), close. */
+int masic_rans_encode_freqs(const int32_t* start_freq, size_t n, uint8_t* out, size_t out_cap, size_t* out_len);
+int masic_rans_decoder_open(const uint8_t* in, size_t in_len, void** handle);
+int masic_rans_decoder_decode_rows(void* handle, const uint16_t* starts, int nrows, int L, int32_t* symbols);
+void masic_rans_decoder_close(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

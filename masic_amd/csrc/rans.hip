@@ -221,3 +221,78 @@ extern "C" int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, 
     }
     return MASIC_OK;
 }
+
+// ---------------------------------------------------------------------------- adaptive tables
+// The y streams of HSIC.compress (reference MASIC.py:855-1158) carry one table PER SYMBOL -- the Gaussian-mixture PMF of
+// that latent element given its context -- so the coder takes (start, freq) pairs instead of table indexes.  The reference
+// drives the third-party `range_coder` package here (not in the image: its byte stream is parity-unpinned); this container
+// uses the rANS coder above with the same 16-bit resolution.  Decoding is incremental: the tables of a wavefront of
+// symbols only exist once the previous wavefront is decoded.
+extern "C" int masic_rans_encode_freqs(const int32_t* start_freq, size_t n, uint8_t* out, size_t out_cap, size_t* out_len) {
+    MASIC_REQUIRE(start_freq && out && out_len, MASIC_ERR_ARG, "rans_encode_freqs: null pointer");
+    std::vector<uint32_t> buf(n + 2);
+    uint32_t* p = buf.data() + buf.size();
+    uint64_t x = kLow;
+    for (size_t k = n; k-- > 0;) {
+        const int32_t st = start_freq[2 * k], fr = start_freq[2 * k + 1];
+        MASIC_REQUIRE(st >= 0 && fr >= 1 && st + fr <= (1 << kPrecision), MASIC_ERR_ARG, "rans_encode_freqs: symbol %zu has interval [%d, %d + %d)", k, st, st, fr);
+        put(x, p, (uint32_t)st, (uint32_t)fr);
+    }
+    p -= 2;
+    p[0] = (uint32_t)x;
+    p[1] = (uint32_t)(x >> 32);
+    const size_t nbytes = (size_t)(buf.data() + buf.size() - p) * sizeof(uint32_t);
+    MASIC_REQUIRE(nbytes <= out_cap, MASIC_ERR_SHAPE, "rans_encode_freqs: output buffer of %zu bytes, %zu needed", out_cap, nbytes);
+    memcpy(out, p, nbytes);
+    *out_len = nbytes;
+    return MASIC_OK;
+}
+
+namespace {
+struct AdaptiveDecoder {
+    std::vector<uint32_t> words;
+    size_t pos;
+    uint64_t x;
+};
+}  // namespace
+
+extern "C" int masic_rans_decoder_open(const uint8_t* in, size_t in_len, void** handle) {
+    MASIC_REQUIRE(in && handle, MASIC_ERR_ARG, "rans_decoder_open: null pointer");
+    MASIC_REQUIRE(in_len >= 8 && in_len % 4 == 0, MASIC_ERR_SHAPE, "rans_decoder_open: stream of %zu bytes", in_len);
+    AdaptiveDecoder* d = new AdaptiveDecoder();
+    d->words.resize(in_len / 4);
+    memcpy(d->words.data(), in, in_len);
+    d->x = (uint64_t)d->words[0] | ((uint64_t)d->words[1] << 32);
+    d->pos = 2;
+    *handle = d;
+    return MASIC_OK;
+}
+
+// rows of L interval starts (u16, starts[0] = 0, strictly increasing, the last interval ends at 2^16); one symbol per row
+extern "C" int masic_rans_decoder_decode_rows(void* handle, const uint16_t* starts, int nrows, int L, int32_t* symbols) {
+    MASIC_REQUIRE(handle && starts && symbols && nrows >= 0 && L >= 1, MASIC_ERR_ARG, "rans_decoder_decode_rows: bad argument");
+    AdaptiveDecoder* d = (AdaptiveDecoder*)handle;
+    for (int r = 0; r < nrows; ++r) {
+        const uint16_t* c = starts + (size_t)r * L;
+        const uint32_t cum = (uint32_t)(d->x & ((1u << kPrecision) - 1));
+        int lo = 0, hi = L;                                  // first start above cum
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)c[mid] > cum) hi = mid;
+            else lo = mid + 1;
+        }
+        const int s = lo - 1;
+        MASIC_REQUIRE(s >= 0, MASIC_ERR_ARG, "rans_decoder_decode_rows: table of row %d does not start at 0", r);
+        const uint32_t st = c[s], en = s + 1 < L ? (uint32_t)c[s + 1] : (1u << kPrecision);
+        MASIC_REQUIRE(en > st, MASIC_ERR_ARG, "rans_decoder_decode_rows: empty interval in row %d", r);
+        d->x = (uint64_t)(en - st) * (d->x >> kPrecision) + cum - st;
+        if (d->x < kLow) {
+            MASIC_REQUIRE(d->pos < d->words.size(), MASIC_ERR_ARG, "rans_decoder_decode_rows: stream ends at row %d", r);
+            d->x = (d->x << 32) | d->words[d->pos++];
+        }
+        symbols[r] = s;
+    }
+    return MASIC_OK;
+}
+
+extern "C" void masic_rans_decoder_close(void* handle) { delete (AdaptiveDecoder*)handle; }

@@ -95,3 +95,59 @@ def test_entropy_bottleneck_update_tables_match_reference():
     assert torch.equal(eb._quantized_cdf.cpu(), eb._ref_quantized_cdf)
     eb.update()                                           # second call is a no-op (reference :305-306)
     assert torch.equal(eb._quantized_cdf.cpu(), eb._ref_quantized_cdf)
+
+
+def test_adaptive_rans_round_trip_in_wavefront_chunks():
+    """masic_rans_encode_freqs / masic_rans_decoder_*: one table per symbol (the y streams of HSIC.compress), decoded
+    incrementally in chunks of rows as the wavefront decoder does; corrupt input is reported, not read past."""
+    from masic_amd import codec
+    rs = np.random.RandomState(0)
+    n, L = 5000, 41
+    cuts = np.sort(rs.choice(np.arange(1, 65536), size=(n, L - 1), replace=True), axis=1)
+    for r in range(n):                                    # strictly increasing starts
+        while len(np.unique(cuts[r])) < L - 1:
+            cuts[r] = np.sort(rs.choice(np.arange(1, 65536), size=L - 1, replace=False))
+    starts = np.concatenate([np.zeros((n, 1), dtype=np.int64), cuts], axis=1)
+    ends = np.concatenate([starts[:, 1:], np.full((n, 1), 65536)], axis=1)
+    p = (ends - starts) / 65536.0
+    sym = np.array([rs.choice(L, p=p[r]) for r in range(n)])
+    sf = np.stack([starts[np.arange(n), sym], (ends - starts)[np.arange(n), sym]], axis=1).astype(np.int32)
+    data = codec.encode_freqs(sf)
+    ideal = float(-np.log2(p[np.arange(n), sym]).sum()) / 8
+    assert len(data) <= ideal * 1.01 + 16                 # rANS: within a percent of the ideal code length
+    dec = codec.AdaptiveDecoder(data)
+    got, r = [], 0
+    for chunk in (1, 7, 300, 1000, n):
+        hi = min(n, r + chunk)
+        got.append(dec.decode_rows(starts[r:hi].astype(np.uint16)))
+        r = hi
+    dec.close()
+    assert (np.concatenate(got) == sym).all()
+    with pytest.raises(RuntimeError):
+        codec.encode_freqs(np.array([[0, 0]], dtype=np.int32))             # empty interval
+    dec = codec.AdaptiveDecoder(data[:8])
+    with pytest.raises(RuntimeError):
+        for _ in range(64):                                               # the truncated stream runs dry
+            dec.decode_rows(starts[:100].astype(np.uint16))
+    dec.close()
+
+
+def test_wavefront_order_is_causal_for_the_type_a_mask():
+    """every latent pixel exactly once, and the 12 causal neighbours of the 5x5 type-A mask in strictly earlier steps"""
+    from masic_amd import codec
+    for h, w in ((1, 1), (4, 4), (8, 12), (5, 3), (32, 32)):
+        steps = codec.wavefront_steps(h, w)
+        when = np.full(h * w, -1)
+        for t, pix in enumerate(steps):
+            assert (when[pix] == -1).all() and (np.diff(pix) > 0).all()
+            when[pix] = t
+        assert (when >= 0).all() and len(steps) == w + 3 * (h - 1)
+        for i in range(h):
+            for j in range(w):
+                for di in (-2, -1, 0):
+                    for dj in range(-2, 3):
+                        if di == 0 and dj >= 0:
+                            continue
+                        a, b = i + di, j + dj
+                        if 0 <= a < h and 0 <= b < w:
+                            assert when[a * w + b] < when[i * w + j]
