@@ -327,6 +327,13 @@ int masic_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexe
 int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32_t* indexes, int n, const int32_t* cdfs,
                                    int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols);
 
+/* ---- upstream of the path, SURVEY.md 8(f)-3: h_matrix of a stereo pair from the UDH network's corner offsets --
+ * udh/udh/model.py:100-111 (kornia.get_perspective_transform(corners, corners + delta), torch.inverse) + h_adjust
+ * (newtrain_codec_real.py:49-59, scale_a = H / patch, scale_b = W / patch).  corners, delta: [B][4][2]; h_out: [B][3][3],
+ * NaN for a degenerate quadrilateral. */
+int masic_homography_from_corners(const float* corners, const float* delta, float* h_out, int B, float scale_a, float scale_b,
+                                  void* stream);
+
 /* ---- HSIC.compress / decompress (MASIC.py:855-1408), SURVEY.md 8(f)-1: the y1 / y2 streams.
  * Per-symbol coding tables (MASIC.py:986-1044 in compress, :1262-1296 in decompress): the K-component Gaussian-mixture
  * PMF of latent element (pixel pix[i], channel chan[j]) over the alphabet 0 .. 2*minmax, clipped to [2^-16, 1],

@@ -112,7 +112,77 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
     }
 }
 
+// ---- upstream of the path: the homography of a stereo pair from the 4 corner offsets the UDH network
+// predicts -- udh/udh/model.py:100-111 (kornia.get_perspective_transform(corners, corners + delta), torch.inverse) followed by
+// h_adjust (newtrain_codec_real.py:49-59: rescale from the 128 x 128 patch frame to the picture).  kornia builds the 8 x 8
+// direct-linear-transform system of the 4 correspondences and solves it with an LU solve (h33 = 1); here one lane per pair does
+// the same elimination with partial pivoting in float64, inverts the 3 x 3 by cofactors and applies h_adjust's four in-place
+// scalings in the reference's order and float32.  kornia is not part of the reference tree: parity is pinned by a float64
+// restatement and by the defining property H [corner, 1] ~ [corner + delta, 1].
+__global__ __launch_bounds__(64) void homography_from_corners_kernel(const float* __restrict__ corners, const float* __restrict__ delta,
+                                                                     float* __restrict__ h_out, int B, float a, float b) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= B) return;
+    double A[8][9];
+    for (int k = 0; k < 4; ++k) {
+        const double px = corners[(i * 4 + k) * 2], py = corners[(i * 4 + k) * 2 + 1];
+        const double qx = (double)(corners[(i * 4 + k) * 2] + delta[(i * 4 + k) * 2]);            // corners_hat is formed in float32
+        const double qy = (double)(corners[(i * 4 + k) * 2 + 1] + delta[(i * 4 + k) * 2 + 1]);
+        double* rx = A[2 * k];
+        double* ry = A[2 * k + 1];
+        rx[0] = px; rx[1] = py; rx[2] = 1; rx[3] = 0; rx[4] = 0; rx[5] = 0; rx[6] = -px * qx; rx[7] = -py * qx; rx[8] = qx;
+        ry[0] = 0; ry[1] = 0; ry[2] = 0; ry[3] = px; ry[4] = py; ry[5] = 1; ry[6] = -px * qy; ry[7] = -py * qy; ry[8] = qy;
+    }
+    bool singular = false;
+    for (int c = 0; c < 8; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 8; ++r)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0) { singular = true; break; }
+        if (piv != c)
+            for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+    double x[9];
+    x[8] = 1.0;
+    for (int c = 7; c >= 0 && !singular; --c) {
+        double s = A[c][8];
+        for (int k = c + 1; k < 8; ++k) s -= A[c][k] * x[k];
+        x[c] = s / A[c][c];
+    }
+    // inverse of H = [x0 x1 x2; x3 x4 x5; x6 x7 1]
+    const double c00 = x[4] * x[8] - x[5] * x[7], c01 = x[5] * x[6] - x[3] * x[8], c02 = x[3] * x[7] - x[4] * x[6];
+    const double det = x[0] * c00 + x[1] * c01 + x[2] * c02;
+    float h[9];
+    if (singular || det == 0.0) {
+        for (int k = 0; k < 9; ++k) h[k] = __builtin_nanf("");
+    } else {
+        const double r = 1.0 / det;
+        h[0] = (float)(c00 * r); h[1] = (float)((x[2] * x[7] - x[1] * x[8]) * r); h[2] = (float)((x[1] * x[5] - x[2] * x[4]) * r);
+        h[3] = (float)(c01 * r); h[4] = (float)((x[0] * x[8] - x[2] * x[6]) * r); h[5] = (float)((x[2] * x[3] - x[0] * x[5]) * r);
+        h[6] = (float)(c02 * r); h[7] = (float)((x[1] * x[6] - x[0] * x[7]) * r); h[8] = (float)((x[0] * x[4] - x[1] * x[3]) * r);
+    }
+    const float ia = 1.0f / a, ib = 1.0f / b;
+    for (int k = 0; k < 3; ++k) h[k] = a * h[k];                   // h[:, 0, :] *= a
+    for (int k = 0; k < 3; ++k) h[3 * k] = ia * h[3 * k];          // h[:, :, 0] *= 1/a
+    for (int k = 0; k < 3; ++k) h[3 + k] = b * h[3 + k];           // h[:, 1, :] *= b
+    for (int k = 0; k < 3; ++k) h[3 * k + 1] = ib * h[3 * k + 1];  // h[:, :, 1] *= 1/b
+    for (int k = 0; k < 9; ++k) h_out[(size_t)i * 9 + k] = h[k];
+}
+
 }  // namespace
+
+extern "C" int masic_homography_from_corners(const float* corners, const float* delta, float* h_out, int B, float scale_a, float scale_b,
+                                             void* stream) {
+    MASIC_REQUIRE(corners && delta && h_out, MASIC_ERR_ARG, "homography_from_corners: null pointer");
+    MASIC_REQUIRE(B > 0 && scale_a > 0.0f && scale_b > 0.0f, MASIC_ERR_SHAPE, "homography_from_corners: B=%d, scales %g %g", B, (double)scale_a, (double)scale_b);
+    hipLaunchKernelGGL(homography_from_corners_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, corners, delta, h_out, B,
+                       scale_a, scale_b);
+    return masic_launch_status("homography_from_corners");
+}
 
 extern "C" int masic_warp_matrix(const float* M, float* minv_norm, int B, int Hs, int Ws, int Hd, int Wd,
                                  int invert_first, void* stream) {

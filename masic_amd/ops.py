@@ -278,6 +278,19 @@ def warp_matrix(M, src_hw, dst_hw, invert_first=False):
     return out
 
 
+def homography_from_corners(corners, delta, ori_hw, patch_hw):
+    """h_matrix [B,3,3] of udh/udh/model.py:100-111 + h_adjust (newtrain_codec_real.py:49-59, :129) from the patch corners
+    [B,4,2] and the predicted offsets [B,4,2]; ori_hw = picture size, patch_hw = the size the homography net saw."""
+    _dev(corners, "corners"); _dev(delta, "delta")
+    B = corners.shape[0]
+    if tuple(corners.shape) != (B, 4, 2) or tuple(delta.shape) != (B, 4, 2):
+        raise RuntimeError("masic_amd.homography_from_corners: corners and delta must be [B,4,2]")
+    out = torch.empty((B, 3, 3), dtype=torch.float32, device=corners.device)
+    check(lib.masic_homography_from_corners(_p(corners.contiguous()), _p(delta.contiguous()), _p(out), B, float(ori_hw[0]) / float(patch_hw[0]),
+                                            float(ori_hw[1]) / float(patch_hw[1]), _stream()), "homography_from_corners")
+    return out
+
+
 def warp_perspective(src, minv_norm, dsize, ones_like=None, out=None, out_coff=0):
     """src None: warp an all-ones [B,1,H,W] image whose size is given by ones_like=(B,H,W)."""
     _dev(minv_norm, "warp matrix")

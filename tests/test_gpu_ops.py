@@ -491,3 +491,25 @@ def test_gemm_f16k_dma_stack(B, Cin, Cmid, Cout, H, W, tr):
     out = torch.full((B, Cout + 40, H, W), 3.0, device=DEV)
     ops.gemm_f16k(t, ops.pack_gemm_f16k_weight(w1.to(DEV), Cmid, Cout, False), b1.to(DEV), B, Cmid, Cout, H, W, ops.ACT_RELU, out_nchw=out, out_coff=8)
     assert torch.equal(out[:, 8:8 + Cout], y) and torch.all(out[:, :8] == 3.0) and torch.all(out[:, 8 + Cout:] == 3.0)
+
+
+def test_homography_from_corners_vs_restatement():
+    """corner offsets -> h_matrix (get_perspective_transform + inverse + h_adjust) in one kernel against the
+    float64 restatement (oracle/udh_oracle.py; kornia absent: parity unpinned), plus the defining property: before h_adjust
+    the inverse maps corners + delta back onto the corners."""
+    ops = _ops()
+    from oracle import udh_oracle as U
+    rs = np.random.RandomState(7)
+    B = 67
+    base = np.array([[32, 32], [160, 32], [160, 160], [32, 160]], dtype=np.float32)
+    corners = np.repeat(base[None], B, 0) + rs.randint(-8, 9, (B, 1, 2)).astype(np.float32)
+    delta = rs.uniform(-16, 16, (B, 4, 2)).astype(np.float32)
+    for ori, patch in (((512, 512), (128, 128)), ((512, 896), (128, 128)), ((128, 128), (128, 128))):
+        got = ops.homography_from_corners(torch.from_numpy(corners).to(DEV), torch.from_numpy(delta).to(DEV), ori, patch).cpu().numpy()
+        want = U.h_matrix_from_corners(corners, delta, ori, patch)
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), (ori, np.abs(got - want).max())
+    hat = np.concatenate([corners + delta, np.ones((B, 4, 1), np.float32)], axis=2).astype(np.float64)      # a = b = 1: h_adjust is the identity
+    back = np.einsum("bij,bkj->bki", got.astype(np.float64), hat)
+    assert np.abs(back[..., :2] / back[..., 2:] - corners).max() <= 1e-3
+    bad = ops.homography_from_corners(torch.zeros(1, 4, 2, device=DEV), torch.zeros(1, 4, 2, device=DEV), (8, 8), (8, 8))
+    assert torch.isnan(bad).all()                                       # degenerate quadrilateral: NaN, not garbage
