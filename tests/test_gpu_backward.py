@@ -75,6 +75,48 @@ def test_conv_backward(case):
     assert_close(mod.bias.grad, br.grad, name + ":db", GTOL)
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_BWD_CASES if c[0] in ("conv5s2", "conv5s1", "conv3s1", "deconv5s2", "masked5", "conv1x1", "ragged", "deconv_to3")],
+                         ids=lambda c: c[0])
+def test_conv_backward_bf16_mode(case):
+    """set_precision("bf16"): forward, input gradient and weight gradient with bf16 operands / float32 accumulation, against
+    float32 autograd at bf16 operand noise (2e-2 of each tensor's peak)."""
+    from masic_amd import autograd as A
+    from masic_amd import nn as mnn
+    from compressai.layers import MaskedConv2d
+    name, B, Cin, H, W, Cout, k, s, tr, masked, act = case
+    act = 0            # an activation mask taken from a bf16-rounded output flips near zero: not a property of the gradient kernels
+    if masked:
+        mod = MaskedConv2d(Cin, Cout, kernel_size=k, padding=k // 2, stride=s)
+    elif tr:
+        mod = mnn.ConvTranspose2d(Cin, Cout, k, stride=s, padding=k // 2, output_padding=s - 1)
+    else:
+        mod = mnn.Conv2d(Cin, Cout, k, stride=s, padding=k // 2)
+    w = _rand(*mod.weight.shape, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    with torch.no_grad():
+        mod.weight.copy_(w)
+        mod.bias.copy_(b)
+    mod = mod.to(DEV)
+    x = _rand(B, Cin, H, W, seed=1, scale=2.0)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    weff = O.masked_weight(wr) if masked else wr
+    yr = (F.conv_transpose2d(xr, weff, b, stride=s, padding=k // 2, output_padding=s - 1) if tr else F.conv2d(xr, weff, b, stride=s, padding=k // 2))
+    yr = {0: lambda t: t, 1: F.relu, 2: F.leaky_relu}[act](yr)
+    go = _rand(*yr.shape, seed=4)
+    yr.backward(go)
+    mnn.set_precision("bf16")
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        y = A.conv(mod, xd, act)
+        y.backward(go.to(DEV))
+    finally:
+        mnn.set_precision("f32")
+    for nm, got, ref in (("y", y, yr), ("dx", xd.grad, xr.grad), ("dw", mod.weight.grad, wr.grad)):
+        peak = float(ref.abs().max())
+        err = float((got.detach().cpu() - ref.detach()).abs().max())
+        assert err <= 2e-2 * peak, (name, nm, err, peak)
+
+
 WGRAD_BF16_CASES = CONV_BWD_CASES + [          # 1x1 layers with 64 | H W take the GEMM-shaped kernel
     ("conv1x1_gemm",   2, 768, 16, 16, 960,  1, 1, False, False, 0),
     ("deconv1x1_gemm", 2, 200, 8,  16, 1152, 1, 1, True,  False, 0),
