@@ -85,6 +85,55 @@ __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int prr = lane >> 5, pcc = lane & 31;
 
+    // Staging.  Float32 form: global -> LDS DMA of the next tile into the other buffer.  BF16 form: the DMA's 4 bytes per lane
+    // make one wave-instruction per 256 bytes and that issue rate (~80 cycles each, measured: 320 of them per tile) bounded the
+    // kernel; the tile is fetched into registers with ordinary loads while the current one is contracted and stored to the other
+    // buffer afterwards (same LDS image).
+    constexpr int NQW = 32 * QT / 8;                  // q channels per wave
+    constexpr int MAXG = QT == 1 ? 8 : 1;             // 64-pixel groups per channel patch the register form holds
+    float rp[8], rq[BF16 ? MAXG * NQW : 1];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int r0 = (trem / a.tiles_w) * 2, c0 = (trem % a.tiles_w) * 32;
+        {
+            const int r = r0 + prr, c = c0 + pcc;
+            const bool pok = r < a.Hc && c < a.Wc;
+            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * cplane + (size_t)(pok ? r : 0) * a.Wc + (pok ? c : 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = wave + 8 * i;
+                rp[i] = (pok && (a0 + ch) < a.CA) ? pb[(size_t)(a0 + ch) * cplane] : 0.0f;
+            }
+        }
+        const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * fplane;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int e = g * 64 + lane;
+            const int rr = e / a.PWq, pc = e - rr * a.PWq;
+            const int fh = r0 * a.s - a.pad + rr, fw = c0 * a.s - a.pad + pc;
+            const bool qok = g < a.QG && e < a.QPIX && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+            const float* src = qb + (size_t)(qok ? fh : 0) * a.Wf + (qok ? fw : 0);
+#pragma unroll
+            for (int i = 0; i < NQW; ++i) {
+                const int ch = wave + 8 * i;
+                rq[BF16 ? g * NQW + i : 0] = (qok && (q0 + ch) < a.CQ) ? src[(size_t)(q0 + ch) * fplane] : 0.0f;
+            }
+        }
+    };
+    auto stash = [&](float* buf) {
+        float* Pt = buf;
+        float* Qt = buf + 64 * PS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Pt[(wave + 8 * i) * PS + lane] = rp[i];
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g < a.QG && g * 64 + lane < a.QPIX) {
+#pragma unroll
+                for (int i = 0; i < NQW; ++i) Qt[(wave + 8 * i) * a.QS + g * 64 + lane] = rq[BF16 ? g * NQW + i : 0];
+            }
+        }
+    };
     auto issue = [&](int tile, float* buf) {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
@@ -120,11 +169,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_f32(const WgradArgs a) {
     };
 
     int it = 0;
-    if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    if constexpr (BF16) {
+        if (blockIdx.z < a.ntiles) fetch(blockIdx.z);
+    } else {
+        if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    }
     for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
         float* cur = lds + (it & 1) * buf_sz;
-        __syncthreads();                                   // this tile landed; everyone left the other buffer
-        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        if constexpr (BF16) {
+            stash(cur);                                        // the other buffer may still be read by a slower wave: untouched
+            __syncthreads();
+            if (tile + a.nsplit < a.ntiles) fetch(tile + a.nsplit);
+        } else {
+            __syncthreads();                                   // this tile landed; everyone left the other buffer
+            if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        }
         if constexpr (BF16) {
             const float* pa = cur + (wa * 32 + j) * PS;
             const float* qa = cur + 64 * PS + (qsub * 32 + j) * a.QS;
@@ -236,12 +295,60 @@ __global__ __launch_bounds__(512) void conv_wgrad_packed_f32(const WgradArgs a) 
         }
     };
 
+    // register-staged form of the same tile (BF16; see conv_wgrad_f32): 8 P channels and up to 8 (channel, group) pairs per wave
+    float rp[8], rq[8];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int r0 = (trem / a.tiles_w) * 2, c0 = (trem % a.tiles_w) * 32;
+        const int r = r0 + prr, c = c0 + pcc;
+        const bool pok = r < a.Hc && c < a.Wc;
+        const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff) * cplane + (size_t)(pok ? r : 0) * a.Wc + (pok ? c : 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = wave + 8 * i;
+            rp[i] = (pok && (a0 + ch) < a.CA) ? pb[(size_t)(a0 + ch) * cplane] : 0.0f;
+        }
+        const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * fplane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cg = wave + 8 * i;
+            const int ch = cg / a.QG, g = cg - ch * a.QG;
+            const int e = g * 64 + lane;
+            const int rr = e / a.PWq, pc = e - rr * a.PWq;
+            const int fh = r0 * a.s - a.pad + rr, fw = c0 * a.s - a.pad + pc;
+            const bool qok = cg < a.CQ * a.QG && e < a.QPIX && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+            rq[i] = qok ? qb[(size_t)ch * fplane + (size_t)fh * a.Wf + fw] : 0.0f;
+        }
+    };
+    auto stash = [&](float* buf) {
+        float* Qt = buf + 64 * PS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) buf[(wave + 8 * i) * PS + lane] = rp[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cg = wave + 8 * i;
+            const int ch = cg / a.QG, g = cg - ch * a.QG;
+            if (cg < a.CQ * a.QG && g * 64 + lane < a.QPIX) Qt[ch * a.QS + g * 64 + lane] = rq[i];
+        }
+    };
+
     int it = 0;
-    if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    if constexpr (BF16) {
+        if (blockIdx.z < a.ntiles) fetch(blockIdx.z);
+    } else {
+        if (blockIdx.z < a.ntiles) issue(blockIdx.z, lds);
+    }
     for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
         float* cur = lds + (it & 1) * buf_sz;
-        __syncthreads();
-        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        if constexpr (BF16) {
+            stash(cur);
+            __syncthreads();
+            if (tile + a.nsplit < a.ntiles) fetch(tile + a.nsplit);
+        } else {
+            __syncthreads();
+            if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, lds + ((it + 1) & 1) * buf_sz);
+        }
         if constexpr (BF16) {
             const float* pa = cur + (wa * 32 + j) * PS;
             const float* qa = cur + 64 * PS;
@@ -452,7 +559,7 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         a.nsplit = nsplit < 1 ? 1 : nsplit;
         const size_t lds = (size_t)2 * (64 * PS + a.CQ * a.QS) * sizeof(float);
         dim3 grid(a_tiles, 1, a.nsplit);
-        if (bf16) {
+        if (bf16 && a.CQ * a.QG <= 64) {                    // (the register-staged form holds 8 (channel, group) pairs per wave)
             if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1, true>), grid, dim3(512), lds, st, a);
             else hipLaunchKernelGGL((conv_wgrad_packed_f32<2, true>), grid, dim3(512), lds, st, a);
         } else if (ncol_tiles <= 4) hipLaunchKernelGGL((conv_wgrad_packed_f32<1, false>), grid, dim3(512), lds, st, a);
@@ -467,7 +574,7 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         const size_t lds = (size_t)2 * (64 * PS + 32 * QT * a.QS) * sizeof(float);
         MASIC_REQUIRE(lds <= 160 * 1024, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: tile does not fit LDS");
         dim3 grid(a_tiles * a.q_tiles, 1, a.nsplit);
-        if (bf16) {
+        if (bf16 && a.QG <= 8) {                            // (the register-staged form holds 8 pixel groups per channel patch)
             if (Tt == 1) hipLaunchKernelGGL((conv_wgrad_f32<4, 1, true>), grid, dim3(512), lds, st, a);
             else if (Tt <= 12) hipLaunchKernelGGL((conv_wgrad_f32<1, 3, true>), grid, dim3(512), lds, st, a);
             else hipLaunchKernelGGL((conv_wgrad_f32<1, 7, true>), grid, dim3(512), lds, st, a);
