@@ -69,6 +69,7 @@ def main():
                     help="operand precision of the forward MFMA contractions (float32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed forward eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-codec", action="store_true", help="skip the compress / decompress timing of one pair (extras.bitstream)")
     ap.add_argument("--no-f32-compare", action="store_true", help="skip the float32 parity-path timing/accuracy extras (profiling runs)")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
@@ -211,6 +212,33 @@ def main():
                       "what": f"forward ({args.precision} operands) + RD loss + backward ({args.precision} operands, f32 accumulate)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                               " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146)"}
 
+    codec_info = None
+    if rank == 0 and not args.no_codec:
+        # the real bitstream of one pair: HSIC.compress / decompress on rank 0, outside every timed region above
+        import shutil
+        import tempfile
+        net.eval()
+        net.update(force=True)
+        tmp = tempfile.mkdtemp()
+        try:
+            with torch.no_grad():
+                net.compress(x1[:1], x2[:1], hm[:1], "warm", tmp)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                enc = net.compress(x1[:1], x2[:1], hm[:1], "pair", tmp)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dec = net.decompress(None, None, hm[:1], "pair", tmp)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            codec_info = {"encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3, "bytes": enc["bytes"], "bpp_per_view_pixel": enc["bpp"],
+                          "lossless_latents": all(bool(torch.equal(enc[k], dec[k])) for k in ("y1_hat", "y2_hat", "z1_hat", "z2_hat")),
+                          "identical_reconstruction": all(bool(torch.equal(enc[k], dec[k])) for k in ("x1_hat", "x2_hat")),
+                          "what": f"HSIC.compress / decompress of one {H}x{W} pair: wavefront-ordered context coding, GMM tables on the GPU, "
+                                  "rANS on one host core (files included)"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if rank == 0:
         line = {
             "metric": "stereo pairs/sec (enc+dec)", "value": world * B * args.steps / elapsed, "unit": "stereo pairs/s",
@@ -227,6 +255,8 @@ def main():
         if f32_info is not None:
             extras["f32_parity_path"] = f32_info
             extras["accuracy_vs_f32"] = accuracy
+        if codec_info is not None:
+            extras["bitstream"] = codec_info
         if extras:
             line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
