@@ -223,6 +223,7 @@ def main():
         try:
             with torch.no_grad():
                 net.compress(x1[:1], x2[:1], hm[:1], "warm", tmp)
+                net.decompress(None, None, hm[:1], "warm", tmp)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 enc = net.compress(x1[:1], x2[:1], hm[:1], "pair", tmp)

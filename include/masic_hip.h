@@ -339,7 +339,7 @@ int masic_homography_from_corners(const float* corners, const float* delta, floa
  * PMF of latent element (pixel pix[i], channel chan[j]) over the alphabet 0 .. 2*minmax, clipped to [2^-16, 1],
  * renormalised to 2^16 and rounded (:1040-1043), the count total then forced to exactly 2^16 at the mode.  sigma / mu /
  * logits: [K*M][HW] head outputs of ONE image (the reference codes batch element 0), logits before the softmax over K.
- * Row r = i * nch + j.  starts (nullable): [npix*nch][2*minmax+1] u16 interval starts -- the decoder's view;
+ * Row r = i * nch + j; a negative pix[i] skips its rows (padding of a fixed-size list).  starts (nullable): [npix*nch][2*minmax+1] u16 interval starts -- the decoder's view;
  * y_hat + start_freq (nullable, together): the integer-valued latent [M][HW] and [npix*nch][2] (start, freq) of its
  * symbols -- the encoder's view.  err_flag (device int, caller-zeroed): bit 0 = a table could not be normalised,
  * bit 1 = a symbol outside the alphabet. */

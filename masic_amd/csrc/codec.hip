@@ -34,6 +34,7 @@ __global__ __launch_bounds__(64) void gmm_cdf_kernel(const float* __restrict__ s
     __shared__ unsigned fr[CDF_MAX_L];
     const int r = blockIdx.x, lane = threadIdx.x;
     const int p = pix[r / nch], m = chan[r % nch];
+    if (p < 0) return;                                     // padding entry of a fixed-size wavefront list (graph replay)
     const int L = 2 * minmax + 1;
     const size_t base = (size_t)m * HW + p, ks = (size_t)M * HW;
     float wk[K], sk[K], mk[K];
