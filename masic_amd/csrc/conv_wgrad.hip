@@ -16,6 +16,8 @@
 // v_mfma_f32_32x32x2_f32 with k = a pixel pair.  Partial tiles of all workgroups are reduced with float atomics into a
 // [tap][a][q] workspace (q contiguous: 128-byte segments per half wave = full atomic rate) and a final pass transposes
 // it into the weight layout.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -484,6 +486,160 @@ __global__ __launch_bounds__(256) void conv_wgrad_1x1_bf16(const Wgrad1x1Args a)
         }
 }
 
+// ---- 5x5 stride-2 layers in the bf16-operand mode (the analysis / synthesis / hyper transforms: the bulk of the weight-gradient
+// time).  Same decomposition as conv_wgrad_f32 -- block = 64 a x 32 q x all 25 taps over a strided share of the 2 x 32 coarse
+// pixel tiles, k = pixel -- but the tiles live in LDS as bf16, laid out so that every MFMA operand is ONE aligned ds_read_b128:
+//   P  [64 a][64 px], 144-byte pitch.
+//   Q  [32 q][7 fine rows][even | odd column plane][48], 1360-byte channel pitch.  Fine column f = 2c + kw - 2: the even taps
+//      (kw = 0, 2, 4) read the even plane at c - 1, c, c + 1, the odd taps (kw = 1, 3) the odd plane at c - 1, c.  Planes are
+//      stored 7 entries to the right, which puts the run of the middle tap on a 16-byte boundary and the 2-pixel pairs a thread
+//      writes on 4-byte ones; the runs shifted by one pixel are funnel-shifted (v_alignbit) out of that read and ONE neighbouring
+//      dword -- 5 operand fragments from 2 ds_read_b128 + 3 ds_read_b32, against 40 strided ds_read_b32 in the float32-tile form.
+// 8 waves: waves 0-4 = kernel row kh with the three even taps (both 32-channel a blocks: 6 accumulators), waves 5-7 = the two
+// odd taps of rows {0,1}, {2,3}, {4} (8, 8, 4 accumulators); a SIMD's two waves carry 10-14 of the 50 accumulators.
+// The next tile is fetched with 16-byte loads into registers while this one is contracted, rounded to bf16 on the way into LDS
+// (single buffer, two barriers per tile).  Workgroups that share pixel tiles (the 8 (a, q) blocks of a 128 x 128 layer) get
+// consecutive ids on ONE XCD, so P and Q cross HBM once.
+constexpr int W5_PP = 144, W5_QP = 1360, W5_ROW = 192, W5_PLANE = 96;
+constexpr int W5_LDS = 64 * W5_PP + 32 * W5_QP;
+
+__global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[W5_LDS];
+    unsigned char* const pl = lds;
+    unsigned char* const ql = lds + 64 * W5_PP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+    const int j = lane & 31, h = lane >> 5;
+    // block -> (split, combo): the combos of one split sit next to each other on one XCD
+    const int ncombo = ((a.CA + 63) / 64) * a.q_tiles;
+    const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+    const int combo = m % ncombo, split = (m / ncombo) * 8 + xcd;
+    const int a0 = (combo / a.q_tiles) * 64, q0 = (combo % a.q_tiles) * 32;
+
+    const size_t cplane = (size_t)a.Hc * a.Wc, fplane = (size_t)a.Hf * a.Wf;
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+
+    // staging roles (tile-invariant, so a tile costs a handful of address instructions per thread):
+    //   P: thread = (channel tid>>4 [+32], coarse row, 4-pixel run);  Q: thread = (fine row, 4-column run) of channels grp + 4k
+    const int p_ch = tid >> 4, p_rr = (tid >> 3) & 1, p_run = tid & 7;
+    const int q_grp = tid / 126, q_rem = tid - q_grp * 126, q_rr = q_rem / 18, q_i = q_rem - q_rr * 18;
+    const bool q_thread = tid < 504;
+    unsigned char* const p_dst = pl + p_ch * W5_PP + p_rr * 64 + p_run * 8;
+    unsigned char* const q_dst = ql + q_grp * W5_QP + q_rr * W5_ROW + (2 * q_i + 6) * 2;       // plane entry e + 7, e = 2i - 1
+    float4 rp[2], rq[8];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int r0 = (trem / a.tiles_w) * 2, c0 = (trem % a.tiles_w) * 32;
+        {
+            const int r = r0 + p_rr, c = c0 + 4 * p_run;
+            const bool ok = r < a.Hc && c < a.Wc;
+            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff + a0 + p_ch) * cplane + (ok ? (size_t)r * a.Wc + c : 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                rp[k] = (ok && a0 + p_ch + 32 * k < a.CA) ? *reinterpret_cast<const float4*>(pb + (size_t)(32 * k) * cplane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        {
+            const int fh = 2 * r0 - 2 + q_rr, fw = 2 * c0 - 4 + 4 * q_i;
+            const bool ok = q_thread && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+            const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff + q0 + q_grp) * fplane + (ok ? (size_t)fh * a.Wf + fw : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                rq[k] = (ok && q0 + q_grp + 4 * k < a.CQ) ? *reinterpret_cast<const float4*>(qb + (size_t)(4 * k) * fplane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bf16x4_t v;
+            v[0] = (__bf16)rp[k].x; v[1] = (__bf16)rp[k].y; v[2] = (__bf16)rp[k].z; v[3] = (__bf16)rp[k].w;
+            *reinterpret_cast<bf16x4_t*>(p_dst + 32 * k * W5_PP) = v;
+        }
+        if (q_thread) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bf16x2_t ev, od;                                           // columns 2c0-4+4i .. +3 = even, odd, even, odd
+                ev[0] = (__bf16)rq[k].x; ev[1] = (__bf16)rq[k].z;
+                od[0] = (__bf16)rq[k].y; od[1] = (__bf16)rq[k].w;
+                *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP) = ev;
+                *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP + W5_PLANE) = od;
+            }
+        }
+    };
+
+    const unsigned char* pa = pl + j * W5_PP + 16 * h;
+    const int q = q0 + j;
+    // one instantiation per wave role (its own accumulator set): EVEN = taps kw 0, 2, 4 of row kh_first; else taps 1, 3 of NROWS rows
+    auto role = [&](auto even_c, auto nrows_c, int kh_first) {
+        constexpr bool EVEN = decltype(even_c)::value;
+        constexpr int NROWS = decltype(nrows_c)::value, NT = EVEN ? 3 : 2, NACC = NROWS * NT * 2;
+        f32x16 acc[NACC];                                  // [row kk][tap t][a block i]
+#pragma unroll
+        for (int n = 0; n < NACC; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+        const unsigned char* qa = ql + j * W5_QP + (EVEN ? 0 : W5_PLANE);
+        int tile = split;
+        if (tile < a.ntiles) fetch(tile);
+        for (; tile < a.ntiles; tile += a.nsplit) {
+            __syncthreads();                               // the previous tile's fragment reads are done
+            stash();
+            __syncthreads();
+            if (tile + a.nsplit < a.ntiles) fetch(tile + a.nsplit);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int rho = ks >> 1, g = 2 * (ks & 1) + h;   // coarse row of the tile, 8-pixel column group
+                const wbf16x8 fa0 = __builtin_bit_cast(wbf16x8, *reinterpret_cast<const uint4*>(pa + 32 * ks));
+                const wbf16x8 fa1 = __builtin_bit_cast(wbf16x8, *reinterpret_cast<const uint4*>(pa + 32 * W5_PP + 32 * ks));
+#pragma unroll
+                for (int kk = 0; kk < NROWS; ++kk) {
+                    const unsigned char* qr = qa + (2 * rho + kh_first + kk) * W5_ROW + 16 * (g + 1);
+                    const uint4 cur = *reinterpret_cast<const uint4*>(qr);
+                    const unsigned prev = *reinterpret_cast<const unsigned*>(qr - 4);
+                    const unsigned a1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16), a2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16),
+                                   a3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16);
+                    const wbf16x8 fm = __builtin_bit_cast(wbf16x8, make_uint4(__builtin_amdgcn_alignbit(cur.x, prev, 16), a1, a2, a3));   // column - 1
+                    const wbf16x8 f0 = __builtin_bit_cast(wbf16x8, cur);
+                    f32x16* ac = acc + kk * NT * 2;
+                    ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fm, ac[0], 0, 0, 0);
+                    ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fm, ac[1], 0, 0, 0);
+                    ac[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, f0, ac[2], 0, 0, 0);
+                    ac[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, f0, ac[3], 0, 0, 0);
+                    if constexpr (EVEN) {
+                        const unsigned next = *reinterpret_cast<const unsigned*>(qr + 16);
+                        const wbf16x8 fp = __builtin_bit_cast(wbf16x8, make_uint4(a1, a2, a3, __builtin_amdgcn_alignbit(next, cur.w, 16)));     // column + 1
+                        ac[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fp, ac[4], 0, 0, 0);
+                        ac[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fp, ac[5], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (q < a.CQ) {
+#pragma unroll
+            for (int kk = 0; kk < NROWS; ++kk)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int kw = EVEN ? 2 * t : 2 * t + 1;
+                    float* wsk = a.ws + (size_t)((kh_first + kk) * 5 + kw) * a.CA * a.CQ;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int ai = a0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (ai < a.CA) atomicAdd(wsk + (size_t)ai * a.CQ + q, acc[(kk * NT + t) * 2 + i][e]);
+                        }
+                }
+        }
+    };
+    typedef std::integral_constant<bool, true> true_c;
+    typedef std::integral_constant<bool, false> false_c;
+    if (u < 5) role(true_c{}, std::integral_constant<int, 1>{}, u);
+    else if (u < 7) role(false_c{}, std::integral_constant<int, 2>{}, 2 * (u - 5));
+    else role(false_c{}, std::integral_constant<int, 1>{}, 4);
+}
+
 // ws [T][CA][CQ] -> dw [CA][CQ][T]
 __global__ __launch_bounds__(256) void wgrad_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int AQ) {
     const size_t total = (size_t)T * AQ;
@@ -552,6 +708,26 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
     }
     const int a_tiles = ceil_div(a.CA, 64);
     const int ncol_tiles = ceil_div(Tt * a.CQ, 32);
+    if (bf16 && d->KH == 5 && d->KW == 5 && a.s == 2 && a.pad == 2 && a.CQ > 8 && a.Wf % 8 == 0 && a.Wf == 2 * a.Wc && a.Hf == 2 * a.Hc) {
+        a.q_tiles = ceil_div(a.CQ, 32);
+        const int ncombo = a_tiles * a.q_tiles;
+        // pixel splits: a multiple of 8 (dealt round-robin to the XCDs); one workgroup per CU at a time, each ends with
+        // 51 200 float atomics (~4 tile times), so: rounds over the 256 CUs x (tiles per workgroup + 4), minimised
+        int nsplit = 8;
+        long best = -1;
+        for (int ns = 8; ns <= 128; ns += 8) {
+            if (ns > round_up(a.ntiles, 8)) break;
+            const long cost = (long)ceil_div(ncombo * ns, 256) * (ceil_div(a.ntiles, ns) + 4);
+            if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+        }
+        a.nsplit = nsplit;
+        hipLaunchKernelGGL(conv_wgrad_k5s2_bf16, dim3(ncombo * nsplit), dim3(512), 0, st, a);
+        const size_t total5 = (size_t)Tt * a.CA * a.CQ;
+        int tb5 = (int)((total5 + 255) / 256);
+        if (tb5 > 4096) tb5 = 4096;
+        hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb5), dim3(256), 0, st, (const float*)workspace, dw, Tt, a.CA * a.CQ);
+        return masic_launch_status("conv2d_wgrad");
+    }
     if (a.CQ <= 8 && Tt > 1 && ncol_tiles <= 8) {          // few fine-side channels: (tap, q) pairs packed into the 32 MFMA columns
         a.q_tiles = 1;
         int nsplit = ceil_div(512, a_tiles);
