@@ -82,11 +82,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MASIC_BENCH_REHEARSAL=1: several ranks on fewer GPUs over gloo -- exercises the N>1 control flow on a one-GPU box (RCCL
+    # refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get("MASIC_BENCH_REHEARSAL", "0") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     import MASIC
     from masic_amd import nn as mnn

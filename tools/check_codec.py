@@ -30,6 +30,10 @@ def run(N, M, K, H, W, prec, seed=100):
     print("    fwd y1_hat equal:", torch.equal(fwd["y1_hat"], enc["y1_hat"]))
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        run(128, 192, 5, 512, 896, "bf16")
+        run(128, 192, 5, 1216, 2176, "bf16")
+        sys.exit(0)
     run(32, 48, 3, 128, 192, "f32")
     run(32, 48, 3, 128, 192, "bf16")
     run(128, 192, 5, 256, 256, "bf16")
