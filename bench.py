@@ -140,6 +140,16 @@ def main():
             net(x1, x2, hm)
         torch.cuda.synchronize()
         ops.set_kernel_timer(None)
+        # the same symbol with the forward on ONE stream: in the three-stream schedule its launches share the CUs with the
+        # entropy chains of the side streams, which is what the step pays but not what the kernel can do
+        solo = ops.KernelTimer(only=dom)
+        net.serial_schedule = True
+        ops.set_kernel_timer(solo)
+        for _ in range(max(2, args.steps // 4)):
+            net(x1, x2, hm)
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(None)
+        net.serial_schedule = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,7 +167,11 @@ def main():
                 "flops_per_launch": a["flops"] / a["launches"],
                 "share_of_step_time": a["ms"] / (elapsed * 1e3),
                 "timing": "HIP events on the launch stream around every launch of this symbol in an eager pass of the same "
-                          "forward right after the timed region (graph replays cannot be bracketed per kernel)",
+                          "forward right after the timed region (graph replays cannot be bracketed per kernel); the launches "
+                          "share the CUs with the side streams' kernels, as in the timed region",
+                "isolated": (lambda b: {"avg_launch_ms": b["ms"] / b["launches"], "achieved": b["flops"] / b["ms"] / 1e9,
+                                        "frac": b["flops"] / b["ms"] / 1e9 / peak,
+                                        "note": "same symbol, same forward issued on one stream (nothing else on the CUs)"})(solo.summary()[dom]),
                 "all_conv_kernels_ms_per_step_warmup_survey": {k: v["ms"] for k, v in survey_agg.items()}}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

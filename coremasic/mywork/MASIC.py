@@ -103,12 +103,22 @@ class AverageMeter:
 _SIDE_STREAMS = {}
 
 
-def _side_streams(device):
-    """Two extra HIP streams per device for independent branches of the forward (captured into graphs like any other work)."""
+def _side_streams(device, n=4):
+    """Extra HIP streams per device for independent branches of the forward (captured into graphs like any other work):
+    0 the right view's branch, 1 the left view's entropy chain, 2-3 the side stacks of the entropy-parameter heads when those
+    are issued from the main stream (compress / decompress)."""
     key = torch.device(device).index
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(n))
     return _SIDE_STREAMS[key]
+
+
+def _keep_until(t, stream):
+    """Tensor.record_stream for a tensor used on another stream than the one it was allocated on.  Skipped inside a HIP-graph
+    capture: there every cross-stream tensor of the forward lives until all streams have joined the capturing one (and
+    record_stream with a non-capturing-origin stream ends torch's capture with a fault on this ROCm)."""
+    if not torch.cuda.is_current_stream_capturing():
+        t.record_stream(stream)
 
 
 def _bf16_inference(*tensors):
@@ -221,15 +231,22 @@ class _GmmHeads(nn.Module):
                                       H, W, act, want_nchw=last)
         return t
 
-    def heads(self, x):
+    def heads(self, x, parallel=True):
+        """parallel: the means / weights stacks on two side streams forked from the current one.  Callers that are themselves on
+        a side stream pass False: a side stream that forks further streams (or a stream waiting for its own event) ends a
+        HIP-graph capture on this ROCm with a fault in hipStreamEndCapture (measured; torch 2.10 / ROCm 7)."""
         from masic_amd import nn as _mnn
         if _mnn.get_precision() == "bf16" and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
             B, _, H, W = x.shape
             xf = _hip.nchw_to_f16k(x)        # converted once, read by the three stacks
             # the three stacks are independent and each of their GEMMs fills about one wave of workgroups: run them on
             # three HIP streams so that their tails overlap
+            if not parallel:
+                return (self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU)),
+                        self._branch_f16k(self.gmm_means, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)),
+                        self._branch_f16k(self.gmm_weights, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)))
             cur = torch.cuda.current_stream()
-            side = _side_streams(x.device)
+            side = _side_streams(x.device)[2:4]
             ready = torch.cuda.Event()
             ready.record(cur)
             outs = [self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU))]
@@ -241,7 +258,7 @@ class _GmmHeads(nn.Module):
                     done.record(st)
                 cur.wait_event(done)
             for t in outs[1:] + [xf]:
-                t.record_stream(cur)
+                _keep_until(t, cur)
             return tuple(outs)
         sigma = self._branch(self.gmm_sigma, x, (_RELU, _RELU, _RELU))
         means = self._branch(self.gmm_means, x, (_LEAKY, _LEAKY, _NONE))
@@ -639,19 +656,23 @@ class HSIC(CompressionModel):
             "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik},
         }
 
-    # ---- eval-mode forward in three segments (no noise draws, so the order of the branches is free).  Most of the right view
-    # does not depend on the left one -- analysis of (warp(x1), x2), its hyper transforms and context model, the masks and
-    # gates; only warp(x1_hat) -> y1_warp does -- and the hyper transforms are chains of small, latency-bound kernels: on a
-    # side stream they fill the machine while the other view's large convolutions run.
-    #   main : encoder1 -> h_a1, EB1, h_s1_up (ctx1 on stream B) -> heads1 -> decoder1 -> warp -> encoder1(x1_hat_warp)
-    #          -> [join] quantize into cat2 -> heads2 -> decoder2
-    #   A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, ctx2
-    # (Split into functions so that a caller can capture or schedule the segments separately; masic_amd/graph.py captures
-    # _forward_eval as a whole -- three graphs on explicit streams measured the same.)
-    def _eval_right_branch(self, x1, x2, m_fwd, m_back):
+    # ---- eval-mode forward (no noise draws, so the order of its branches is free).  What the reconstructions need is short:
+    #   x1_hat = decoder1(round(y1)),  x2_hat = decoder2(round(y2), warp(x1_hat))
+    # -- the quantised latents do not depend on the entropy parameters (entropy_models.py:851-853: means = None).  Everything
+    # else only produces likelihoods: the hyper transforms, context models and head stacks are chains of small, latency-bound
+    # kernels (a few dozen workgroups each).  They run on two side streams and fill the machine while the large analysis /
+    # synthesis convolutions run:
+    #   main : encoder1 -> round -> decoder1 -> warp -> [y2 from A] round -> decoder2
+    #   E    : context model 1, h_a1 -> EB1 -> h_s1_up -> heads1 -> GMM likelihood
+    #   A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, context model 2
+    #          -> [warp(x1_hat) from main] encoder1 -> round into cat2 -> heads2 -> GMM likelihood
+    # Every fork of this DAG starts on the main stream (nested forks break HIP-graph capture here, see _GmmHeads.heads).  masic_amd/graph.py captures the whole DAG; issued eagerly the same events order it.
+    def _eval_right_branch(self, x1, x2, m_fwd, m_back, ev_y2=None):
         M = self.M
         B, _, H, W = x1.shape
         y2 = self.encoder2.forward_views(_hip.warp_perspective(x1, m_fwd, (H, W)), x2)
+        if ev_y2 is not None:
+            ev_y2.record(torch.cuda.current_stream())
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
         h, w = y2.shape[-2:]
@@ -665,60 +686,75 @@ class HSIC(CompressionModel):
         self._context(self.context_prediction2, y2, cat2, 2 * M, gates, 1)
         return {"y2": y2, "z2_hat": z2_hat, "z2_lik": z2_lik, "cat2": cat2, "gates": gates, "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L}
 
-    def _eval_left_main(self, x1, m_fwd):
+    def _eval_left_entropy(self, y1):
+        """On the current (side) stream: everything of the left view that only feeds likelihoods."""
         M = self.M
-        B, _, H, W = x1.shape
-        cur = torch.cuda.current_stream()
-        sB = _side_streams(x1.device)[1]
-        y1 = self.encoder1.latent(x1)
-        cat1 = torch.empty((B, 4 * M) + tuple(y1.shape[-2:]), dtype=x1.dtype, device=x1.device)   # params1 | ctx_params1
-        ev_y1 = torch.cuda.Event()
-        ev_y1.record(cur)
-        sB.wait_event(ev_y1)
-        with torch.cuda.stream(sB):
-            self._context(self.context_prediction1, y1, cat1, 2 * M)
-            ev_ctx1 = torch.cuda.Event()
-            ev_ctx1.record(sB)
+        B = y1.shape[0]
+        cat1 = torch.empty((B, 4 * M) + tuple(y1.shape[-2:]), dtype=y1.dtype, device=y1.device)   # params1 | ctx_params1
+        self._context(self.context_prediction1, y1, cat1, 2 * M)
         z1 = self._h_a1(y1)
         z1_hat, z1_lik = self.entropy_bottleneck1(z1)
         self._hyper_up(self.h_s1_up, z1_hat, cat1, 0)
-        cur.wait_event(ev_ctx1)
-        s1, m1, l1 = self._h_s1_same_resolution.heads(cat1)
-        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
-        x1_hat = self.decoder1.reconstruct(y1_hat)
-        x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
-        y1_warp = self.encoder1.latent(x1_hat_warp)                                  # the one left -> right dependency
-        return {"x1_hat": x1_hat, "y1_hat": y1_hat, "z1_hat": z1_hat, "y1_lik": y1_lik, "z1_lik": z1_lik,
-                "x1_hat_warp": x1_hat_warp, "y1_warp": y1_warp}
+        s1, m1, l1 = self._h_s1_same_resolution.heads(cat1, parallel=False)
+        _, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
+        return {"z1_hat": z1_hat, "z1_lik": z1_lik, "y1_lik": y1_lik}
 
-    def _eval_tail(self, left, right):
+    def _eval_right_entropy(self, x1_hat_warp, right):
+        """On the right view's stream, after its branch: the warped left reconstruction through the left analysis transform
+        (the one left -> right dependency of the entropy model), then the right view's heads and likelihood."""
         M = self.M
+        y1_warp = self.encoder1.latent(x1_hat_warp)
         cat2, gates, y2 = right["cat2"], right["gates"], right["y2"]
-        _hip.quantize(left["y1_warp"], "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
-        s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
-        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
-        x2_hat = self.decoder2(y2_hat, left["x1_hat_warp"])
-        return {
-            "x1_hat": left["x1_hat"], "x2_hat": x2_hat, "y1_hat": left["y1_hat"], "z1_hat": left["z1_hat"],
-            "x1_mask_R": right["x1_mask_R"], "x1_mask_L": right["x1_mask_L"],
-            "likelihoods": {"y1": left["y1_lik"], "y2": y2_lik, "z1": left["z1_lik"], "z2": right["z2_lik"]},
-        }
+        _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+        s2, m2, l2 = self._h_s2_same_resolution.heads(cat2, parallel=False)
+        _, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
+        return y2_lik
 
     def _forward_eval(self, x1, x2, m_fwd, m_back):
+        B, _, H, W = x1.shape
         cur = torch.cuda.current_stream()
-        sA = _side_streams(x1.device)[0]
-        start = torch.cuda.Event()
+        sA, sE = _side_streams(x1.device)[:2]
+        if getattr(self, "serial_schedule", False):      # everything on the current stream, in issue order (kernel timing in isolation; eager only)
+            sA = sE = cur
+        start, ev_y2 = torch.cuda.Event(), torch.cuda.Event()
         start.record(cur)
         sA.wait_event(start)
         with torch.cuda.stream(sA):
-            right = self._eval_right_branch(x1, x2, m_fwd, m_back)
+            right = self._eval_right_branch(x1, x2, m_fwd, m_back, ev_y2)
+        # left view: analysis, then the reconstruction chain here and the entropy chain beside it
+        y1 = self.encoder1.latent(x1)
+        ev_y1 = torch.cuda.Event()
+        ev_y1.record(cur)
+        sE.wait_event(ev_y1)
+        with torch.cuda.stream(sE):
+            left = self._eval_left_entropy(y1)
+            ev_left = torch.cuda.Event()
+            ev_left.record(sE)
+        _keep_until(y1, sE)
+        y1_hat = _hip.quantize(y1, "dequantize")
+        x1_hat = self.decoder1.reconstruct(y1_hat)
+        x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
+        ev_xw = torch.cuda.Event()
+        ev_xw.record(cur)
+        sA.wait_event(ev_xw)
+        with torch.cuda.stream(sA):
+            y2_lik = self._eval_right_entropy(x1_hat_warp, right)
             ev_right = torch.cuda.Event()
             ev_right.record(sA)
-        left = self._eval_left_main(x1, m_fwd)
+        _keep_until(x1_hat_warp, sA)
+        # right view reconstruction
+        cur.wait_event(ev_y2)
+        y2_hat = _hip.quantize(right["y2"], "dequantize")
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        cur.wait_event(ev_left)
         cur.wait_event(ev_right)
-        for t in right.values():
-            t.record_stream(cur)
-        return self._eval_tail(left, right)
+        for t in list(right.values()) + list(left.values()) + [y2_lik]:
+            _keep_until(t, cur)
+        return {
+            "x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "z1_hat": left["z1_hat"],
+            "x1_mask_R": right["x1_mask_R"], "x1_mask_L": right["x1_mask_L"],
+            "likelihoods": {"y1": left["y1_lik"], "y2": y2_lik, "z1": left["z1_lik"], "z2": right["z2_lik"]},
+        }
 
     def latents(self, x1, x2, h_matrix):
         """Unquantised latents (y1, y2, z1, z2) -- the inputs of the int32 symbol streams that feed the
