@@ -1,6 +1,6 @@
 """HIP-graph replay of the inference forward.
 
-An eval-mode `HSIC.forward` is ~110 dependent launches of 5-300 us on three streams; issued eagerly from Python the host
+An eval-mode `HSIC.forward` is ~110 launches of 5-300 us on three streams (coremasic/mywork/MASIC.py: _forward_eval); issued eagerly from Python the host
 side costs ~15 % of the step.  Everything in it is capturable -- kernels go to torch's current stream, outputs come from
 torch's caching allocator (graph-private pool during capture), weight packs are cached per weight version, the side
 streams fork and join through events -- except the host-side float32 evaluation of the 3x3 sampling matrices
