@@ -334,6 +334,14 @@ int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32
 int masic_homography_from_corners(const float* corners, const float* delta, float* h_out, int B, float scale_a, float scale_b,
                                   void* stream);
 
+/* ---- host data path, SURVEY.md 8(f)-4: one view of a dataset item (compressai/datasets/utils.py:207-285) from the decoded
+ * uint8 RGB picture [H][W][3] on the device: pic_chw (nullable) = the crop [start_h : +ph, start_w : +pw] as float32
+ * [3][ph][pw] / 255 (ToTensor); homo_patch (nullable) = the [homopatch][homopatch] window at (patch_x, patch_y) of
+ * mean_c(Normalize(ToTensor(cv2.resize(crop, (homopic, homopic))))) -- uint8 INTER_LINEAR resize with OpenCV's fixed-point
+ * arithmetic (2x decimation = rounded 2x2 box mean), scalar MEAN / STD of utils.py:26-27. */
+int masic_pair_prep(const uint8_t* img_hwc, int H, int W, int start_h, int start_w, int ph, int pw, float* pic_chw,
+                    int homopic, int patch_x, int patch_y, int homopatch, float* homo_patch, void* stream);
+
 /* ---- HSIC.compress / decompress (MASIC.py:855-1408), SURVEY.md 8(f)-1: the y1 / y2 streams.
  * Per-symbol coding tables (MASIC.py:986-1044 in compress, :1262-1296 in decompress): the K-component Gaussian-mixture
  * PMF of latent element (pixel pix[i], channel chan[j]) over the alphabet 0 .. 2*minmax, clipped to [2^-16, 1],

@@ -54,6 +54,7 @@ SIGNATURES = {
     "masic_rans_encode_with_indexes": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "masic_rans_decode_with_indexes": (c_int, [_P, c_size_t, _P, c_int, _P, c_int, _P, _P, c_int, _P]),
     "masic_homography_from_corners": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
+    "masic_pair_prep": (c_int, [_P] + [c_int] * 6 + [_P] + [c_int] * 4 + [_P, _P]),
     "masic_gmm_cdf_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "masic_rans_encode_freqs": (c_int, [_P, c_size_t, _P, c_size_t, _P]),
     "masic_rans_decoder_open": (c_int, [_P, c_size_t, _P]),

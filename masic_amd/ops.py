@@ -278,6 +278,21 @@ def warp_matrix(M, src_hw, dst_hw, invert_first=False):
     return out
 
 
+def pair_prep(img_u8, start_hw, crop_hw, homopic=256, patch_xy=(0, 0), homopatch=128):
+    """One view of a dataset item (compressai/datasets/utils.py:207-285) from the decoded uint8 RGB picture [H,W,3] on the
+    device -> (float32 [3,ph,pw] crop / 255, float32 [1,homopatch,homopatch] grey patch of the 256 x 256 resized crop)."""
+    if not (isinstance(img_u8, torch.Tensor) and img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3
+            and img_u8.shape[2] == 3 and img_u8.is_contiguous()):
+        raise RuntimeError("masic_amd.pair_prep: the picture must be a contiguous uint8 [H,W,3] CUDA (HIP) tensor")
+    H, W = img_u8.shape[:2]
+    ph, pw = crop_hw
+    pic = torch.empty((3, ph, pw), dtype=torch.float32, device=img_u8.device)
+    patch = torch.empty((1, homopatch, homopatch), dtype=torch.float32, device=img_u8.device)
+    check(lib.masic_pair_prep(_p(img_u8), H, W, int(start_hw[0]), int(start_hw[1]), int(ph), int(pw), _p(pic), int(homopic),
+                              int(patch_xy[0]), int(patch_xy[1]), int(homopatch), _p(patch), _stream()), "pair_prep")
+    return pic, patch
+
+
 def homography_from_corners(corners, delta, ori_hw, patch_hw):
     """h_matrix [B,3,3] of udh/udh/model.py:100-111 + h_adjust (newtrain_codec_real.py:49-59, :129) from the patch corners
     [B,4,2] and the predicted offsets [B,4,2]; ori_hw = picture size, patch_hw = the size the homography net saw."""

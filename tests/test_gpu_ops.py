@@ -513,3 +513,25 @@ def test_homography_from_corners_vs_restatement():
     assert np.abs(back[..., :2] / back[..., 2:] - corners).max() <= 1e-3
     bad = ops.homography_from_corners(torch.zeros(1, 4, 2, device=DEV), torch.zeros(1, 4, 2, device=DEV), (8, 8), (8, 8))
     assert torch.isnan(bad).all()                                       # degenerate quadrilateral: NaN, not garbage
+
+
+@pytest.mark.parametrize("H,W,start,crop,xy", [(600, 700, (31, 57), (512, 512), (45, 83)),      # 2x decimation: OpenCV's INTER_AREA case
+                                              (400, 640, (3, 64), (384, 512), (0, 128)),        # scales 1.5 / 2.0: fixed-point bilinear
+                                              (300, 260, (0, 0), (200, 260), (100, 17)),        # upscaling rows, scale ~1.016 columns
+                                              (256, 256, (0, 0), (256, 256), (64, 64))])         # identity resize
+def test_pair_prep_vs_restatement(H, W, start, crop, xy):
+    """crop + ToTensor and resize + normalise + grey + patch of one view in two launches, against the numpy
+    restatement of the reference's cv2 / torchvision chain (oracle/data_oracle.py; cv2 absent: parity unpinned) -- equal bit for
+    bit: the resize is integer arithmetic, the float32 steps are done in the same order."""
+    ops = _ops()
+    from oracle import data_oracle as D
+    rs = np.random.RandomState(H + W)
+    img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    img[:40, :60] = 255                                               # saturated / flat regions as well
+    img[-30:, -50:] = 0
+    pic, patch = ops.pair_prep(torch.from_numpy(img).to(DEV), start, crop, 256, xy, 128)
+    want_pic, want_patch = D.prepare_view(img, start[0], start[1], crop[0], crop[1], 256, xy[0], xy[1], 128)
+    assert np.array_equal(pic.cpu().numpy(), want_pic)
+    assert np.array_equal(patch.cpu().numpy(), want_patch)
+    with pytest.raises(RuntimeError):
+        ops.pair_prep(torch.from_numpy(img).to(DEV), (H - 10, 0), crop)     # crop outside the picture
