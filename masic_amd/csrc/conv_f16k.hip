@@ -119,6 +119,7 @@ struct F16kArgs {
     unsigned stream_bytes[4];     // bytes of one (phase, co-block) slab stream
     GeomParams q;
     int nphase;
+    int xcd_images;               // B % 8 == 0: image b runs on XCD b % 8 (the halos of its tiles meet in one L2)
 };
 
 #ifndef F16K_ABLATE
@@ -249,13 +250,25 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
     // block -> (tile, phase): the phases of a tile sit 8 block ids apart, i.e. on the same XCD and next to each other in
     // time, so their interleaved output pixels meet in one L2
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int phase = rest % a.nphase;
-    const int tile = (rest / a.nphase) * 8 + xcd;
+    // With a multiple of 8 images, image b = 8 slot + k is walked tile by tile on XCD k (workgroup ids go round-robin over the 8
+    // XCDs and gridDim.x is a multiple of 8): the 5x5 halos that neighbouring tiles share are then re-read from that XCD's L2
+    // instead of HBM (measured on the 128 -> 128 stride-2 layers: 142 -> 129 MB per launch against 105 algorithmic).
+    int phase, tile, b;
+    if (a.xcd_images) {
+        const int idx = (blockIdx.x >> 3) + (gridDim.x >> 3) * blockIdx.z;
+        const int slot = idx / (int)gridDim.x, rest = idx - slot * (int)gridDim.x;
+        b = slot * 8 + (blockIdx.x & 7);
+        phase = rest % a.nphase;
+        tile = rest / a.nphase;
+    } else {
+        const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        phase = rest % a.nphase;
+        tile = (rest / a.nphase) * 8 + xcd;
+        b = blockIdx.z;
+    }
     if (tile >= a.ntiles) return;
     if (F16K_ABLATE == 6) return;                 // launch cost only
     const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
-    const int b = blockIdx.z;
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
     const int nchunks = a.Cin16 / KS;
     const int gpk = a.NPIXp >> 5;                             // DMA wave-instructions per 16-channel plane of the patch (2*NPIXp/64)
@@ -840,7 +853,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                (unsigned)((0x100000000ull + c.PW - 1) / c.PW), (unsigned)((0x100000000ull + c.PWh - 1) / c.PWh),
                (unsigned)((0x100000000ull + c.NPIXp / 32 - 1) / (c.NPIXp / 32)),
                {c.phase_off[0], c.phase_off[1], c.phase_off[2], c.phase_off[3]},
-               {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np};
+               {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np, d->B % 8 == 0};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
 #define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV, NPV)                                                                         \

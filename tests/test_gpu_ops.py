@@ -305,6 +305,8 @@ F16K_CASES = [c for c in CONV_CASES if c[2] % 16 == 0 and c[5] >= 64 and c[5] % 
     ("ctx_masked_f16k", 2, 192, 16, 24, 384, 5, 1, False, True, 0, 0),
     ("g_a_conv2_big",   1, 128, 136, 200, 128, 5, 2, False, False, 0, 0),     # several tiles, ragged right / bottom edges
     ("g_s_conv3_big",   1, 128, 40, 72, 128, 5, 2, True, False, 0, 0),
+    ("g_a_conv2_b8",    8, 128, 40, 72, 128, 5, 2, False, False, 0, 0),       # 8 images: one image per XCD (the block -> tile map of B % 8 == 0)
+    ("g_s_conv3_b16",  16, 128, 12, 20, 192, 5, 2, True, False, 0, 0),        # two image slots per XCD, two output-channel blocks, 4 phases
 ]
 
 
