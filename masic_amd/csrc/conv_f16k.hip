@@ -25,6 +25,8 @@
 //
 // Epilogue: bias + activation, then either float32 NCHW (channel view of a concat buffer, optional gate) or F16K bf16
 // for the next layer.
+#include <stdlib.h>
+
 #include "common.h"
 #include <type_traits>
 #include "conv_geom.h"
@@ -125,7 +127,7 @@ struct F16kArgs {
 #ifndef F16K_ABLATE
 #define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers, 3 no fragment reads, 4 a quarter of the MFMAs
 #endif
-constexpr int MAXTAPS = 32;   // tap table entries (taps of a phase padded to a multiple of T)
+constexpr int MAXTAPS = 64;   // tap table entries ([step][T rounded up to a power of two])
 
 // Weights for this path, in the order the kernel consumes them ("slab stream"): for each phase, each 128-channel
 // co-block, each chunk c of KS 16-channel blocks, each step t of T taps (taps padded with zeros to a multiple of T):
@@ -323,8 +325,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 #pragma unroll
         for (int n = 0; n < NP; ++n) bl[n] = (h * a.NPIXp + (((wave * NP + n) * a.SR + jr) * g.is) * PWe + jc) * 16;
         // tap table: byte offset of each tap's record inside the LDS patch image (padding taps alias tap 0; their weights are zero)
-        if (tid < MAXTAPS) {
-            const int tap = tid < g.ntaps ? tid : 0;
+        if (tid < MAXTAPS) {                                   // [step][TP] entries, TP = T rounded up to a power of two
+            constexpr int TP = T == 5 ? 8 : T;
+            const int tidx = (tid / TP) * T + (tid % TP);
+            const int tap = (tid % TP) < T && tidx < g.ntaps ? tidx : 0;
             const int ti = tap / g.ntw, tj = tap - ti * g.ntw;
             const int ta = (g.dh0 - g.dh_min) + ti * g.dsh, tb = (g.dw0 - g.dw_min) + tj * g.dsw;
             const int slot = g.is == 2 ? ((tb & 1) * a.PH + ta) * a.PWh + (tb >> 1) : ta * a.PW + tb;
@@ -392,14 +396,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         // `s_waitcnt vmcnt(0)` in front (the DMA in flight might alias it), which would drain the prefetch queue every step.
         // The fragments of k-step i+1 are requested before the MFMAs of k-step i are issued.
         v4u tvv;
-        if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 16) : "memory");
+        unsigned tv4 = 0;
+        if constexpr (T == 5) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 32) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(tv4) : "v"(ldsb + table_off + t * 32) : "memory");
+        } else if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 16) : "memory");
         else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv), "+v"(tv4)::"memory");
         const unsigned wst = ldsb + al + cslot;
         v4u af[2][NM], bfr[2][NP];
         auto request = [&](auto ic, auto bc) {
             constexpr int i = decltype(ic)::value, buf = decltype(bc)::value, tt = i / KS, ks = i % KS;
-            const unsigned toff = ldsb + cb + tvv[tt] + ks * gpk * 1024;
+            const unsigned toff = ldsb + cb + (tt < 4 ? tvv[tt < 4 ? tt : 0] : tv4) + ks * gpk * 1024;
             static_for<0, NP>([&](auto nc) {
                 constexpr int n = decltype(nc)::value;
                 ds_read128<0>(bfr[buf][n], toff + bl[n]);
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
 
 struct F16kCfg {
     int ok;
-    int KS, T, L, NP;             // template selection: strided conv <1,4,D,6,1>, stride-1 walk <2,2,D,3,2>, large stride-1 walk <1,2,D,*,2> with NP > 1
+    int KS, T, L, NP, D;          // template selection: strided conv <1,4,D,6,1>, stride-1 walk <2,2,D,3,2>, large stride-1 walk <1,2,D,*,2> with NP > 1
     int TW, TWlog, SR, TH, PH, PW, PWh, NPIXp, PB;
     int Cin16, ncb;
     unsigned phase_off[4], stream_bytes[4];
@@ -702,15 +710,21 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     const int is = g[0].is, Wp = g[0].Wp, Hp = g[0].Hp;
     int NPI;
     c.NP = 1;
+    c.D = F16K_D;
     if (is == 2) { c.KS = 1; c.T = 4; NPI = 12; c.L = 1; }    // strided conv: big patch, 16-channel chunks, 4 taps per step
     else { c.KS = 2; c.T = 2; NPI = 8; c.L = 2; }             // stride-1 walk (transposed phases, 3x3, 5x5 s1, masked): 32-channel chunks
+    // strided 5x5: 5 taps per step -- 25 taps need no zero-weight padding (4 per step pad to 28: 12 % more MFMAs) and a chunk
+    // takes 5 barriers instead of 7; the 20-KiB slab groups leave room for a 3-slot ring only (look-ahead 2 steps = 40 MFMAs per
+    // wave).  MASIC_F16K_T5=0 keeps 4 taps per step (A/B timing).
+    static const bool t5 = !(getenv("MASIC_F16K_T5") && getenv("MASIC_F16K_T5")[0] == '0');
+    if (t5 && is == 2 && min_taps == 25 && max_taps == 25) { c.T = 5; c.D = 2; }
     // large stride-1-walk layers: 512- (128-channel blocks) or 1024-pixel tiles (<= 32 channels), 16-channel chunks
     if (is == 1 && Wp >= 32) {
         const int np = d.Cout <= 32 ? 4 : 2;
         const long tiles = (long)ceil_div(Wp, 32) * ceil_div(Hp, 8 * np) * nphase * d.B * ceil_div(d.Cout, 128);
         if (tiles >= 512 && ceil_div(min_taps, 2) >= 2) { c.NP = np; c.KS = 1; c.T = 2; c.L = 2; NPI = np == 4 ? 10 : 6; }
     }
-    if (round_up(max_taps, c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
+    if (ceil_div(max_taps, c.T) * (c.T == 5 ? 8 : c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
     c.Cin16 = d.Cin / 16;
     if (c.Cin16 % c.KS != 0) return c;                        // whole chunks only
     c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
@@ -736,7 +750,7 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     }
     if (off >= (1u << 31)) return c;
     c.packed_bytes = off;
-    c.lds_bytes = (size_t)(F16K_D + 1) * c.T * c.KS * 4096 + (size_t)(c.L + 1) * c.PB + 1024 + MAXTAPS * 4;
+    c.lds_bytes = (size_t)(c.D + 1) * c.T * c.KS * 4096 + (size_t)(c.L + 1) * c.PB + 1024 + MAXTAPS * 4;
     if (c.lds_bytes > 160 * 1024 || c.lds_bytes < 65536 + 2048) return c;       // (the fused GDN parks its 64 KiB image + beta^ at offset 0)
     c.ok = 1;
     return c;
@@ -761,7 +775,7 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
     if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
-    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, 4, %d, 6, 1, %s, 4, 1>", F16K_D, gdn ? "true" : "false");
+    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1>", c.T, c.D, gdn ? "true" : "false");
     else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
 }
@@ -856,9 +870,9 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np, d->B % 8 == 0};
     dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
     hipStream_t st = (hipStream_t)stream;
-#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV, NPV)                                                                         \
+#define F16K_LAUNCH_D(KSV, TV, DV, PSPV, LV, GDNV, NMV, NPV)                                                                   \
     do {                                                                                                             \
-        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV, NMV, NPV>;                                                     \
+        auto kfn = conv_f16k<KSV, TV, DV, PSPV, LV, GDNV, NMV, NPV>;                                                         \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -866,12 +880,16 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         }                                                                                                            \
         hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
     } while (0)
+#define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV, NPV) F16K_LAUNCH_D(KSV, TV, F16K_D, PSPV, LV, GDNV, NMV, NPV)
     MASIC_REQUIRE(c.NP == 1 || (d->Cout <= 32) == (c.NP == 4), MASIC_ERR_UNSUPPORTED, "conv_f16k: tile configuration");
     if (c.NP == 4) {
         F16K_LAUNCH(1, 2, 5, 2, false, 1, 4);
     } else if (c.NP == 2) {
         if (gdn_packed) F16K_LAUNCH(1, 2, 3, 2, true, 4, 2);
         else F16K_LAUNCH(1, 2, 3, 2, false, 4, 2);
+    } else if (c.KS == 1 && c.T == 5) {
+        if (gdn_packed) F16K_LAUNCH_D(1, 5, 2, 6, 1, true, 4, 1);
+        else F16K_LAUNCH_D(1, 5, 2, 6, 1, false, 4, 1);
     } else if (c.KS == 1) {
         if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4, 1);
         else F16K_LAUNCH(1, 4, 6, 1, false, 4, 1);
@@ -881,6 +899,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         else F16K_LAUNCH(2, 2, 4, 2, false, 4, 1);
     }
 #undef F16K_LAUNCH
+#undef F16K_LAUNCH_D
     return masic_launch_status("conv_f16k_fwd");
 }
 }  // namespace
