@@ -723,6 +723,10 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         const int np = d.Cout <= 32 ? 4 : 2;
         const long tiles = (long)ceil_div(Wp, 32) * ceil_div(Hp, 8 * np) * nphase * d.B * ceil_div(d.Cout, 128);
         if (tiles >= 512 && ceil_div(min_taps, 2) >= 2) { c.NP = np; c.KS = 1; c.T = 2; c.L = 2; NPI = np == 4 ? 10 : 6; }
+        // 128-channel blocks: 32-channel chunks (2 taps x 2 channel blocks = 32 MFMAs per wave and barrier instead of 16), one chunk of
+        // patch look-ahead and a 3-slot ring.  MASIC_F16K_KS2=0 keeps 16-channel chunks (A/B timing).
+        static const bool ks2 = !(getenv("MASIC_F16K_KS2") && getenv("MASIC_F16K_KS2")[0] == '0');
+        if (ks2 && c.NP == 2 && d.Cin % 32 == 0) { c.KS = 2; c.D = 2; c.L = 1; NPI = 10; }
     }
     if (ceil_div(max_taps, c.T) * (c.T == 5 ? 8 : c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
     c.Cin16 = d.Cin / 16;
@@ -774,7 +778,8 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
-    if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
+    if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2>", gdn ? "true" : "false");
+    else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
     else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1>", c.T, c.D, gdn ? "true" : "false");
     else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
@@ -885,7 +890,10 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (c.NP == 4) {
         F16K_LAUNCH(1, 2, 5, 2, false, 1, 4);
     } else if (c.NP == 2) {
-        if (gdn_packed) F16K_LAUNCH(1, 2, 3, 2, true, 4, 2);
+        if (c.KS == 2) {
+            if (gdn_packed) F16K_LAUNCH_D(2, 2, 2, 5, 1, true, 4, 2);
+            else F16K_LAUNCH_D(2, 2, 2, 5, 1, false, 4, 2);
+        } else if (gdn_packed) F16K_LAUNCH(1, 2, 3, 2, true, 4, 2);
         else F16K_LAUNCH(1, 2, 3, 2, false, 4, 2);
     } else if (c.KS == 1 && c.T == 5) {
         if (gdn_packed) F16K_LAUNCH_D(1, 5, 2, 6, 1, true, 4, 1);
