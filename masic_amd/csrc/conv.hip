@@ -842,7 +842,10 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
     __shared__ __attribute__((aligned(16))) float lds[8 * PSZ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tx = tid & 15, ty = tid >> 4;
+    // a wave takes rows wave, wave+4, wave+8, wave+12 of the tile: with the 20-float row pitch their 16-lane runs start 80 floats
+    // = 16 banks apart, so the 64 lanes of a tap read hit 64 different banks (adjacent rows overlap in 12 of them: measured
+    // half of the LDS cycles were conflicts)
+    const int tx = tid & 15, ty = ((tid >> 4) & 3) * 4 + (tid >> 6);
     const int tile_x = blockIdx.x % a.tiles_w, tile_y = blockIdx.x / a.tiles_w;
     const int b = blockIdx.y;
     const int oy = tile_y * T + ty, ox = tile_x * T + tx;
