@@ -321,6 +321,17 @@ def test_bf16_operand_path_config1_accuracy_streams_and_graph():
                 assert torch.equal(rep[k], out[k]), k
             for k in out["likelihoods"]:
                 assert torch.equal(rep["likelihoods"][k], out["likelihoods"][k]), k
+            # a new batch written straight into the graph's input buffers and passed back (no copy) == the same batch passed from outside
+            xa, xb = graphed.inputs
+            y1n, y2n = x1.flip(-1).contiguous(), x2.flip(-2).contiguous()
+            want = {k: v.clone() for k, v in graphed(y1n, y2n, hm).items() if torch.is_tensor(v)}
+            xa.copy_(y1n)
+            xb.copy_(y2n)
+            got = graphed(xa, xb, hm)
+            torch.cuda.synchronize()
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+            assert not torch.equal(want["x1_hat"], out["x1_hat"])
     finally:
         mnn.set_precision("f32")
     for k in ("x1_mask_R", "x1_mask_L"):
