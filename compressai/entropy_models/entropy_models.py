@@ -318,9 +318,7 @@ class GaussianMixtureConditional(_GaussianBase):
         lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
         if self.training and torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, scales, means, weights)):
             from masic_amd import autograd as A
-            if not weights_are_logits:
-                raise NotImplementedError("training-mode GMM on pre-normalised weights: pass the head logits (weights_are_logits=True)")
-            return A.GmmFn.apply(inputs, noise, scales, means, weights, self.K, self._scale_bound_value, lb)
+            return A.GmmFn.apply(inputs, noise, scales, means, weights, self.K, self._scale_bound_value, lb, bool(weights_are_logits))
         return _hip.gmm_likelihood(inputs.contiguous(), scales.contiguous(), means.contiguous(), weights.contiguous(),
                                    self.K, training=self.training, noise=noise, weights_are_logits=weights_are_logits,
                                    scale_bound=self._scale_bound_value,

@@ -29,6 +29,7 @@ from compressai.models.utils import conv, deconv, update_registered_buffers  # n
 from masic_amd import ops as _hip
 from masic_amd.homography import warp_matrices as _warp_matrices
 from masic_amd import autograd as _ag
+from masic_amd.streams import ForkJoin as _ForkJoin
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
 
@@ -245,18 +246,17 @@ class _GmmHeads(nn.Module):
                 return (self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU)),
                         self._branch_f16k(self.gmm_means, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)),
                         self._branch_f16k(self.gmm_weights, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)))
-            cur = torch.cuda.current_stream()
+            fj = _ForkJoin()               # raises (instead of faulting in hipStreamEndCapture) if we are on a side stream of a capture
+            cur = fj.main
             side = _side_streams(x.device)[2:4]
-            ready = torch.cuda.Event()
-            ready.record(cur)
-            outs = [self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU))]
-            for st, (seq, acts) in zip(side, ((self.gmm_means, (_LEAKY, _LEAKY, _NONE)), (self.gmm_weights, (_LEAKY, _LEAKY, _NONE)))):
-                st.wait_event(ready)
-                with torch.cuda.stream(st):
-                    outs.append(self._branch_f16k(seq, xf, B, H, W, acts))
-                    done = torch.cuda.Event()
-                    done.record(st)
-                cur.wait_event(done)
+            outs = [None, None, None]
+            for i, (st, (seq, acts)) in enumerate(zip(side, ((self.gmm_means, (_LEAKY, _LEAKY, _NONE)), (self.gmm_weights, (_LEAKY, _LEAKY, _NONE))))):
+                fj.fork(st)
+                with fj.on(st):
+                    outs[i + 1] = self._branch_f16k(seq, xf, B, H, W, acts)
+            outs[0] = self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU))
+            for st in side:
+                fj.join(st)
             for t in outs[1:] + [xf]:
                 _keep_until(t, cur)
             return tuple(outs)
@@ -606,6 +606,11 @@ class HSIC(CompressionModel):
 
         m_fwd, m_back = warp_matrices if warp_matrices is not None else _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
         if not train:
+            if getattr(self, "eval_autograd", False) and torch.is_grad_enabled():
+                # the graph the reference records when CQE training runs HSIC in eval mode WITHOUT no_grad (newtrain_cqe_real.py:130,
+                # :160): round() has zero gradient, so only the two synthesis transforms (and the warp between them) carry any
+                with torch.no_grad():
+                    return self._forward_eval(x1, x2, m_fwd, m_back, synthesis_grad=True)
             return self._forward_eval(x1, x2, m_fwd, m_back)
 
         # ---- left view
@@ -667,12 +672,12 @@ class HSIC(CompressionModel):
     #   A    : warp(x1) -> encoder2 -> h_a2 -> EB2 -> masks -> mask2weights -> h_s2_up, context model 2
     #          -> [warp(x1_hat) from main] encoder1 -> round into cat2 -> heads2 -> GMM likelihood
     # Every fork of this DAG starts on the main stream (nested forks break HIP-graph capture here, see _GmmHeads.heads).  masic_amd/graph.py captures the whole DAG; issued eagerly the same events order it.
-    def _eval_right_branch(self, x1, x2, m_fwd, m_back, ev_y2=None):
+    def _eval_right_branch(self, x1, x2, m_fwd, m_back, on_y2=None):
         M = self.M
         B, _, H, W = x1.shape
         y2 = self.encoder2.forward_views(_hip.warp_perspective(x1, m_fwd, (H, W)), x2)
-        if ev_y2 is not None:
-            ev_y2.record(torch.cuda.current_stream())
+        if on_y2 is not None:
+            on_y2()                # the reconstruction chain on the main stream only needs y2, not the entropy side of this branch
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
         h, w = y2.shape[-2:]
@@ -710,44 +715,52 @@ class HSIC(CompressionModel):
         _, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
         return y2_lik
 
-    def _forward_eval(self, x1, x2, m_fwd, m_back):
+    def _forward_eval(self, x1, x2, m_fwd, m_back, synthesis_grad=False):
+        """synthesis_grad (called under no_grad): decoder1 -> warp -> decoder2 are recorded as differentiable HIP nodes, the
+        rest of the forward stays the fused inference schedule (`eval_autograd`, see forward)."""
+        import contextlib
+        recorded = torch.enable_grad if synthesis_grad else contextlib.nullcontext
         B, _, H, W = x1.shape
-        cur = torch.cuda.current_stream()
+        fj = _ForkJoin()             # every cross-stream wait goes through it: the three capture rules raise instead of faulting
+        cur = fj.main
         sA, sE = _side_streams(x1.device)[:2]
         if getattr(self, "serial_schedule", False):      # everything on the current stream, in issue order (kernel timing in isolation; eager only)
             sA = sE = cur
-        start, ev_y2 = torch.cuda.Event(), torch.cuda.Event()
-        start.record(cur)
-        sA.wait_event(start)
-        with torch.cuda.stream(sA):
-            right = self._eval_right_branch(x1, x2, m_fwd, m_back, ev_y2)
+        serial = sA is cur
+        if not serial:
+            fj.fork(sA)
+        with fj.on(sA):
+            y2_ready = []
+            right = self._eval_right_branch(x1, x2, m_fwd, m_back, on_y2=lambda: y2_ready.append(fj.record(sA)))
+            ev_y2 = y2_ready[0]
         # left view: analysis, then the reconstruction chain here and the entropy chain beside it
         y1 = self.encoder1.latent(x1)
-        ev_y1 = torch.cuda.Event()
-        ev_y1.record(cur)
-        sE.wait_event(ev_y1)
-        with torch.cuda.stream(sE):
+        if not serial:
+            fj.fork(sE)
+        with fj.on(sE):
             left = self._eval_left_entropy(y1)
-            ev_left = torch.cuda.Event()
-            ev_left.record(sE)
+            ev_left = fj.record(sE)
         _keep_until(y1, sE)
         y1_hat = _hip.quantize(y1, "dequantize")
-        x1_hat = self.decoder1.reconstruct(y1_hat)
-        x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))                   # used twice (:821, :833)
-        ev_xw = torch.cuda.Event()
-        ev_xw.record(cur)
-        sA.wait_event(ev_xw)
-        with torch.cuda.stream(sA):
+        with recorded():
+            x1_hat = self.decoder1(y1_hat)[0] if synthesis_grad else self.decoder1.reconstruct(y1_hat)
+            x1_hat_warp = (_ag.WarpFn.apply(x1_hat, m_fwd, (H, W)) if synthesis_grad
+                           else _hip.warp_perspective(x1_hat, m_fwd, (H, W)))        # used twice (:821, :833)
+        if not serial:
+            fj.fork(sA)
+        with fj.on(sA):
             y2_lik = self._eval_right_entropy(x1_hat_warp, right)
-            ev_right = torch.cuda.Event()
-            ev_right.record(sA)
+            ev_right = fj.record(sA)
         _keep_until(x1_hat_warp, sA)
         # right view reconstruction
-        cur.wait_event(ev_y2)
+        if not serial:
+            fj.wait(cur, ev_y2)
         y2_hat = _hip.quantize(right["y2"], "dequantize")
-        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
-        cur.wait_event(ev_left)
-        cur.wait_event(ev_right)
+        with recorded():
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        if not serial:
+            fj.wait(cur, ev_left)
+            fj.wait(cur, ev_right)
         for t in list(right.values()) + list(left.values()) + [y2_lik]:
             _keep_until(t, cur)
         return {
@@ -778,7 +791,12 @@ class HSIC(CompressionModel):
 
     # ---- bitstream (reference :855-1408).  masic_amd/codec.py holds the wavefront coder; here the model
     # side: which tensors condition the tables of each view, computed identically by compress and decompress.
-    def _codec_check(self, B):
+    def _codec_check(self, B, H=None, W=None):
+        if H is not None and (H % 64 or W % 64):
+            # the header stores H, W and the decoder derives the latent geometry as H//16, H//64 (reference :1308-1322); other
+            # sizes would be written with ceil-div latents that decompress cannot reproduce
+            raise ValueError(f"HSIC.compress/decompress: picture size {H}x{W} must be a multiple of 64 in both dimensions "
+                             "(pad the pair as the reference's drivers do)")
         if self.training:
             raise RuntimeError("HSIC.compress/decompress: call .eval() first (the reference quantises with noise in training mode)")
         if B != 1:
@@ -825,7 +843,7 @@ class HSIC(CompressionModel):
         from masic_amd import codec, nn as _mnn
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, _, H, W = x1.shape
-        self._codec_check(B)
+        self._codec_check(B, H, W)
         M, K = self.M, self.K
         with torch.no_grad():
             m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
@@ -898,6 +916,7 @@ class HSIC(CompressionModel):
             for _ in range(2):
                 n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])
                 streams.append(f.read(n))
+        self._codec_check(1, H, W)
         h, w = H // 16, W // 16
         with torch.no_grad():
             m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
@@ -964,7 +983,41 @@ class Independent_EN(nn.Module):
         self.conv2 = conv3x3(96, 3)
         self.mask2weights_unit = mask2weights_EN()
 
+    def _needs_graph(self, *inputs):
+        return torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in self.parameters()))
+
+    def _forward_graph(self, x1_hat, x2_hat, h_matrix):
+        """The same arithmetic as a differentiable graph of HIP nodes (masic_amd/autograd.py) for the CQE training step
+        (reference newtrain_cqe_real.py:128-174): every warp of a tensor that carries gradient, every gate product and every
+        concat is a node with a HIP backward, so all 86 parameters receive their gradient; the inference-only fusions (gated
+        writes into concat buffers) are not used.  The masks carry no gradient (functions of h_matrix only, which the drivers
+        detach)."""
+        x1_hat = x1_hat.contiguous()
+        x2_hat = x2_hat.contiguous()
+        B, _, H, W = x1_hat.shape
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        mask_L = _hip.warp_perspective(mask_R, m_back, (H, W))
+        w_R = self.mask2weights_unit(mask_R)
+        w_L = self.mask2weights_unit(mask_L)
+
+        def warp(t, m):
+            return _ag.WarpFn.apply(t, m, (H, W)) if t.requires_grad else _hip.warp_perspective(t, m, (H, W))
+        gate = _ag.GateFn.apply
+        x1_warp, x2_warp = warp(x1_hat, m_fwd), warp(x2_hat, m_back)
+        x1c, x2c = self.conv0(x1_hat), self.conv0(x2_hat)
+        out1 = self.EBl1(self.conv1(_ag.cat(gate(x2_warp, w_L, 0), gate(x1_hat, w_L, 1))))      # :1470
+        out2 = self.EBr1(self.conv1(_ag.cat(gate(x1_warp, w_R, 0), gate(x2_hat, w_R, 1))))      # :1471
+        out1_warp, out2_warp = warp(out1, m_fwd), warp(out2, m_back)
+        out1 = self.EBl2(_ag.cat(gate(out1, w_L, 1), gate(out2_warp, w_L, 0)))                  # :1481
+        out2 = self.EBr2(_ag.cat(gate(out2, w_R, 1), gate(out1_warp, w_R, 0)))                  # :1482
+        out1 = self.EBl3(_ag.cat(out1, x1c))
+        out2 = self.EBr3(_ag.cat(out2, x2c))
+        return {"x1_hat": self.conv2.run(out1, res1=x1_hat), "x2_hat": self.conv2.run(out2, res1=x2_hat)}
+
     def forward(self, x1_hat, x2_hat, h_matrix):
+        if self._needs_graph(x1_hat, x2_hat):
+            return self._forward_graph(x1_hat, x2_hat, h_matrix)
         x1_hat = x1_hat.contiguous()
         x2_hat = x2_hat.contiguous()
         B, _, H, W = x1_hat.shape

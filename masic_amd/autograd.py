@@ -156,14 +156,16 @@ class AuxLossFn(Function):
 
 
 class GmmFn(Function):
-    """training-mode GaussianMixtureConditional_gf.forward with the softmax over K fused: (y, noise, sigma, mu, logits)."""
+    """training-mode GaussianMixtureConditional_gf.forward: (y, noise, sigma, mu, weights).  `are_logits`: the weights are the
+    head's logits and the softmax over K runs inside the kernels (HSIC's own calls); False: already-normalised weights, the
+    reference's signature (entropy_models.py:836-858 called as at MASIC.py:767)."""
 
     @staticmethod
-    def forward(ctx, y, noise, sigma, mu, logits, K, scale_bound, lik_bound):
+    def forward(ctx, y, noise, sigma, mu, logits, K, scale_bound, lik_bound, are_logits=True):
         y, sigma, mu, logits = _c(y), _c(sigma), _c(mu), _c(logits)
-        y_hat, lik = ops.gmm_likelihood(y, sigma, mu, logits, K, training=True, noise=noise, weights_are_logits=True,
+        y_hat, lik = ops.gmm_likelihood(y, sigma, mu, logits, K, training=True, noise=noise, weights_are_logits=are_logits,
                                         scale_bound=scale_bound, lik_bound=lik_bound)
-        ctx.K, ctx.sb, ctx.lb = K, scale_bound, lik_bound
+        ctx.K, ctx.sb, ctx.lb, ctx.are_logits = K, scale_bound, lik_bound, bool(are_logits)
         ctx.save_for_backward(y_hat, sigma, mu, logits)
         return y_hat, lik
 
@@ -172,8 +174,8 @@ class GmmFn(Function):
         y_hat, sigma, mu, logits = ctx.saved_tensors
         g_lik = _c(g_lik) if g_lik is not None else torch.zeros_like(y_hat)
         g_yhat = _c(g_yhat) if g_yhat is not None else None
-        g_y, g_s, g_m, g_w = ops.gmm_likelihood_bwd(y_hat, sigma, mu, logits, g_lik, g_yhat, ctx.K, True, ctx.sb, ctx.lb)
-        return g_y, None, g_s, g_m, g_w, None, None, None
+        g_y, g_s, g_m, g_w = ops.gmm_likelihood_bwd(y_hat, sigma, mu, logits, g_lik, g_yhat, ctx.K, ctx.are_logits, ctx.sb, ctx.lb)
+        return g_y, None, g_s, g_m, g_w, None, None, None, None
 
 
 class AddNoiseFn(Function):

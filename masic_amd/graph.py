@@ -16,13 +16,21 @@ from .homography import warp_matrices_host
 
 class GraphedHSIC:
     """Callable with the signature of `HSIC.forward`; outputs are static tensors that the next call overwrites.
-    `h_matrix` may be a CPU tensor; if it is a device tensor it must already be complete when the call is made (it is read
-    on a separate copy stream so that the read does not wait for the previous replay)."""
+    `h_matrix` may be a CPU tensor or a device tensor (read on a separate copy stream after an event recorded on the
+    caller's stream, so a homography just produced there is complete when it is read)."""
 
-    def __init__(self, net, x1, x2, h_matrix, warmup=2):
+    def __init__(self, net, x1, x2, h_matrix, warmup=2, on_stale="recapture"):
+        """on_stale: what a call does when a parameter or buffer of `net` has changed since the capture (optimizer step,
+        load_state_dict, .to()): "recapture" (default) or "raise".  The captured kernels hold raw pointers to the weight packs
+        and tables derived from the parameters; those tensors are kept alive by this object, and they are never replayed
+        against parameters they were not derived from."""
         if net.training:
             raise RuntimeError("GraphedHSIC captures the eval-mode forward")
+        if on_stale not in ("recapture", "raise"):
+            raise ValueError("on_stale must be 'recapture' or 'raise'")
         self.net = net
+        self.on_stale = on_stale
+        self.warmup = warmup
         dev = x1.device
         self.x1, self.x2 = x1.clone(), x2.clone()
         H, W = x1.shape[-2:]
@@ -40,21 +48,45 @@ class GraphedHSIC:
             ev.record(torch.cuda.current_stream())
         self.parity = 0
         self._prepare(h_matrix)
+        self._capture()
+
+    def _capture(self):
+        from . import nn as _mnn
+        net = self.net
+        if net.training:
+            raise RuntimeError("GraphedHSIC captures the eval-mode forward; the model was put in training mode")
         torch.cuda.current_stream().synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                      # packs weights, warms the allocator
+            for _ in range(self.warmup):                 # packs weights, warms the allocator
                 net(self.x1, self.x2, self.h, warp_matrices=(self.mf, self.mb))
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = net(self.x1, self.x2, self.h, warp_matrices=(self.mf, self.mb))
+        # what the captured launches point at: every weight pack / table the forward used, and what they were derived from
+        self._packs = _mnn.cached_packs(net)
+        self._sources = _mnn.pack_sources(net)
+        self._signature = _mnn.pack_signature(self._sources)
+        self._precision = _mnn.get_precision()
+
+    def _check_fresh(self):
+        from . import nn as _mnn
+        if _mnn.pack_signature(self._sources) == self._signature and _mnn.get_precision() == self._precision and not self.net.training:
+            return
+        if self.on_stale == "raise":
+            raise RuntimeError("GraphedHSIC: the model's parameters / buffers, its mode or the operand precision changed since the "
+                               "capture; build a new GraphedHSIC (or pass on_stale='recapture')")
+        self._capture()
 
     def _prepare(self, h_matrix):
         """Host chain for this call's homography and its upload; the main stream is made to wait for the upload only."""
         cs = self.copy_stream
         if h_matrix.is_cuda:
+            produced = torch.cuda.Event()
+            produced.record(torch.cuda.current_stream())     # the homography may just have been produced on the caller's stream
+            cs.wait_event(produced)
             with torch.cuda.stream(cs):
                 self.h_pinned.copy_(h_matrix.detach().to(torch.float32), non_blocking=True)
             cs.synchronize()
@@ -87,6 +119,7 @@ class GraphedHSIC:
         return self.x1, self.x2
 
     def __call__(self, x1, x2, h_matrix):
+        self._check_fresh()
         self._prepare(h_matrix)
         if x1 is not self.x1:
             self.x1.copy_(x1)

@@ -44,3 +44,21 @@ def rate_distortion(output, target1, target2, lmbda):
     out["psnr1"] = 10 * math.log10(1 / float(mse1))
     out["psnr2"] = 10 * math.log10(1 / float(mse2))
     return out
+
+
+def distortion(output, target1, target2, lmbda):
+    """The criterion of the CQE stage (coremasic/mywork/newtrain_cqe_real.py:66-96, kind=0): loss = lmbda * 255^2 *
+    (MSE(x1_hat, d1) + MSE(x2_hat, d2)) on the outputs of Independent_EN, plus psnr1 / psnr2 (the reference's MS-SSIM entries
+    are reporting only and need pytorch_msssim, which is outside the path)."""
+    import torch
+    x1_hat, x2_hat = output["x1_hat"], output["x2_hat"]
+    mse1 = ops.sse(x1_hat.detach().contiguous(), target1.contiguous()) / target1.numel()
+    mse2 = ops.sse(x2_hat.detach().contiguous(), target2.contiguous()) / target2.numel()
+    mse = mse1 + mse2
+    if torch.is_grad_enabled() and (x1_hat.requires_grad or x2_hat.requires_grad):
+        from .autograd import RateDistortionFn
+        loss = RateDistortionFn.apply(lmbda, target1, target2, x1_hat, x2_hat)      # no likelihood terms: distortion only
+    else:
+        loss = (lmbda * 255 ** 2 * mse).float()
+    return {"mse_loss": mse.float(), "loss": loss, "mse1": mse1, "mse2": mse2,
+            "psnr1": 10 * math.log10(1 / float(mse1)), "psnr2": 10 * math.log10(1 / float(mse2))}

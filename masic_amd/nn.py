@@ -34,6 +34,49 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def _cached(obj, slot, version_key, shape_key, build):
+    """Per-module pack cache: one dict per parameter version, one entry per (shape, precision) it was packed for.  A call at
+    another shape adds an entry instead of evicting the previous one -- a captured HIP graph (masic_amd/graph.py) keeps
+    replaying against the pack it was captured with; a new parameter version (optimizer step, load_state_dict) drops them all."""
+    d = obj.__dict__.get(slot)
+    if d is None or d[0] != version_key:
+        d = (version_key, {})
+        obj.__dict__[slot] = d
+    t = d[1].get(shape_key)
+    if t is None:
+        t = d[1][shape_key] = build()
+    return t
+
+
+def pack_sources(module):
+    """The tensors every cached pack / table of `module` is derived from: its parameters (all of them -- HSIC.parameters()
+    hides the entropy bottlenecks) and the context models' mask buffers."""
+    return [t for _, t in module.named_parameters()] + [t for n, t in module.named_buffers() if n.endswith(".mask")]
+
+
+def pack_signature(tensors):
+    """(version counter, storage pointer) of each source tensor.  GraphedHSIC compares it before each replay (~50 us)."""
+    return tuple([(t._version, t.data_ptr()) for t in tensors])
+
+
+def cached_packs(module):
+    """Every pack / table tensor currently cached under `module` (held by GraphedHSIC so that they outlive the caches)."""
+    out = []
+    for m in module.modules():
+        for k, v in m.__dict__.items():
+            if k.endswith("_cache") and isinstance(v, tuple):
+                stack = list(v[1:])
+                while stack:
+                    x = stack.pop()
+                    if isinstance(x, torch.Tensor):
+                        out.append(x)
+                    elif isinstance(x, dict):
+                        stack.extend(x.values())
+                    elif isinstance(x, (tuple, list)):
+                        stack.extend(x)
+    return out
+
+
 def packed_gdn_f16k(gdn):
     """Fragment-order parameters of a GDN module for conv_f16k's fused epilogue, cached per parameter version."""
     key = (gdn.beta._version, gdn.gamma._version, gdn.beta.data_ptr(), gdn.gamma.data_ptr())
@@ -69,12 +112,8 @@ class _PackedWeightMixin:
 
     def packed_weight(self, desc):
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi, desc.prec)
-        cache = self.__dict__.get("_packed_cache")
-        if cache is None or cache[0] != key:
-            cache = (key, ops.pack_conv_weight(w.detach().contiguous(), desc))
-            self.__dict__["_packed_cache"] = cache
-        return cache[1]
+        return _cached(self, "_packed_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi, desc.prec),
+                       lambda: ops.pack_conv_weight(w.detach().contiguous(), desc))
 
     def packed_gemm_weight(self):
         """[ci/16][co][16] bf16 pack of a 1x1 layer for the register-streamed GEMM (masic_amd/csrc/gemm_bf16.hip)."""
@@ -100,12 +139,8 @@ class _PackedWeightMixin:
 
     def packed_f16k_weight(self, desc):
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device), desc.B, desc.Hi, desc.Wi)
-        cache = self.__dict__.get("_packed_f16k_cache")
-        if cache is None or cache[0] != key:
-            cache = (key, ops.pack_conv_f16k_weight(w.detach().contiguous(), desc))
-            self.__dict__["_packed_f16k_cache"] = cache
-        return cache[1]
+        return _cached(self, "_packed_f16k_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi),
+                       lambda: ops.pack_conv_f16k_weight(w.detach().contiguous(), desc))
 
     def packed_first_layer_weight(self):
         """Fragment image of a Conv2d(3, 128, 5, stride 2) weight for the fused conv + GDN kernel of the first analysis layer."""
@@ -124,13 +159,13 @@ class _PackedWeightMixin:
             raise RuntimeError("masic_amd: run_f16k_d2s is for ConvTranspose2d(k=5, s=2, p=2)")
         desc = ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, 3, 3, 1, 1, prec=PREC_BF16)
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device), B, Hi, Wi, None if self.bias is None else self.bias._version)
-        cache = self.__dict__.get("_packed_d2s_cache")
-        if cache is None or cache[0] != key:
+
+        def build():
             wc, bc = ops.deconv_s2_as_conv_weight(w.detach(), None if self.bias is None else self.bias.detach())
-            cache = (key, ops.pack_conv_f16k_weight(wc, desc), bc)
-            self.__dict__["_packed_d2s_cache"] = cache
-        return ops.conv2d_f16k_d2s(x16, cache[1], cache[2], desc, self.out_channels, out=out, out_coff=out_coff)
+            return ops.pack_conv_f16k_weight(wc, desc), bc
+        wp, bc = _cached(self, "_packed_d2s_cache", (w._version, w.data_ptr(), str(w.device), None if self.bias is None else self.bias._version),
+                         (B, Hi, Wi), build)
+        return ops.conv2d_f16k_d2s(x16, wp, bc, desc, self.out_channels, out=out, out_coff=out_coff)
 
     def d2s_supported(self, B, Hi, Wi):
         return (self.transposed_conv and self._geometry() == (5, 5, 2, 2) and self.out_channels <= 8 and self.in_channels % 32 == 0

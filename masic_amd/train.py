@@ -4,7 +4,7 @@ aux loss -> backward -> aux Adam step.  Optimizers are torch's (plumbing); every
 is a HIP launch.  With a GradientAllReducer the main-loss gradients are averaged across ranks before the step."""
 import torch
 
-from .loss import rate_distortion
+from .loss import distortion, rate_distortion
 
 
 def make_optimizers(model, lr=1e-4, aux_lr=1e-3):
@@ -27,3 +27,36 @@ def train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer
     aux_loss.backward()
     aux_optimizer.step()
     return out_criterion, aux_loss
+
+
+def cqe_train_step(model, model2, optimizer, d1, d2, h_matrix, lmbda, reducer=None, reference_graph=False):
+    """One step of the CQE stage (coremasic/mywork/newtrain_cqe_real.py:128-174): HSIC `model` in eval mode, Independent_EN
+    `model2` in train mode, distortion-only criterion on model2's outputs, Adam on model2's parameters (`optimizer`, :472).
+
+    By default HSIC runs under no_grad: its parameters are not in the stepped optimizer and round() blocks every gradient to
+    the analysis side, so the parameter update is identical to the reference's without recording and
+    back-propagating through the codec.  `reference_graph=True` records what the reference records -- the two synthesis
+    transforms of HSIC as differentiable nodes (model.eval_autograd) -- for timing parity; gradients then also reach
+    model.decoder1/2 (never stepped)."""
+    if model.training or not model2.training:
+        raise RuntimeError("cqe_train_step: HSIC must be in eval mode and Independent_EN in train mode (newtrain_cqe_real.py:130-131)")
+    optimizer.zero_grad()
+    if reducer is not None:
+        reducer.arm()
+    if reference_graph:
+        prev = getattr(model, "eval_autograd", False)
+        model.eval_autograd = True
+        try:
+            out_net = model(d1, d2, h_matrix)
+        finally:
+            model.eval_autograd = prev
+    else:
+        with torch.no_grad():
+            out_net = model(d1, d2, h_matrix)
+    out_net2 = model2(out_net["x1_hat"], out_net["x2_hat"], h_matrix)
+    out_criterion = distortion(out_net2, d1, d2, lmbda)
+    out_criterion["loss"].backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step()
+    return out_criterion, out_net2

@@ -353,7 +353,7 @@ def test_training_step_gradients_vs_reference_golden():
         if e > worst:
             worst, worst_name = e, name
     print(f"training step: {n} parameter gradients, worst relative error {worst:.2e} ({worst_name})")
-    assert n == 164 and worst <= 1e-3, (n, worst, worst_name)     # the 2 quantiles get no gradient from the main loss
+    assert n == 164 and worst <= 1e-4, (n, worst, worst_name)     # the 2 quantiles get no gradient from the main loss
     assert net.entropy_bottleneck1.quantiles.grad is None
     # masked taps of the context model do receive gradient, as in the reference
     gm = net.context_prediction1.weight.grad

@@ -1,0 +1,217 @@
+"""GPU parity tests (-m gpu) of the CQE stage (BASELINE config 3): Independent_EN's backward and the
+training step of coremasic/mywork/newtrain_cqe_real.py:128-174, against gradient goldens produced by the reference
+(tests/golden/make_cqe_goldens.py -> cqe_train.npz) and against the CPU oracle; plus the stream-capture guard on hardware
+and the reference's GMM module signature under autograd."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hsic_oracle as O
+from tests.util import assert_close, golden_state_dict, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GTOL = 1e-4
+
+
+def _en(seed):
+    import MASIC
+    from masic_amd import synth
+    net = MASIC.Independent_EN()
+    sd = synth.synth_state_dict(net.state_dict(), seed=seed)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+def _check_grad(fx, key, got, worst):
+    """Against a golden stored in full or as 512 sampled entries + L2 norm (make_cqe_goldens.put_grad)."""
+    assert got is not None, key
+    got = got.detach().cpu()
+    if key in fx:
+        ref = torch.from_numpy(fx[key])
+        e = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    else:
+        idx = torch.from_numpy(fx[key + "@idx"])
+        ref = torch.from_numpy(fx[key + "@val"])
+        amax = float(fx[key + "@absmax"])
+        e = float((got.reshape(-1)[idx] - ref).abs().max()) / (amax + 1e-30)
+        e = max(e, abs(float(got.double().norm()) / (float(fx[key + "@norm"]) + 1e-300) - 1.0))
+    if e > worst[0]:
+        worst[0], worst[1] = e, key
+    return e
+
+
+def test_independent_en_backward_vs_reference_golden():
+    """All 86 parameter gradients and both input gradients of Independent_EN (train mode, distortion criterion) against the
+    reference's autograd, 2x3x32x48."""
+    from masic_amd.loss import distortion
+    fx = load_npz("cqe_train.npz")
+    net, _ = _en(int(fx["seed_en"]))
+    net.train()
+    d1, d2, hm = (torch.from_numpy(fx["standalone/" + k]).to(DEV) for k in ("d1", "d2", "h_matrix"))
+    xa = torch.from_numpy(fx["standalone/x1_in"]).to(DEV).requires_grad_(True)
+    xb = torch.from_numpy(fx["standalone/x2_in"]).to(DEV).requires_grad_(True)
+    out = net(xa, xb, hm)
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], torch.from_numpy(fx["standalone/" + k]), "cqe-train:" + k)
+    crit = distortion(out, d1, d2, float(fx["lmbda"]))
+    assert abs(float(crit["loss"]) - float(fx["standalone/loss"])) <= 1e-4 * abs(float(fx["standalone/loss"]))
+    crit["loss"].backward()
+    worst, n = [0.0, ""], 0
+    for name, p in net.named_parameters():
+        _check_grad(fx, "standalone/grad/" + name, p.grad, worst)
+        n += 1
+    print(f"Independent_EN backward: {n} parameter gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
+    assert n == 86 and worst[0] <= GTOL, (n, worst)
+    assert_close(xa.grad, torch.from_numpy(fx["standalone/gin/x1"]), "d loss / d x1_hat", GTOL)
+    assert_close(xb.grad, torch.from_numpy(fx["standalone/gin/x2"]), "d loss / d x2_hat", GTOL)
+
+
+@pytest.mark.parametrize("reference_graph", [False, True])
+def test_cqe_training_step_chain_vs_reference_golden(reference_graph):
+    """newtrain_cqe_real.py:128-174 on HSIC(16,24,3) of hsic_tiny.npz (eval) -> Independent_EN (train) -> distortion loss ->
+    backward -> Adam: Independent_EN's 86 gradients against the reference's; HSIC under no_grad (default) gives the same
+    parameter gradients as the reference's full graph, and with reference_graph=True the gradients that reach HSIC's synthesis
+    transforms match the reference's as well while everything else of HSIC stays without gradient."""
+    import MASIC
+    from masic_amd.train import cqe_train_step
+    fx = load_npz("cqe_train.npz")
+    tiny = load_npz("hsic_tiny.npz")
+    N, M, K = (int(v) for v in tiny["NMK"])
+    hsic = MASIC.HSIC(N, M, K)
+    hsic.load_state_dict(golden_state_dict(tiny, hsic.state_dict()))
+    hsic = hsic.to(DEV).eval()
+    net2, _ = _en(int(fx["seed_en"]))
+    net2.train()
+    x1, x2, hm = (torch.from_numpy(tiny[k]).to(DEV) for k in ("x1", "x2", "h_matrix"))
+    before = {n: p.detach().clone() for n, p in net2.named_parameters()}
+    opt = torch.optim.Adam(net2.parameters(), lr=1e-4)
+    grads = {}
+    hooks = [p.register_post_accumulate_grad_hook(lambda p, n=n: grads.__setitem__(n, p.grad.detach().clone()))
+             for n, p in net2.named_parameters()]
+    hsic.zero_grad()
+    crit, out2 = cqe_train_step(hsic, net2, opt, x1, x2, hm, float(fx["lmbda"]), reference_graph=reference_graph)
+    for h in hooks:
+        h.remove()
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out2[k], torch.from_numpy(fx["chain/" + k]), "chain:" + k)
+    assert abs(float(crit["loss"]) - float(fx["chain/loss"])) <= 1e-4 * abs(float(fx["chain/loss"]))
+    worst = [0.0, ""]
+    for name in before:
+        _check_grad(fx, "chain/grad/" + name, grads.get(name), worst)
+    print(f"CQE step (reference_graph={reference_graph}): 86 gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
+    assert len(grads) == 86 and worst[0] <= GTOL, worst
+    # Adam moved every parameter by ~lr (first step: lr * g / (|g| + eps))
+    moved = [float((p.detach() - before[n]).abs().max()) for n, p in net2.named_parameters()]
+    assert min(moved) > 0 and max(moved) <= 1.01e-4, (min(moved), max(moved))
+    hs_worst, nd = [0.0, ""], 0
+    for name, p in hsic.named_parameters():
+        if reference_graph and name.startswith(("decoder1.", "decoder2.")):
+            _check_grad(fx, "chain/hsic_grad/" + name, p.grad, hs_worst)
+            nd += 1
+        else:
+            assert p.grad is None, name
+    if reference_graph:
+        print(f"  gradients reaching HSIC's synthesis transforms: {nd}, worst relative error {hs_worst[0]:.2e} ({hs_worst[1]})")
+        assert nd == 32 and hs_worst[0] <= GTOL, hs_worst
+
+
+def test_cqe_forward_refuses_nothing_and_every_parameter_gets_gradient_bf16_mode():
+    """bf16-operand mode (what bench.py times): the step runs, all 86 parameters get a finite gradient close to the float32
+    one (cosine >= 0.999 over the concatenated gradient), and three steps reduce the loss."""
+    from masic_amd import nn as mnn, synth
+    from masic_amd.loss import distortion
+    net, _ = _en(8)
+    net.train()
+    d1, d2, hm = (t.to(DEV) for t in synth.synth_inputs(2, 64, 96, seed=8))
+    xa = (d1 + 0.03 * torch.randn_like(d1)).contiguous()
+    xb = (d2 + 0.03 * torch.randn_like(d2)).contiguous()
+
+    def grads():
+        net.zero_grad()
+        distortion(net(xa, xb, hm), d1, d2, 0.01)["loss"].backward()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()
+    g32 = grads()
+    mnn.set_precision("bf16")
+    try:
+        g16 = grads()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+        cos = float((g32 @ g16) / (g32.norm() * g16.norm()))
+        print(f"CQE gradient, bf16 operands vs float32: cosine {cos:.6f}, relative L2 {float((g32 - g16).norm() / g32.norm()):.3e}")
+        assert cos >= 0.999
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        losses = []
+        for _ in range(4):
+            opt.zero_grad()
+            c = distortion(net(xa, xb, hm), d1, d2, 0.01)
+            c["loss"].backward()
+            opt.step()
+            losses.append(float(c["loss"]))
+        assert losses[-1] < losses[0], losses
+    finally:
+        mnn.set_precision("f32")
+
+
+def test_gmm_module_reference_signature_under_autograd():
+    """GaussianMixtureConditional_gf.forward(y, scales, means, weights) with ALREADY-SOFTMAXED weights in training mode -- the
+    reference's own call (MASIC.py:767 with weights from :389-393) -- against torch autograd over the oracle."""
+    from compressai.entropy_models import GaussianMixtureConditional_gf
+    from masic_amd import ops
+    B, M, K, H, W = 2, 8, 3, 6, 10
+    g = torch.Generator().manual_seed(3)
+    y = (4 * torch.randn(B, M, H, W, generator=g)).requires_grad_(True)
+    sigma = torch.rand(B, K * M, H, W, generator=g).mul(1.5).requires_grad_(True)       # part of it below the 0.11 bound
+    mu = torch.randn(B, K * M, H, W, generator=g).requires_grad_(True)
+    logits = torch.randn(B, K * M, H, W, generator=g).requires_grad_(True)
+    noise = torch.rand(B, M, H, W, generator=g) - 0.5
+    go = torch.randn(B, M, H, W, generator=g)
+    # oracle: softmax over K on the (B,K,M,H,W) view, then the likelihood on y + noise
+    w_ref = O._softmax_over_k(logits, K)
+    lik_ref = O.gmm_likelihood(y + noise, sigma, mu, w_ref, K)
+    (lik_ref * go).sum().backward()
+    ref = [t.grad.clone() for t in (y, sigma, mu, logits)]
+    mod = GaussianMixtureConditional_gf(K=K).to(DEV).train()
+    td = [t.detach().to(DEV).requires_grad_(True) for t in (y, sigma, mu, logits)]
+    mod._get_noise_cached = lambda x: noise.to(DEV)
+    w_dev = ops.softmax_k(td[3].detach(), K).requires_grad_(True)                       # weights as the reference passes them
+    y_hat, lik = mod(td[0], td[1], td[2], w_dev)
+    assert_close(lik, lik_ref, "gmm(weights):lik")
+    (lik * go.to(DEV)).sum().backward()
+    for u, v, n in zip(td[:3], ref[:3], ("dy", "dsigma", "dmu")):
+        assert_close(u.grad, v, "gmm(weights):" + n, 2e-4)
+    # d/d weights, pushed through the softmax Jacobian by hand, equals the oracle's d/d logits
+    w = w_dev.detach().view(B, K, M, H, W)
+    gw = w_dev.grad.view(B, K, M, H, W)
+    glog = (w * (gw - (gw * w).sum(1, keepdim=True))).reshape(B, K * M, H, W)
+    assert_close(glog, ref[3], "gmm(weights):dlogits", 2e-4)
+
+
+def test_capture_guard_raises_before_end_capture_on_hardware():
+    """During a real HIP-graph capture a fork from a side stream raises RuntimeError (rule 1) instead of reaching
+    hipStreamEndCapture; after joining, the capture ends cleanly and the graph replays."""
+    from masic_amd.streams import ForkJoin
+    side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+    buf = torch.zeros(1024, device=DEV)
+    g = torch.cuda.CUDAGraph()
+    raised = []
+    with torch.cuda.graph(g):
+        fj = ForkJoin()
+        fj.fork(side)
+        with fj.on(side):
+            buf.add_(1.0)
+            inner = ForkJoin()
+            try:
+                inner.fork(side2)
+            except RuntimeError as e:
+                raised.append(str(e))
+            ev = fj.record(side)
+            try:
+                fj.wait(side, ev)
+            except RuntimeError as e:
+                raised.append(str(e))
+        fj.join(side)
+    assert len(raised) == 2 and "capture rule 1" in raised[0] and "capture rule 3" in raised[1], raised
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(buf[0]) == 2.0

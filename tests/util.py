@@ -38,13 +38,13 @@ def assert_close(a, b, name="", rtol=RTOL):
     return e
 
 
-def tie_zone(y, eps=1e-3):
+def tie_zone(y, eps=1e-4):
     """latents within eps of a rounding boundary (SURVEY.md 7.3 policy (b))."""
     y = y.detach().double().cpu()
     return ((y - torch.floor(y)) - 0.5).abs() < eps
 
 
-def assert_symbols(sym_hip, sym_ref, y_ref, name="", eps=1e-3):
+def assert_symbols(sym_hip, sym_ref, y_ref, name="", eps=1e-4):
     """Bit-exact except inside the declared tie zone |frac(y) - 1/2| < eps; returns #mismatches."""
     sym_hip = sym_hip.cpu().to(torch.int64)
     sym_ref = sym_ref.cpu().to(torch.int64)
