@@ -3,13 +3,18 @@ an averaging all-reduce of the gradients over RCCL/xGMI (backend "nccl" on ROCm)
 
 The reference has no distributed code; this is the exchange step north_star adds.  Design for
 MI355X: xGMI is point-to-point (7 links per GPU), so a few large flat buckets (default 32 MiB, ~5 for the 140 MB of
-HSIC gradients) keep every link busy with long messages instead of many latency-bound small ones.  Buckets are
-filled in reverse parameter order (the order backward produces gradients) and each bucket's all-reduce is launched
-from a post-accumulate-grad hook as soon as its last gradient lands, so communication hides under the rest of
-backward.  `HSIC.parameters()` hides the entropy-bottleneck parameters (MASIC.py:77-83), so the reducer registers
-`named_parameters()` -- all 166 tensors; parameters that receive no gradient from the main loss (the two `quantiles`)
-are skipped consistently on every rank, and the aux-loss backward (a function of the parameters only, identical on
-every rank) needs no communication at all.
+HSIC gradients) keep every link busy with long messages instead of many latency-bound small ones.
+
+Buckets are PERSISTENT flat buffers and every parameter's `.grad` is a view into its bucket: backward accumulates straight
+into the buffer the collective reduces in place -- no gather copy before the all-reduce and no scatter copy after it
+(round 1 `torch.cat`-ed each bucket: 2 x 140 MB of extra device copies per step).  Buckets are filled in reverse
+parameter order (the order backward produces gradients) and each bucket's all-reduce is launched from a
+post-accumulate-grad hook as soon as its last gradient lands, so communication hides under the rest of backward.
+`HSIC.parameters()` hides the entropy-bottleneck parameters (MASIC.py:77-83), so the reducer registers
+`named_parameters()` -- all 166 tensors.  Parameters that receive no gradient from the main loss (the two `quantiles`:
+`_quantize(..., 'noise')` ignores the medians) are learnt on the first step: they stop gating their bucket's launch and
+their `.grad` is reset to None after the step, exactly what a single process sees; the aux-loss backward (a function of
+the parameters only, identical on every rank) needs no communication at all.
 """
 import torch
 import torch.distributed as dist
@@ -27,9 +32,13 @@ class GradientAllReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        self.overlap = overlap
         self.params = [p for _, p in reversed(list(module.named_parameters())) if p.requires_grad]
         self.buckets, cur, size = [], [], 0
         for p in self.params:
+            if cur and (cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self.buckets.append(cur)
+                cur, size = [], 0
             cur.append(p)
             size += p.numel() * p.element_size()
             if size >= bucket_bytes:
@@ -37,56 +46,85 @@ class GradientAllReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
+        # persistent flat gradient storage; element offsets are kept 64-byte aligned so every view starts on a cache line
+        self.flat, self._views = [], {}
+        for b in self.buckets:
+            offs, n = [], 0
+            align = max(1, 64 // b[0].element_size())
+            for p in b:
+                offs.append(n)
+                n += (p.numel() + align - 1) // align * align
+            flat = torch.zeros(n, dtype=b[0].dtype, device=b[0].device)
+            self.flat.append(flat)
+            for p, o in zip(b, offs):
+                self._views[id(p)] = flat[o:o + p.numel()].view_as(p)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._expected = None            # ids of the parameters that receive a gradient (learnt on the first step)
+        self._got = set()
         self._pending = [len(b) for b in self.buckets]
         self._inflight = {}
-        self._hooks = []
         self._armed = False
-        if overlap and self.world > 1:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
-    # ---- overlap path: called by autograd when a parameter's gradient is complete
+    def bucket_plan(self):
+        """[(number of tensors, bytes)] per bucket, in launch order."""
+        return [(len(b), f.numel() * f.element_size()) for b, f in zip(self.buckets, self.flat)]
+
     def arm(self):
-        """Call before the main-loss backward of each step."""
-        self._pending = [len(b) for b in self.buckets]
+        """Call after optimizer.zero_grad() and before the main-loss backward of each step: zeroes the buckets and (re)binds
+        every parameter's .grad to its view, so that autograd accumulates into the buffers the collective reduces."""
+        for flat in self.flat:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self._views[id(p)]
+        if self._expected is None:
+            self._pending = [len(b) for b in self.buckets]
+        else:
+            self._pending = [sum(1 for p in b if id(p) in self._expected) for b in self.buckets]
+        self._got = set()
         self._inflight = {}
         self._armed = True
 
+    # ---- called by autograd when a parameter's gradient is complete
     def _on_grad(self, p):
         if not self._armed:
             return
+        if p.grad is None or p.grad.data_ptr() != self._views[id(p)].data_ptr():
+            # autograd replaced the tensor (cannot happen while .grad is bound before backward; kept as a hard check)
+            raise RuntimeError("GradientAllReducer: a parameter's .grad is no longer the bucket view; call arm() after zero_grad()")
+        self._got.add(id(p))
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
-        if self._pending[i] == 0:
+        if self._pending[i] == 0 and self.overlap:
             self._launch(i)
 
     def _launch(self, i):
-        ps = [p for p in self.buckets[i] if p.grad is not None]
-        if not ps or i in self._inflight:
+        if i in self._inflight:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
-        self._inflight[i] = (ps, flat, work)
+        work = None
+        if self.world > 1:
+            work = dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight[i] = work
 
     def finish(self):
-        """Call after backward: launches the buckets no hook completed (parameters without gradient), waits, and
-        writes the averaged gradients back."""
+        """Call after backward: launches the buckets no hook completed, waits, averages in place, and resets to None the
+        .grad of parameters the loss did not reach (as a single process would see them)."""
         self._armed = False
         for i in range(len(self.buckets)):
-            if i not in self._inflight:
-                self._launch(i)
-        for i, (ps, flat, work) in self._inflight.items():
+            self._launch(i)
+        for i, work in self._inflight.items():
             if work is not None:
                 work.wait()
             if self.average and self.world > 1:
-                flat.div_(self.world)
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+                self.flat[i].div_(self.world)
         self._inflight = {}
+        if self._expected is None:
+            self._expected = set(self._got)
+        elif self._got != self._expected:
+            self._expected = None          # the graph changed (e.g. another loss): relearn next step, this step was still correct
+        for p in self.params:
+            if id(p) not in self._got:
+                p.grad = None
 
     def remove(self):
         for h in self._hooks:

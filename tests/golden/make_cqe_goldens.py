@@ -100,6 +100,18 @@ def main():
         g, og = p.grad, sd_g[name].grad
         worst = max(worst, float((g - og).abs().max()) / (float(g.abs().max()) + 1e-30))
     report["standalone_oracle_vs_reference_grad_maxrel"] = worst
+    # float32 noise floor of each gradient: the same restatement evaluated in float64 (two correct float32 evaluations can
+    # differ by this much; a LeakyReLU argument near 0 or a cancelling sum amplifies rounding) -- tests gate on
+    # max(1e-4, 2 x floor)
+    sd64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    o64 = O.independent_en_forward(sd64, xa.detach().double(), xb.detach().double(), H.double())
+    cqe_loss(o64, d1.double(), d2.double()).backward()
+    floors = {}
+    for name, p in en.named_parameters():
+        floors[name] = float((p.grad.double() - sd64[name].grad).abs().max() / sd64[name].grad.abs().max())
+        fx["standalone/f32_floor/" + name] = np.array(floors[name])
+    report["standalone_f32_vs_f64_grad_maxrel"] = max(floors.values())
+    report["standalone_f32_vs_f64_grad_worst"] = max(floors, key=floors.get)
     report["standalone_oracle_vs_reference_gin_maxabs"] = float(max((xa.grad - xa2.grad).abs().max(), (xb.grad - xb2.grad).abs().max()))
 
     # ---------------------------------------------------------------- chain: the reference's full graph
@@ -132,6 +144,25 @@ def main():
         elif p.grad is not None:
             zero_side = max(zero_side, float(p.grad.abs().max()))
     report["chain_decoder_params_with_grad"] = dec
+    # float32 floors for this case: decoder1 -> warp -> decoder2 -> Independent_EN -> loss restated in float64 on the
+    # reference's own quantised latents (the part of the graph that carries gradient)
+    with torch.no_grad():
+        y2 = net.encoder2(O.warp_perspective(x1, Hm, x1.shape[-2:]), x2)
+    h64 = {k: (v.double().clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in hsd.items()}
+    e64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    x1h = O.decoder1(out1["y1_hat"].detach().double(), h64)
+    x2h = O.decoder2(torch.round(y2).double(), O.warp_perspective(x1h, Hm.double(), x1.shape[-2:]), h64)
+    cqe_loss(O.independent_en_forward(e64, x1h, x2h, Hm.double()), x1.double(), x2.double()).backward()
+    fl = {}
+    for name, p in en.named_parameters():
+        fl[name] = float((p.grad.double() - e64[name].grad).abs().max() / e64[name].grad.abs().max())
+        fx["chain/f32_floor/" + name] = np.array(fl[name])
+    for name, p in net.named_parameters():
+        if name.startswith(("decoder1.", "decoder2.")):
+            fl[name] = float((p.grad.double() - h64[name].grad).abs().max() / h64[name].grad.abs().max())
+            fx["chain/hsic_f32_floor/" + name] = np.array(fl[name])
+    report["chain_f32_vs_f64_grad_maxrel"] = max(fl.values())
+    report["chain_f32_vs_f64_grad_worst"] = max(fl, key=fl.get)
     report["chain_max_abs_grad_outside_the_decoders"] = zero_side      # round() has zero gradient: analysis / entropy side gets 0
     np.savez_compressed(os.path.join(HERE, "cqe_train.npz"), **fx)
     import json

@@ -51,10 +51,15 @@ def _worker(rank, world, port, overlap, q):
     lo, hi = shard_range(8, rank, world)
     red = GradientAllReducer(net, bucket_bytes=4096, overlap=overlap)       # several small buckets
     assert len(red.buckets) >= 2
-    red.arm()
-    loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
-    loss.backward()
-    red.finish()
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    for step in range(2):          # the second step runs on the learnt no-gradient set and on re-bound views after zero_grad()
+        opt.zero_grad()
+        red.arm()
+        loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+        loss.backward()
+        # every gradient lives in its bucket's flat buffer: no gather / scatter copies around the collective
+        assert all(p.grad.data_ptr() == red._views[id(p)].data_ptr() for p in red.params)
+        red.finish()
     grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
     # single-process reference: the mean over equal shards of per-shard mean losses == full-batch mean loss
     ref = _Net()
@@ -84,11 +89,25 @@ def test_gradient_allreduce_world2_gloo_matches_full_batch(overlap):
 
 def test_reducer_single_process_is_identity():
     net = _Net()
+    x = torch.randn(4, 6)
+    net(x).sum().backward()
+    plain = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    net.zero_grad()
     red = GradientAllReducer(net, bucket_bytes=1024)
+    for _ in range(2):
+        net.zero_grad()
+        red.arm()
+        net(x).sum().backward()
+        red.finish()
+        for n, p in net.named_parameters():
+            if plain[n] is None:
+                assert p.grad is None, n          # a parameter the loss does not reach keeps .grad None, as without the reducer
+            else:
+                assert torch.equal(p.grad, plain[n]), n
+    # a second backward into the same (zeroed, re-bound) views accumulates like plain autograd does
+    net.zero_grad()
     red.arm()
-    net(torch.randn(4, 6)).sum().backward()
-    before = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net(x).sum().backward()
+    net(x).sum().backward()
     red.finish()
-    for n, p in net.named_parameters():
-        if p.grad is not None:
-            assert torch.equal(p.grad, before[n])
+    assert torch.allclose(net.a.weight.grad, 2 * plain["a.weight"])

@@ -23,8 +23,11 @@ def _en(seed):
     return net.to(DEV), sd
 
 
-def _check_grad(fx, key, got, worst):
-    """Against a golden stored in full or as 512 sampled entries + L2 norm (make_cqe_goldens.put_grad)."""
+def _check_grad(fx, key, got, worst, floor_key=None):
+    """Against a golden stored in full or as 512 sampled entries + L2 norm (make_cqe_goldens.put_grad).  The error is
+    reported in units of the tensor's tolerance max(GTOL, 2 x float32 floor): the fixture stores, per tensor, how far the
+    reference's own float32 arithmetic is from a float64 evaluation of the same graph (1.7e-4 on one tensor of this case: a
+    LeakyReLU argument at the rounding level)."""
     assert got is not None, key
     got = got.detach().cpu()
     if key in fx:
@@ -36,6 +39,8 @@ def _check_grad(fx, key, got, worst):
         amax = float(fx[key + "@absmax"])
         e = float((got.reshape(-1)[idx] - ref).abs().max()) / (amax + 1e-30)
         e = max(e, abs(float(got.double().norm()) / (float(fx[key + "@norm"]) + 1e-300) - 1.0))
+    tol = GTOL if floor_key is None or floor_key not in fx else max(GTOL, 2.0 * float(fx[floor_key]))
+    e = e / tol
     if e > worst[0]:
         worst[0], worst[1] = e, key
     return e
@@ -59,10 +64,11 @@ def test_independent_en_backward_vs_reference_golden():
     crit["loss"].backward()
     worst, n = [0.0, ""], 0
     for name, p in net.named_parameters():
-        _check_grad(fx, "standalone/grad/" + name, p.grad, worst)
+        _check_grad(fx, "standalone/grad/" + name, p.grad, worst, "standalone/f32_floor/" + name)
         n += 1
-    print(f"Independent_EN backward: {n} parameter gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
-    assert n == 86 and worst[0] <= GTOL, (n, worst)
+    print(f"Independent_EN backward: {n} parameter gradients, worst error / tolerance {worst[0]:.2f} ({worst[1]}); tolerance = "
+          f"max({GTOL:.0e}, 2 x float32 floor of the reference's arithmetic)")
+    assert n == 86 and worst[0] <= 1.0, (n, worst)
     assert_close(xa.grad, torch.from_numpy(fx["standalone/gin/x1"]), "d loss / d x1_hat", GTOL)
     assert_close(xb.grad, torch.from_numpy(fx["standalone/gin/x2"]), "d loss / d x2_hat", GTOL)
 
@@ -98,22 +104,22 @@ def test_cqe_training_step_chain_vs_reference_golden(reference_graph):
     assert abs(float(crit["loss"]) - float(fx["chain/loss"])) <= 1e-4 * abs(float(fx["chain/loss"]))
     worst = [0.0, ""]
     for name in before:
-        _check_grad(fx, "chain/grad/" + name, grads.get(name), worst)
-    print(f"CQE step (reference_graph={reference_graph}): 86 gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
-    assert len(grads) == 86 and worst[0] <= GTOL, worst
+        _check_grad(fx, "chain/grad/" + name, grads.get(name), worst, "chain/f32_floor/" + name)
+    print(f"CQE step (reference_graph={reference_graph}): 86 gradients, worst error / tolerance {worst[0]:.2f} ({worst[1]})")
+    assert len(grads) == 86 and worst[0] <= 1.0, worst
     # Adam moved every parameter by ~lr (first step: lr * g / (|g| + eps))
     moved = [float((p.detach() - before[n]).abs().max()) for n, p in net2.named_parameters()]
     assert min(moved) > 0 and max(moved) <= 1.01e-4, (min(moved), max(moved))
     hs_worst, nd = [0.0, ""], 0
     for name, p in hsic.named_parameters():
         if reference_graph and name.startswith(("decoder1.", "decoder2.")):
-            _check_grad(fx, "chain/hsic_grad/" + name, p.grad, hs_worst)
+            _check_grad(fx, "chain/hsic_grad/" + name, p.grad, hs_worst, "chain/hsic_f32_floor/" + name)
             nd += 1
         else:
             assert p.grad is None, name
     if reference_graph:
-        print(f"  gradients reaching HSIC's synthesis transforms: {nd}, worst relative error {hs_worst[0]:.2e} ({hs_worst[1]})")
-        assert nd == 32 and hs_worst[0] <= GTOL, hs_worst
+        print(f"  gradients reaching HSIC's synthesis transforms: {nd}, worst error / tolerance {hs_worst[0]:.2f} ({hs_worst[1]})")
+        assert nd == 32 and hs_worst[0] <= 1.0, hs_worst
 
 
 def test_cqe_forward_refuses_nothing_and_every_parameter_gets_gradient_bf16_mode():
