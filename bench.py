@@ -8,14 +8,23 @@ A step = one HSIC(N=128,M=192,K=5) eval forward over a batch of synthetic stereo
 in HBM (BASELINE.json configs[1]: 8 x 512x512 per GPU; weak scaling: every rank runs its own batch, no
 data-path collective).  Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- the dominant kernel symbol (by device time): algorithmic FLOPs per launch / average launch
-                  duration, both measured with HIP events on the launch stream inside the timed region
-  cpu_baseline -- oracle/ (CPU restatement of the reference, kind "port") timed on this box's host cores on a
-                  bounded sample (N=1 only).
+                  duration, both measured with HIP events on the launch stream; `traffic` = HBM bytes per launch
+                  from two rocprofv3 --pmc child passes of this same script run before the parent touches the GPU
+                  (N=1 only; FETCH_SIZE doubled, WRITE_SIZE at face value, MI355X_MICROARCH.md HBM section)
+  cpu_baseline -- oracle/ (CPU restatement of the reference, kind "port") timed on this box's host cores on
+                  bounded samples (N=1 only): eval forward and training step at the C1 / C2 picture sizes
+  extras       -- training step, float32 parity path, accuracy of both operand modes against the oracle
+                  (bpp / PSNR / symbol mismatch: BASELINE.json's "bpp/PSNR vs ref"), upload-inclusive rates,
+                  Independent_EN (CQE) forward + training step, the real bitstream of one pair.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,35 +37,189 @@ import torch  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
+HSIC_GFLOP_PER_PAIR_512 = 161.12   # SURVEY.md 8(d), forward, 512x512; proportional to H*W
+CQE_GFLOP_PER_PAIR_512 = 817.5
+KERNEL_SOURCES = ("conv_f16k.hip", "conv.hip", "conv_geom.h", "common.h", "gemm_bf16.hip")
 
 
-def cpu_baseline(N, M, K, H, W, seed):
-    """Oracle (CPU float32 restatement pinned to the reference) on the host cores: 1 pair, 1 warm-up + 3 runs."""
-    import MASIC
-    from masic_amd import synth
-    from oracle import hsic_oracle as O
-    # the GPU box gives one GPU's job a 16-core share of its host CPUs; oversubscribing torch's pool
-    # beyond that share (os.cpu_count() reports the whole machine) makes the CPU path slower, not faster
+def kernel_source_stamp():
+    """sha256 over the kernel sources a PMC figure depends on: a stored figure is only reported for the sources it was taken on."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "masic_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def host_cores():
+    # the GPU box gives one GPU's job a 16-core share of its host CPUs; oversubscribing torch's pool beyond that share
+    # (os.cpu_count() reports the whole machine) makes the CPU path slower, not faster
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
+    return max(1, min(avail, 16))
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs (oracle = checker)
+def cpu_baseline(N, M, K, seed, budget_s=45.0):
+    """Oracle (CPU float32 restatement pinned to the reference, kind "port") on the host cores.  BASELINE.md section 4 legs:
+    eval forward and training step (forward + RD loss + backward + Adam + aux loss + aux Adam: newtrain_codec_real.py:135-146)
+    at the C1 (256x256) and C2 (512x512) picture sizes, B = 1 and B = 8 for the eval forward; each leg = median of up to 3 runs
+    after one warm-up, bounded by a wall-clock budget (legs that no longer fit are skipped and say so).  Also returns the
+    oracle's outputs on the 1x512x512 sample for extras.accuracy_vs_ref."""
+    import MASIC
+    from masic_amd import synth
+    from oracle import hsic_oracle as O
+    cores = host_cores()
     torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=seed)
+    t_start = time.perf_counter()
+    legs = {}
+
+    def timed(fn, runs=3):
+        fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s:
+                break
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    def eval_leg(B, H, W):
+        x1, x2, hm = synth.synth_inputs(B, H, W, seed=seed)
+
+        def run():
+            with torch.no_grad():
+                return O.hsic_forward(sd, x1, x2, hm, K=K)
+        t, n = timed(run)
+        return {"value": B / t, "unit": "stereo pairs/s", "seconds_per_step": t, "runs": n, "shape": f"{B}x3x{H}x{W}"}
+
+    names = [n for n, _ in MASIC.HSIC(N, M, K).named_parameters()]
+
+    def train_leg(B, H, W):
+        x1, x2, hm = synth.synth_inputs(B, H, W, seed=seed)
+        noise = synth.synth_noise(B, N, M, H, W, seed=seed)
+        psd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+        opt = torch.optim.Adam([psd[n] for n in names if not n.startswith("entropy_bottleneck")], lr=1e-4)
+        aopt = torch.optim.Adam([psd[n] for n in names if n.startswith("entropy_bottleneck")], lr=1e-3)
+
+        def run():
+            opt.zero_grad(); aopt.zero_grad()
+            out = O.hsic_forward(psd, x1, x2, hm, K=K, training=True, noise=noise)
+            O.rd_loss(out, x1, x2, 0.01)["loss"].backward()
+            opt.step()
+            (O.eb_aux_loss(psd, "entropy_bottleneck1") + O.eb_aux_loss(psd, "entropy_bottleneck2")).backward()
+            aopt.step()
+        t, n = timed(run, runs=2)
+        return {"value": B / t, "unit": "stereo pairs/s", "seconds_per_step": t, "runs": n, "shape": f"{B}x3x{H}x{W}"}
+
+    plan = [("eval_c2_b1", eval_leg, (1, 512, 512)), ("eval_c1_b1", eval_leg, (1, 256, 256)), ("eval_c2_b8", eval_leg, (8, 512, 512)),
+            ("train_c1_b1", train_leg, (1, 256, 256)), ("train_c2_b1", train_leg, (1, 512, 512))]
+    for name, fn, a in plan:
+        if time.perf_counter() - t_start > budget_s:
+            legs[name] = {"skipped": f"CPU budget of {budget_s:.0f} s spent"}
+            continue
+        legs[name] = fn(*a)
+    head = legs.get("eval_c2_b8") if "value" in legs.get("eval_c2_b8", {}) else legs["eval_c2_b1"]
+    return {"value": head["value"], "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/hsic_oracle.py (torch CPU float32, {torch.get_num_threads()} threads) eval forward on {head['shape']} synthetic pairs, "
+                      f"median of {head['runs']} runs after 1 warm-up; all legs (eval / training step at the C1 and C2 picture sizes) under `legs`",
+            "legs": legs, "seconds_total": time.perf_counter() - t_start}
+
+
+def oracle_reference_sample(N, M, K, H, W, seed):
+    """The oracle's outputs, RD scalars and symbol streams on one HxW pair (the checker for extras.accuracy_vs_ref)."""
+    import MASIC
+    from masic_amd import synth
+    from oracle import hsic_oracle as O
+    torch.set_num_threads(host_cores())
     sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=seed)
     x1, x2, hm = synth.synth_inputs(1, H, W, seed=seed)
     with torch.no_grad():
-        O.hsic_forward(sd, x1, x2, hm, K=K)
-        ts = []
+        ref = O.hsic_forward(sd, x1, x2, hm, K=K, keep=True)
+    crit = O.rd_loss(ref, x1, x2, 0.01)
+    return {"inputs": (x1, x2, hm), "sym": O.symbols(ref["_aux"], sd), "x1_hat": ref["x1_hat"], "x2_hat": ref["x2_hat"],
+            "bpp": float(crit["bpp_loss"]), "psnr1": crit["psnr1"], "psnr2": crit["psnr2"]}
+
+
+# ------------------------------------------------------------------------------------------------ HBM traffic (PMC child passes)
+def pmc_child(args):
+    """`bench.py --pmc-child`: the bf16 eval forward issued eagerly a few times, nothing else (run under rocprofv3 --pmc)."""
+    import MASIC
+    from masic_amd import nn as mnn, synth
+    mnn.set_precision(args.precision)
+    dev = torch.device("cuda", 0)
+    net = MASIC.HSIC(128, 192, 5)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100))
+    net = net.to(dev).eval()
+    x1, x2, hm = (t.to(dev) for t in synth.synth_inputs(args.batch, args.height, args.width, seed=100))
+    with torch.no_grad():
         for _ in range(3):
-            t0 = time.perf_counter()
-            O.hsic_forward(sd, x1, x2, hm, K=K)
-            ts.append(time.perf_counter() - t0)
-    ts.sort()
-    return {"value": 1.0 / ts[1], "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/hsic_oracle.py eval forward, 1x3x{H}x{W} pair, median of 3 runs after 1 warm-up, torch CPU float32"}
+            net(x1, x2, hm)
+    torch.cuda.synchronize()
 
 
+def measure_pmc_traffic(args, timeout_s=240):
+    """{kernel symbol: {"FETCH_SIZE": KiB/launch, "WRITE_SIZE": KiB/launch, "launches": n}} from two `rocprofv3 --pmc` passes
+    of `bench.py --pmc-child` (separate passes: the two counters do not fit one; no tracing domains besides the kernel trace),
+    or (None, reason).  Must run BEFORE this process initialises the GPU."""
+    import csv
+    import glob
+    import re
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="masic_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    agg = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--pmc-child", "--precision", args.precision, "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+                    a = agg.setdefault(name, {}).setdefault(row["Counter_Name"], [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+    except Exception as e:            # never let the measurement of an extra take the bench down
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {n: {"launches": max(v[0] for v in c.values()), **{cn: v[1] / v[0] for cn, v in c.items()}} for n, c in agg.items()}, None
+
+
+def traffic_for(symbol, pmc, pmc_reason):
+    """(bytes per launch or None, how it was obtained)."""
+    if pmc is not None and symbol in pmc and "FETCH_SIZE" in pmc[symbol] and "WRITE_SIZE" in pmc[symbol]:
+        e = pmc[symbol]
+        return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py --pmc-child` "
+                                                                   f"(eager forward, {e['launches']} launches); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    stored = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(stored))
+        e = d.get(symbol)
+        if isinstance(e, dict) and e.get("source_stamp") == kernel_source_stamp():
+            return float(e["bytes"]), f"profiles/pmc_traffic.json (taken on kernel sources {e['source_stamp']}, commit {e.get('commit')}); live pass unavailable: {pmc_reason}"
+        if isinstance(e, dict):
+            return None, f"stored figure is for kernel sources {e.get('source_stamp')}, current sources are {kernel_source_stamp()}: nulled; live pass unavailable: {pmc_reason}"
+    except Exception:
+        pass
+    return None, f"not measured: {pmc_reason}"
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,10 +234,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the timed forward eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-codec", action="store_true", help="skip the compress / decompress timing of one pair (extras.bitstream)")
     ap.add_argument("--no-f32-compare", action="store_true", help="skip the float32 parity-path timing/accuracy extras (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--no-cqe", action="store_true", help="skip the Independent_EN (CQE) forward / training-step extras")
+    ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive timings (extras.with_upload)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
                          "2x Adam) after the headline region; reported under extras.train_step, 0 to skip")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -82,6 +251,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+
+    # HBM traffic of the kernels: child processes under rocprofv3, before anything here touches the GPU
+    pmc, pmc_reason = None, "skipped (--no-pmc or N > 1)"
+    if world == 1 and not args.no_pmc:
+        t0 = time.perf_counter()
+        pmc, pmc_reason = measure_pmc_traffic(args)
+        pmc_seconds = time.perf_counter() - t0
+
     # MASIC_BENCH_REHEARSAL=1: several ranks on fewer GPUs over gloo -- exercises the N>1 control flow on a one-GPU box (RCCL
     # refuses two ranks on one device); never a measurement
     rehearsal = os.environ.get("MASIC_BENCH_REHEARSAL", "0") == "1"
@@ -98,6 +275,7 @@ def main():
     import MASIC
     from masic_amd import nn as mnn
     from masic_amd import ops, synth
+    from masic_amd.loss import distortion, rate_distortion
     mnn.set_precision(args.precision)
 
     N, M, K = 128, 192, 5
@@ -105,12 +283,20 @@ def main():
     net = MASIC.HSIC(N, M, K)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100))
     net = net.to(dev).eval()
-    x1, x2, hm = (t.to(dev) for t in synth.synth_inputs(B, H, W, seed=100 + rank))
+    x1h, x2h, hmh = synth.synth_inputs(B, H, W, seed=100 + rank)
+    x1, x2, hm = x1h.to(dev), x2h.to(dev), hmh.to(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(t):
+        if world > 1:
+            v = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            return float(v.item())
+        return t
 
     from masic_amd.graph import GraphedHSIC
     with torch.no_grad():
@@ -126,7 +312,64 @@ def main():
         for _ in range(args.steps):
             out = step(xa, xb, hm)
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+
+        # ---- upload-inclusive rates (never `value`): the boundary takes device pointers; a caller that owns host batches pays PCIe
+        upload = None
+        if not args.no_upload and not args.no_graph:
+            x1p, x2p = x1h.pin_memory(), x2h.pin_memory()
+            nb = 2 * x1p.numel() * 4
+            cur = torch.cuda.current_stream()
+            # (a) synchronous: upload on the compute stream, then the step
+            for _ in range(2):
+                xa.copy_(x1p, non_blocking=True); xb.copy_(x2p, non_blocking=True); step(xa, xb, hm)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                xa.copy_(x1p, non_blocking=True)
+                xb.copy_(x2p, non_blocking=True)
+                step(xa, xb, hm)
+            barrier()
+            t_sync = max_over_ranks(time.perf_counter() - t0)
+            # (b) overlapped: batch n+1 goes up on a copy stream into the other of two staging buffers while batch n runs;
+            #     the compute stream waits for its batch's upload event and copies it into the graph's inputs (device to device)
+            cs = torch.cuda.Stream()
+            stage = [(torch.empty_like(x1), torch.empty_like(x2)) for _ in range(2)]
+            up = [torch.cuda.Event(), torch.cuda.Event()]
+            free = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in free:
+                e.record(cur)
+
+            def upload_into(p):
+                cs.wait_event(free[p])
+                with torch.cuda.stream(cs):
+                    stage[p][0].copy_(x1p, non_blocking=True)
+                    stage[p][1].copy_(x2p, non_blocking=True)
+                    up[p].record(cs)
+
+            def run_overlapped(n):
+                upload_into(0)
+                for i in range(n):
+                    p = i & 1
+                    if i + 1 < n:
+                        upload_into(1 - p)
+                    cur.wait_event(up[p])
+                    step(stage[p][0], stage[p][1], hm)
+                    free[p].record(cur)
+            run_overlapped(3)
+            barrier()
+            t0 = time.perf_counter()
+            run_overlapped(args.steps)
+            barrier()
+            t_ovl = max_over_ranks(time.perf_counter() - t0)
+            upload = {"bytes_per_step": nb, "synchronous": {"value": world * B * args.steps / t_sync, "ms_per_step": t_sync / args.steps * 1e3},
+                      "overlapped": {"value": world * B * args.steps / t_ovl, "ms_per_step": t_ovl / args.steps * 1e3},
+                      "unit": "stereo pairs/s",
+                      "what": "the same graph replay with each step's batch uploaded from pinned host memory: on the compute stream (synchronous) / "
+                              "on a copy stream into double-buffered staging, one batch ahead (overlapped)"}
+            xa.copy_(x1); xb.copy_(x2)
+            out = step(xa, xb, hm)
+
         # Roofline pass (not part of `value`): the same forward issued eagerly -- kernels inside a graph replay cannot be
         # bracketed individually -- first with HIP events around every conv launch to find the dominant kernel symbol and
         # the per-kernel split, then `steps` more with events around that symbol only.
@@ -152,22 +395,23 @@ def main():
         torch.cuda.synchronize()
         ops.set_kernel_timer(None)
         net.serial_schedule = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # dominant conv kernel symbol by device time (HIP events on the launch stream, inside the timed region)
+    # dominant conv kernel symbol by device time (HIP events on the launch stream)
     agg = timer.summary()
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS
+    traffic, traffic_source = traffic_for(dom, pmc, pmc_reason)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
-                "frac": tflops / peak, "traffic": None,
+                "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": a["bytes"] / a["launches"] / (2.0 if peak == BF16_MFMA_PEAK_TFLOPS else 1.0),
                 "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,
                 "flops_per_launch": a["flops"] / a["launches"],
                 "share_of_step_time": a["ms"] / (elapsed * 1e3),
+                "end_to_end": {"achieved": B * HSIC_GFLOP_PER_PAIR_512 * (H * W) / (512 * 512) / 1e3 / (elapsed / args.steps), "unit": "TFLOP/s",
+                               "frac": B * HSIC_GFLOP_PER_PAIR_512 * (H * W) / (512 * 512) / 1e3 / (elapsed / args.steps) / peak,
+                               "note": "whole step: SURVEY 8(d) forward FLOPs per pair x pairs / ms_per_step"},
                 "timing": "HIP events on the launch stream around every launch of this symbol in an eager pass of the same "
                           "forward right after the timed region (graph replays cannot be bracketed per kernel); the launches "
                           "share the CUs with the side streams' kernels, as in the timed region",
@@ -175,18 +419,34 @@ def main():
                                         "frac": b["flops"] / b["ms"] / 1e9 / peak,
                                         "note": "same symbol, same forward issued on one stream (nothing else on the CUs)"})(solo.summary()[dom]),
                 "all_conv_kernels_ms_per_step_warmup_survey": {k: v["ms"] for k, v in survey_agg.items()}}
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            roofline["traffic"] = json.load(open(pmc)).get(dom)   # keyed by kernel symbol; null when not profiled for it
-        except Exception:
-            pass
+    if pmc is not None:
+        roofline["pmc_seconds"] = pmc_seconds
+        top = sorted(((n, (2.0 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024.0 * e["launches"]) for n, e in pmc.items()), key=lambda t: -t[1])[:6]
+        roofline["pmc_hbm_bytes_by_kernel_3_forwards"] = {n: b for n, b in top}
 
-    # ---- the float32 parity path on the same inputs: its rate, and what bf16 operands cost in codec terms
-    accuracy = None
-    f32_info = None
+    # ---- accuracy of both operand modes against the ORACLE on one pair of the headline size, and the float32 path's rate
+    accuracy_ref, accuracy, f32_info = None, None, None
+    want_ref = world == 1 and not args.no_cpu_baseline
+    if want_ref:
+        ref = oracle_reference_sample(N, M, K, H, W, seed=100)
+        r1, r2, rh = (t.to(dev) for t in ref["inputs"])
+        accuracy_ref = {"sample": f"1x3x{H}x{W} pair (synth seed 100), oracle = oracle/hsic_oracle.py on the host (pinned to the reference)",
+                        "oracle": {"bpp": ref["bpp"], "psnr1": ref["psnr1"], "psnr2": ref["psnr2"]}}
+        with torch.no_grad():
+            for mode in (["bf16", "f32"] if args.precision == "bf16" else ["f32"]):
+                mnn.set_precision(mode)
+                o = net(r1, r2, rh)
+                s = net.symbol_streams(r1, r2, rh)
+                c = rate_distortion(o, r1, r2, 0.01)
+                nsym = sum(v.numel() for v in ref["sym"].values())
+                nbad = sum(int((s[k].cpu() != ref["sym"][k]).sum()) for k in ref["sym"])
+                accuracy_ref[mode] = {"bpp": float(c["bpp_loss"]), "bpp_rel_delta": float(c["bpp_loss"]) / ref["bpp"] - 1.0,
+                                      "psnr1_delta_db": c["psnr1"] - ref["psnr1"], "psnr2_delta_db": c["psnr2"] - ref["psnr2"],
+                                      "symbol_mismatch_rate": nbad / nsym, "symbol_mismatches": nbad, "symbols": nsym,
+                                      "x1_hat_max_rel_err": float((o["x1_hat"].cpu() - ref["x1_hat"]).abs().max() / ref["x1_hat"].abs().max()),
+                                      "x2_hat_max_rel_err": float((o["x2_hat"].cpu() - ref["x2_hat"]).abs().max() / ref["x2_hat"].abs().max())}
+            mnn.set_precision(args.precision)
     if args.precision == "bf16" and not args.no_f32_compare:
-        from masic_amd.loss import rate_distortion
         with torch.no_grad():
             sym_b = net.symbol_streams(x1, x2, hm)
             crit_b = rate_distortion(out, x1, x2, 0.01)
@@ -200,7 +460,7 @@ def main():
             for _ in range(nf):
                 net(x1, x2, hm)
             barrier()
-            tf = time.perf_counter() - t0
+            tf = max_over_ranks(time.perf_counter() - t0)
             mnn.set_precision("bf16")
         nsym = sum(v.numel() for v in sym_f.values())
         nbad = sum(int((sym_b[k] != sym_f[k]).sum()) for k in sym_f)
@@ -208,9 +468,63 @@ def main():
                     "bpp_rel_delta": float(crit_b["bpp_loss"]) / float(crit_f["bpp_loss"]) - 1.0,
                     "psnr1_delta_db": crit_b["psnr1"] - crit_f["psnr1"], "psnr2_delta_db": crit_b["psnr2"] - crit_f["psnr2"],
                     "symbol_mismatch_rate": nbad / nsym, "symbols": nsym,
-                    "note": "bf16-operand forward vs the float32 parity path (itself within 1e-4 of the reference, symbols bit-exact "
-                            "outside the tie zone), same inputs and weights, rank 0"}
+                    "note": "bf16-operand forward vs the float32 parity path on the whole bench batch, rank 0 (the comparison against the ORACLE "
+                            "is extras.accuracy_vs_ref)"}
         f32_info = {"value": world * B * nf / tf, "unit": "stereo pairs/s", "steps": nf, "ms_per_step": tf / nf * 1e3, "dtype": "f32"}
+
+    # ---- Independent_EN (CQE): forward rate + its dominant kernel, and the CQE training step (BASELINE configs[2] stage)
+    cqe_info = None
+    if not args.no_cqe:
+        en = MASIC.Independent_EN()
+        en.load_state_dict(synth.synth_state_dict(en.state_dict(), seed=101))
+        en = en.to(dev).eval()
+        with torch.no_grad():
+            xh1, xh2 = out["x1_hat"].clone(), out["x2_hat"].clone()
+            for _ in range(2):
+                en(xh1, xh2, hm)
+            barrier()
+            t0 = time.perf_counter()
+            ne = max(3, args.steps // 4)
+            for _ in range(ne):
+                en(xh1, xh2, hm)
+            barrier()
+            te = max_over_ranks(time.perf_counter() - t0)
+            sv = ops.KernelTimer()
+            ops.set_kernel_timer(sv)
+            en(xh1, xh2, hm)
+            ops.set_kernel_timer(None)
+            sva = sv.summary()
+        edom = max(sva, key=lambda k: sva[k]["ms"])
+        ea = sva[edom]
+        epeak = BF16_MFMA_PEAK_TFLOPS if ("bf16" in edom or "f16k" in edom) else F32_MFMA_PEAK_TFLOPS
+        gf = B * CQE_GFLOP_PER_PAIR_512 * (H * W) / (512 * 512)
+        cqe_info = {"forward": {"value": world * B * ne / te, "unit": "stereo pairs/s", "ms_per_step": te / ne * 1e3, "steps": ne,
+                                "achieved_tflops": gf / 1e3 / (te / ne), "frac_of_mfma_peak": gf / 1e3 / (te / ne) / epeak,
+                                "dominant_kernel": {"kernel": edom, "launches": ea["launches"], "avg_launch_ms": ea["ms"] / ea["launches"],
+                                                    "achieved": ea["flops"] / ea["ms"] / 1e9, "peak": epeak, "unit": "TFLOP/s",
+                                                    "frac": ea["flops"] / ea["ms"] / 1e9 / epeak, "share_of_forward_time": ea["ms"] / (te / ne * 1e3)},
+                                "what": f"Independent_EN eval forward on the codec's reconstructions, {B}x3x{H}x{W} per GPU, {args.precision} operands, "
+                                        f"{CQE_GFLOP_PER_PAIR_512} GFLOP/pair at 512x512 (SURVEY 8d)"}}
+        if args.train_steps > 0:
+            from masic_amd.parallel import GradientAllReducer
+            from masic_amd.train import cqe_train_step
+            en.train()
+            opt2 = torch.optim.Adam(en.parameters(), lr=1e-4)
+            red2 = GradientAllReducer(en) if world > 1 else None
+            cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.train_steps):
+                crit2, _ = cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
+            barrier()
+            tc = max_over_ranks(time.perf_counter() - t0)
+            cqe_info["train_step"] = {"value": world * B * args.train_steps / tc, "unit": "stereo pairs/s", "steps": args.train_steps,
+                                      "ms_per_step": tc / args.train_steps * 1e3, "loss_after": float(crit2["loss"]),
+                                      "what": "newtrain_cqe_real.py:128-174: HSIC eval forward (no_grad) + Independent_EN forward + distortion loss + "
+                                              "backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + Adam"}
+            if red2 is not None:
+                red2.remove()
+        del en
 
     train_info = None
     if args.train_steps > 0:
@@ -225,21 +539,18 @@ def main():
         for _ in range(args.train_steps):
             crit, _ = train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)
         barrier()
-        tt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([tt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tt = float(t.item())
+        tt = max_over_ranks(time.perf_counter() - t0)
+        gf = B * 3 * HSIC_GFLOP_PER_PAIR_512 * (H * W) / (512 * 512)
         train_info = {"value": world * B * args.train_steps / tt, "unit": "stereo pairs/s", "steps": args.train_steps,
                       "ms_per_step": tt / args.train_steps * 1e3, "loss_after": float(crit["loss"]),
+                      "achieved_tflops": gf / 1e3 / (tt / args.train_steps),
+                      "frac_of_mfma_peak": gf / 1e3 / (tt / args.train_steps) / (BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS),
                       "what": f"forward ({args.precision} operands) + RD loss + backward ({args.precision} operands, f32 accumulate)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
-                              " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146)"}
+                              " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146); algorithmic work = 3 x the forward's (SURVEY 8d)"}
 
     codec_info = None
     if rank == 0 and not args.no_codec:
         # the real bitstream of one pair: HSIC.compress / decompress on rank 0, outside every timed region above
-        import shutil
-        import tempfile
         net.eval()
         net.update(force=True)
         tmp = tempfile.mkdtemp()
@@ -279,12 +590,18 @@ def main():
         if f32_info is not None:
             extras["f32_parity_path"] = f32_info
             extras["accuracy_vs_f32"] = accuracy
+        if accuracy_ref is not None:
+            extras["accuracy_vs_ref"] = accuracy_ref
+        if upload is not None:
+            extras["with_upload"] = upload
+        if cqe_info is not None:
+            extras["independent_en"] = cqe_info
         if codec_info is not None:
             extras["bitstream"] = codec_info
         if extras:
             line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, M, K, H, W, seed=100)
+            line["cpu_baseline"] = cpu_baseline(N, M, K, seed=100)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -104,8 +104,12 @@ def main():
     # differ by this much; a LeakyReLU argument near 0 or a cancelling sum amplifies rounding) -- tests gate on
     # max(1e-4, 2 x floor)
     sd64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
-    o64 = O.independent_en_forward(sd64, xa.detach().double(), xb.detach().double(), H.double())
+    xa64, xb64 = xa.detach().double().requires_grad_(True), xb.detach().double().requires_grad_(True)
+    o64 = O.independent_en_forward(sd64, xa64, xb64, H.double())
     cqe_loss(o64, d1.double(), d2.double()).backward()
+    for key, g32, g64 in (("x1", xa.grad, xa64.grad), ("x2", xb.grad, xb64.grad)):
+        fx["standalone/f32_floor/gin/" + key] = np.array(float((g32.double() - g64).abs().max() / g64.abs().max()))
+        report["standalone_f32_vs_f64_gin_" + key] = float(fx["standalone/f32_floor/gin/" + key])
     floors = {}
     for name, p in en.named_parameters():
         floors[name] = float((p.grad.double() - sd64[name].grad).abs().max() / sd64[name].grad.abs().max())

@@ -69,8 +69,11 @@ def test_independent_en_backward_vs_reference_golden():
     print(f"Independent_EN backward: {n} parameter gradients, worst error / tolerance {worst[0]:.2f} ({worst[1]}); tolerance = "
           f"max({GTOL:.0e}, 2 x float32 floor of the reference's arithmetic)")
     assert n == 86 and worst[0] <= 1.0, (n, worst)
-    assert_close(xa.grad, torch.from_numpy(fx["standalone/gin/x1"]), "d loss / d x1_hat", GTOL)
-    assert_close(xb.grad, torch.from_numpy(fx["standalone/gin/x2"]), "d loss / d x2_hat", GTOL)
+    # input gradients: same tolerance rule (the reference's float32 arithmetic is 7.5e-4 from float64 on one element of d/dx1)
+    for key, t in (("x1", xa), ("x2", xb)):
+        tol = max(GTOL, 2.0 * float(fx["standalone/f32_floor/gin/" + key]))
+        e = assert_close(t.grad, torch.from_numpy(fx["standalone/gin/" + key]), f"d loss / d {key}_hat", tol)
+        print(f"d loss / d {key}_hat: relative error {e:.2e} (tolerance {tol:.1e})")
 
 
 @pytest.mark.parametrize("reference_graph", [False, True])

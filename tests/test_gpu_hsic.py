@@ -393,65 +393,93 @@ def test_full_size_properties_bf16_vs_f32_paths(B, H, W):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE shapes against the oracle
-def _flip_exclusion(sym, osym, H, W):
-    """[B,1,H,W] bool: picture region that a flipped symbol can reach.  A y flip moves the reconstruction within +-2 latent
-    pixels (four k5 s2 transposed layers), is shifted by the homography (<= 2 latent pixels for synth_inputs) and re-enters the
-    right view's entropy model through the analysis transform (+-3): 8 latent pixels cover the chain; a z flip reaches +-2 z
-    pixels of the hyper synthesis (= 8 latent pixels) before that."""
-    import torch.nn.functional as F
-    fy = ((sym["y1"].cpu() != osym["y1"]) | (sym["y2"].cpu() != osym["y2"])).any(1, keepdim=True).float()
-    fz = ((sym["z1"].cpu() != osym["z1"]) | (sym["z2"].cpu() != osym["z2"])).any(1, keepdim=True).float()
-    fz = F.max_pool2d(fz, 5, 1, 2)
-    lat = torch.maximum(fy, F.interpolate(fz, size=fy.shape[-2:], mode="nearest"))
-    lat = F.max_pool2d(lat, 17, 1, 8)
-    return lat > 0, F.interpolate(lat, size=(H, W), mode="nearest") > 0
-
-
-def _check_outputs_outside(out, ref, excl_lat, excl_pix, tag, rtol=1e-4):
-    """_check_outputs restricted to what no flipped symbol can reach (everything when nothing flipped)."""
-    errs = {}
-    zl = torch.nn.functional.max_pool2d(excl_lat.float(), 4, 4) > 0
-    for k, ex in (("x1_hat", excl_pix), ("x2_hat", excl_pix), ("y1_hat", excl_lat), ("z1_hat", zl)):
-        a, b = out[k].detach().cpu().double(), ref[k].double()
-        keep = ~ex.expand_as(b)
-        errs[k] = float(((a - b).abs() * keep).max()) / float(b.abs().max())
-    for k in ("x1_mask_R", "x1_mask_L"):
-        errs[k] = assert_close(out[k], ref[k], f"{tag}:{k}", rtol)
-    for k, ex in (("y1", excl_lat), ("y2", excl_lat), ("z1", zl), ("z2", zl)):
-        a, b = out["likelihoods"][k].detach().cpu().double(), ref["likelihoods"][k].double()
-        keep = ~ex.expand_as(b)
-        errs["lik_" + k] = float(((a - b).abs() * keep).max()) / float(b.abs().max())
-    bad = {k: v for k, v in errs.items() if v > rtol}
-    assert not bad, f"{tag}: relative errors above {rtol:.0e}: {bad}"
-    return errs
+def _rel(a, b, keep=None):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    d = (a - b).abs()
+    if keep is not None:
+        d = d * keep.expand_as(d)
+    return float(d.max()) / float(b.abs().max())
 
 
 def _f32_vs_oracle(B, H, W, seed, tag):
-    """The float32 parity path against the CPU oracle at a BASELINE shape: symbols bit-exact outside the tie zone
-    |frac - 1/2| < 1e-4 (flips inside it counted and printed), float outputs within 1e-4 of the value range everywhere a
-    flipped symbol cannot reach (everywhere, when nothing flipped)."""
+    """The float32 parity path against the CPU oracle at a BASELINE picture size (one pair).  With 4e5 ... 4e6 symbols a few
+    latents always sit within float32 rounding of a .5 boundary and round the other way than the CPU's accumulation order
+    (measured 3 of 409 600 at 512x512), and one flipped symbol moves everything downstream of it.  So parity is
+    checked where it is well defined, in two stages that together cover every kernel of the forward at this size:
+
+      A  encoder side (no quantiser upstream): the four latents at 1e-4, their int32 symbol streams bit-exact outside the tie
+         zone |frac - 1/2| < 1e-4 (flips inside it counted and printed), masks at 1e-4;
+      B  decoder side on the ORACLE's quantised latents (the modules HSIC.decompress runs): both reconstructions, the
+         entropy parameters and all four likelihoods at 1e-4.  The one quantiser inside this stage -- round(encoder1(warp(
+         x1_hat))) feeding the right view's 1x1 heads -- touches a single latent pixel per symbol: pixels where the oracle's
+         value lies in the tie zone are left out of the y2 likelihood comparison (counted, printed);
+      C  the composed forward HSIC.forward: identical to A + B when nothing flipped (asserted then); always within 1e-3 of the
+         oracle's rate and 0.01 dB of its PSNRs."""
     import MASIC
-    from masic_amd import synth
+    from masic_amd import ops as hip, synth
+    from masic_amd.homography import warp_matrices
+    from masic_amd.loss import rate_distortion
     N, M, K = 128, 192, 5
     sd = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=seed)
     net = _model(N, M, K, sd).eval()
     x1, x2, hm = synth.synth_inputs(B, H, W, seed=seed)
+    x1d, x2d, hmd = x1.to(DEV), x2.to(DEV), hm.to(DEV)
     with torch.no_grad():
-        out = net(x1.to(DEV), x2.to(DEV), hm.to(DEV))
-        sym = net.symbol_streams(x1.to(DEV), x2.to(DEV), hm.to(DEV))
         ref = O.hsic_forward(sd, x1, x2, hm, K=K, keep=True)
-    osym = O.symbols(ref["_aux"], sd)
-    flips, zone = 0, 0
-    for k in ("y1", "y2", "z1", "z2"):
-        lat = ref["_aux"][k] if k[0] == "y" else ref["_aux"][k] - sd[f"entropy_bottleneck{k[1]}.quantiles"][:, 0, 1].view(1, -1, 1, 1)
-        flips += assert_symbols(sym[k], osym[k], lat, k)
-        zone += int(tie_zone(lat).sum())
-    total = sum(v.numel() for v in osym.values())
-    excl_lat, excl_pix = _flip_exclusion(sym, osym, H, W)
-    errs = _check_outputs_outside(out, ref, excl_lat, excl_pix, tag)
-    print(f"{tag}: {total} symbols, {zone} inside the tie zone, {flips} flipped there; picture area excluded from the float "
-          f"comparison {100.0 * float(excl_pix.float().mean()):.2f} %; relative errors {({k: f'{v:.1e}' for k, v in errs.items()})}")
-    assert float(excl_pix.float().mean()) < 0.25
+        aux = ref["_aux"]
+        # ---- A
+        lat = dict(zip(("y1", "y2", "z1", "z2"), net.latents(x1d, x2d, hmd)))
+        sym = net.symbol_streams(x1d, x2d, hmd)
+        errs = {k: assert_close(lat[k], aux[k], f"{tag}:A:{k}") for k in lat}
+        osym = O.symbols(aux, sd)
+        flips, zone = 0, 0
+        for k in ("y1", "y2", "z1", "z2"):
+            v = aux[k] if k[0] == "y" else aux[k] - sd[f"entropy_bottleneck{k[1]}.quantiles"][:, 0, 1].view(1, -1, 1, 1)
+            flips += assert_symbols(sym[k], osym[k], v, k)
+            zone += int(tie_zone(v).sum())
+        total = sum(v.numel() for v in osym.values())
+        # ---- B
+        h, w = aux["y1"].shape[-2:]
+        y1_hat, y2_hat = ref["y1_hat"].to(DEV), aux["y2_hat"].to(DEV)
+        z1_hat, z1_lik = net.entropy_bottleneck1(aux["z1"].to(DEV))
+        z2_hat, z2_lik = net.entropy_bottleneck2(aux["z2"].to(DEV))
+        errs["z1_hat"] = assert_close(z1_hat, ref["z1_hat"], f"{tag}:B:z1_hat")
+        errs["z2_hat"] = assert_close(z2_hat, aux["z2_hat"], f"{tag}:B:z2_hat")
+        errs["lik_z1"] = assert_close(z1_lik, ref["likelihoods"]["z1"], f"{tag}:B:lik_z1")
+        errs["lik_z2"] = assert_close(z2_lik, ref["likelihoods"]["z2"], f"{tag}:B:lik_z2")
+        m_fwd, m_back = warp_matrices(hmd, (H, W), (H, W), want_inverse=True)
+        s1, m1, l1 = net._left_params_fn(ref["z1_hat"].to(DEV), h, w)(y1_hat)
+        for k, t in (("sigma1", s1), ("mu1", m1)):
+            errs[k] = assert_close(t, aux[k], f"{tag}:B:{k}")
+        errs["w1"] = assert_close(hip.softmax_k(l1, K), aux["w1"], f"{tag}:B:w1")
+        errs["lik_y1"] = assert_close(net.gaussian1(y1_hat, s1, m1, l1, weights_are_logits=True)[1], ref["likelihoods"]["y1"], f"{tag}:B:lik_y1")
+        x1_hat = net.decoder1.reconstruct(y1_hat)
+        errs["x1_hat"] = assert_close(x1_hat, ref["x1_hat"], f"{tag}:B:x1_hat")
+        params2, x1_hat_warp = net._right_params_fn(aux["z2_hat"].to(DEV), ref["x1_hat"].to(DEV), m_fwd, m_back, H, W, h, w)
+        errs["x1_hat_warp"] = assert_close(x1_hat_warp, aux["x1_hat_warp"], f"{tag}:B:x1_hat_warp")
+        s2, m2, l2 = params2(y2_hat)
+        y2_lik = net.gaussian2(y2_hat, s2, m2, l2, weights_are_logits=True)[1]
+        tied = tie_zone(aux["y1_warp"]).any(1, keepdim=True)            # [B,1,h,w]: latent pixels whose gated y1_warp_hat input may differ by one
+        keep = (~tied).double()
+        for k, t, r in (("sigma2", s2, aux["sigma2"]), ("mu2", m2, aux["mu2"]), ("w2", hip.softmax_k(l2, K), aux["w2"]),
+                        ("lik_y2", y2_lik, ref["likelihoods"]["y2"])):
+            errs[k] = _rel(t, r, keep)
+            assert errs[k] <= 1e-4, f"{tag}:B:{k}: relative error {errs[k]:.3e}"
+        errs["x2_hat"] = assert_close(net.decoder2(y2_hat, aux["x1_hat_warp"].to(DEV)), ref["x2_hat"], f"{tag}:B:x2_hat")
+        # ---- C
+        out = net(x1d, x2d, hmd)
+        for k in ("x1_mask_R", "x1_mask_L"):
+            errs[k] = assert_close(out[k], ref[k], f"{tag}:C:{k}")
+        crit = rate_distortion(out, x1d, x2d, 0.01)
+        oc = O.rd_loss(ref, x1, x2, 0.01)
+        assert abs(float(crit["bpp_loss"]) / float(oc["bpp_loss"]) - 1.0) <= 1e-3
+        for k in ("psnr1", "psnr2"):
+            assert abs(crit[k] - oc[k]) <= 0.01, (k, crit[k], oc[k])
+        if flips == 0 and int(tied.sum()) == 0:
+            _check_outputs(out, ref, tag + ":C")
+    print(f"{tag}: {total} symbols, {zone} inside the tie zone, {flips} flipped there; {int(tied.sum())} of {tied.numel()} latent pixels of "
+          f"the right view's heads left out (y1_warp in the tie zone); bpp {float(crit['bpp_loss']):.5f} vs oracle {float(oc['bpp_loss']):.5f}, "
+          f"psnr1 {crit['psnr1']:.4f} vs {oc['psnr1']:.4f}; relative errors {({k: f'{v:.1e}' for k, v in errs.items()})}")
     return net, sd, out, ref, (x1, x2, hm)
 
 
