@@ -30,6 +30,7 @@ from masic_amd import ops as _hip
 from masic_amd.homography import warp_matrices as _warp_matrices
 from masic_amd import autograd as _ag
 from masic_amd.streams import ForkJoin as _ForkJoin
+from masic_amd import fp8 as _fp8
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
 
@@ -125,7 +126,7 @@ def _keep_until(t, stream):
 def _bf16_inference(*tensors):
     """True when the forward runs with bf16 operands and nothing needs a gradient: the F16K chains apply."""
     from masic_amd import nn as _mnn
-    if _mnn.get_precision() != "bf16":
+    if not _mnn.reduced_precision():
         return False
     return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
 
@@ -165,10 +166,12 @@ def _gdn_f16k(gdn, x):
     return _hip.gdn_f16k(x, gdn.beta.detach(), gdn.gamma.detach(), inverse=gdn.inverse, beta_min=gdn.beta_min)
 
 
-def _analysis_f16k(convs, gdns, x):
+def _analysis_f16k(owner, convs, gdns, x):
     """conv+GDN x3 -> conv of an analysis transform on the float32 NCHW image `x` with bf16 operands: every GDN runs in
     the epilogue of the convolution that feeds it and the 128-channel activations stay in F16K bf16 in between
-    (conv_f16k.hip). None if a shape has no such configuration (the caller then takes the NCHW path)."""
+    (conv_f16k.hip). None if a shape has no such configuration (the caller then takes the NCHW path).
+    fp8 mode (masic_amd/fp8.py; `owner` calibrated): the two 128 -> 128 layers take fp8 operands -- the first layer and the
+    second write F8K, the third writes F16K for the latent-producing last layer, which stays bf16."""
     from masic_amd import nn as _mnn
     B, C, H, W = x.shape
     c1 = convs[0]
@@ -182,9 +185,17 @@ def _analysis_f16k(convs, gdns, x):
         sizes.append((d.Ho, d.Wo))
     if convs[1].out_channels != 128 or convs[2].out_channels != 128:
         return None
-    t16, _, _ = _hip.conv_a_gdn_f16k(x, c1.packed_first_layer_weight(), None if c1.bias is None else c1.bias.detach(),
-                                     (_mnn.packed_gdn_f16k(gdns[0]), gdns[0].inverse))
+    b1 = None if c1.bias is None else c1.bias.detach()
+    sc = _fp8.scales(owner)
+    if sc is not None and convs[1].f8k_supported(B, *sizes[0]) and convs[2].f8k_supported(B, *sizes[1]):
+        t8, _, _ = _hip.conv_a_gdn_f8k(x, c1.packed_first_layer_weight(), b1, (_mnn.packed_gdn_f16k(gdns[0]), gdns[0].inverse), sc["a1"])
+        t8, _, _ = convs[1].run_f8k(t8, sc["a1"], B, *sizes[0], gdn=gdns[1], out="f8k", out_scale=sc["a2"])
+        t16, _, _ = convs[2].run_f8k(t8, sc["a2"], B, *sizes[1], gdn=gdns[2], out="f16k")
+        return convs[3].run_f16k(t16, B, *sizes[2], want_nchw=True)[0]
+    t16, _, _ = _hip.conv_a_gdn_f16k(x, c1.packed_first_layer_weight(), b1, (_mnn.packed_gdn_f16k(gdns[0]), gdns[0].inverse))
+    _fp8.record(owner, "a1", t16)
     t16, _, _ = convs[1].run_f16k(t16, B, *sizes[0], gdn=gdns[1])
+    _fp8.record(owner, "a2", t16)
     t16, _, _ = convs[2].run_f16k(t16, B, *sizes[1], gdn=gdns[2])
     return convs[3].run_f16k(t16, B, *sizes[2], want_nchw=True)[0]
 
@@ -232,29 +243,59 @@ class _GmmHeads(nn.Module):
                                       H, W, act, want_nchw=last)
         return t
 
+    def _branch_f8k(self, seq, x8, sc, tag, B, H, W, acts):
+        """fp8 mode: the first two layers with fp8 operands (F8K in; the first writes F8K, the second F16K), the last -- the one
+        that produces sigma / means / weight logits -- with bf16 operands."""
+        l0, l1, l2 = seq[0], seq[2], seq[4]
+        wp, ws = l0.packed_gemm_f8k_weight(sc["c"])
+        t = _hip.gemm_f8k(x8, wp, ws, l0.bias.detach(), B, l0.in_channels, l0.out_channels, H, W, acts[0], out="f8k", out_scale=sc[tag])
+        wp, ws = l1.packed_gemm_f8k_weight(sc[tag])
+        t = _hip.gemm_f8k(t, wp, ws, l1.bias.detach(), B, l1.in_channels, l1.out_channels, H, W, acts[1], out="f16k")
+        return _hip.gemm_f16k(t, l2.packed_gemm_dma_weight(), l2.bias.detach(), B, l2.in_channels, l2.out_channels, H, W, acts[2], want_nchw=True)
+
+    def _f8k_heads_ok(self):
+        return all(seq[i].in_channels % 32 == 0 and seq[i].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights) for i in (0, 2)) \
+            and all(seq[4].in_channels % 16 == 0 and seq[4].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights))
+
     def heads(self, x, parallel=True):
         """parallel: the means / weights stacks on two side streams forked from the current one.  Callers that are themselves on
         a side stream pass False: a side stream that forks further streams (or a stream waiting for its own event) ends a
         HIP-graph capture on this ROCm with a fault in hipStreamEndCapture (measured; torch 2.10 / ROCm 7)."""
         from masic_amd import nn as _mnn
-        if _mnn.get_precision() == "bf16" and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
+        if _mnn.reduced_precision() and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
             B, _, H, W = x.shape
-            xf = _hip.nchw_to_f16k(x)        # converted once, read by the three stacks
+            sc = _fp8.scales(self)
+            if sc is not None and self._f8k_heads_ok():
+                x8 = _hip.nchw_to_f8k(x, sc["c"])          # quantised once, read by the three stacks
+                branch = lambda seq, tag, acts: self._branch_f8k(seq, x8, sc, tag, B, H, W, acts)
+                xf = x8
+            else:
+                xf = _hip.nchw_to_f16k(x)        # converted once, read by the three stacks
+
+                def branch(seq, tag, acts):
+                    if _fp8.recording():
+                        _fp8.record(self, "c", x)
+                        l0 = seq[0]
+                        _fp8.record(self, tag, _hip.gemm_f16k(xf, l0.packed_gemm_dma_weight(), l0.bias.detach(), B, l0.in_channels, l0.out_channels, H, W, acts[0])
+                                    if l0.in_channels % 16 == 0 and l0.out_channels % 32 == 0 else
+                                    _hip.gemm1x1_bf16(xf, l0.packed_gemm_weight(), l0.bias.detach(), B, l0.in_channels, l0.out_channels, H, W, acts[0]))
+                    return self._branch_f16k(seq, xf, B, H, W, acts)
             # the three stacks are independent and each of their GEMMs fills about one wave of workgroups: run them on
             # three HIP streams so that their tails overlap
             if not parallel:
-                return (self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU)),
-                        self._branch_f16k(self.gmm_means, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)),
-                        self._branch_f16k(self.gmm_weights, xf, B, H, W, (_LEAKY, _LEAKY, _NONE)))
+                return (branch(self.gmm_sigma, "h_sigma", (_RELU, _RELU, _RELU)),
+                        branch(self.gmm_means, "h_means", (_LEAKY, _LEAKY, _NONE)),
+                        branch(self.gmm_weights, "h_weights", (_LEAKY, _LEAKY, _NONE)))
             fj = _ForkJoin()               # raises (instead of faulting in hipStreamEndCapture) if we are on a side stream of a capture
             cur = fj.main
             side = _side_streams(x.device)[2:4]
             outs = [None, None, None]
-            for i, (st, (seq, acts)) in enumerate(zip(side, ((self.gmm_means, (_LEAKY, _LEAKY, _NONE)), (self.gmm_weights, (_LEAKY, _LEAKY, _NONE))))):
+            for i, (st, (seq, tag, acts)) in enumerate(zip(side, ((self.gmm_means, "h_means", (_LEAKY, _LEAKY, _NONE)),
+                                                                  (self.gmm_weights, "h_weights", (_LEAKY, _LEAKY, _NONE))))):
                 fj.fork(st)
                 with fj.on(st):
-                    outs[i + 1] = self._branch_f16k(seq, xf, B, H, W, acts)
-            outs[0] = self._branch_f16k(self.gmm_sigma, xf, B, H, W, (_RELU, _RELU, _RELU))
+                    outs[i + 1] = branch(seq, tag, acts)
+            outs[0] = branch(self.gmm_sigma, "h_sigma", (_RELU, _RELU, _RELU))
             for st in side:
                 fj.join(st)
             for t in outs[1:] + [xf]:
@@ -346,8 +387,17 @@ def _synthesis_f16k(dec, y_hat):
     if not dec.g_s_conv4.d2s_supported(B, *sizes[3]):
         return None
     t16 = _hip.nchw_to_f16k(y_hat)
+    sc = _fp8.scales(dec)
+    if sc is not None and convs[1].f8k_supported(B, *sizes[1]) and convs[2].f8k_supported(B, *sizes[2]):
+        # fp8 mode: g_s_conv1 keeps bf16 operands (its input are the integer symbols) and writes F8K for the two 128 -> 128 layers
+        t8, _, _ = convs[0].run_f16k_f8out(t16, B, *sizes[0], sc["d1"], gdn=gdns[0])
+        t8, _, _ = convs[1].run_f8k(t8, sc["d1"], B, *sizes[1], gdn=gdns[1], out="f8k", out_scale=sc["d2"])
+        t16, _, _ = convs[2].run_f8k(t8, sc["d2"], B, *sizes[2], gdn=gdns[2], out="f16k")
+        return dec.g_s_conv4.run_f16k_d2s(t16, B, *sizes[3])
     for i in range(3):
         t16, _, _ = convs[i].run_f16k(t16, B, *sizes[i], gdn=gdns[i])
+        if i < 2:
+            _fp8.record(dec, "d%d" % (i + 1), t16)
     return dec.g_s_conv4.run_f16k_d2s(t16, B, *sizes[3])
 
 
@@ -373,7 +423,7 @@ class Encoder1(nn.Module):
     def latent(self, x):
         """forward(x)[0]; with bf16 operands and no autograd the intermediate activations stay in F16K."""
         if _bf16_inference(x, self.g_a_conv1.weight):
-            y = _analysis_f16k((self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
+            y = _analysis_f16k(self, (self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
                                (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), x.contiguous())
             if y is not None:
                 return y
@@ -438,7 +488,7 @@ class Encoder2(nn.Module):
 
     def _analysis(self, t):
         if _bf16_inference(t, self.g_a_conv1.weight):
-            y = _analysis_f16k((self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
+            y = _analysis_f16k(self, (self.g_a_conv1, self.g_a_conv2, self.g_a_conv3, self.g_a_conv4),
                                (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), t)
             if y is not None:
                 return y
@@ -882,7 +932,7 @@ class HSIC(CompressionModel):
                 f.write(s_z)
         out2 = os.path.join(output_path, str(output_name) + ".bin")
         with open(out2, "wb") as f:
-            f.write(codec.MAGIC + bytes([1 if _mnn.get_precision() == "bf16" else 0, 0, 0, 0]))
+            f.write(codec.MAGIC + bytes([{"f32": 0, "bf16": 1, "fp8": 2}[_mnn.get_precision()], 0, 0, 0]))
             for s_y in (s_y1, s_y2):
                 f.write(np.array([len(s_y)], dtype=np.uint32).tobytes())
                 f.write(s_y)
@@ -909,9 +959,9 @@ class HSIC(CompressionModel):
             head = f.read(8)
             if head[:4] != codec.MAGIC:
                 raise ValueError("HSIC.decompress: not a stream of this library (magic %r)" % head[:4])
-            if head[4] != (1 if _mnn.get_precision() == "bf16" else 0):
+            if head[4] != {"f32": 0, "bf16": 1, "fp8": 2}[_mnn.get_precision()]:
                 raise ValueError("HSIC.decompress: the stream was written in the %s operand mode; the coding tables depend on it "
-                                 "(masic_amd.nn.set_precision)" % ("bf16" if head[4] else "f32"))
+                                 "(masic_amd.nn.set_precision)" % ("f32", "bf16", "fp8")[head[4] if head[4] < 3 else 0])
             streams = []
             for _ in range(2):
                 n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])

@@ -38,7 +38,8 @@ enum { MASIC_ACT_NONE = 0, MASIC_ACT_RELU = 1, MASIC_ACT_LEAKY = 2,
  * of `_quantize(...,'dequantize')` entropy_models.py:116 feeding context_prediction MASIC.py:755-757) */
 enum { MASIC_INOP_NONE = 0, MASIC_INOP_ABS = 1, MASIC_INOP_ROUND = 2 };
 /* operand precision of the MFMA contraction; accumulation is always float32 */
-enum { MASIC_PREC_F32 = 0, MASIC_PREC_BF16 = 1 };
+enum { MASIC_PREC_F32 = 0, MASIC_PREC_BF16 = 1,
+       MASIC_PREC_FP8 = 2 /* OCP e4m3fn operands on v_mfma_scale_f32_32x32x64_f8f6f4 (conv_f8k / gemm_f8k entry points only) */ };
 
 int masic_version(void);
 const char* masic_last_error(void);
@@ -153,6 +154,34 @@ int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed, const floa
 
 /* First analysis layer g_a_conv1 + g_a_gdn1 (MASIC.py:515-516, :563-564) in one kernel: Conv2d(3 -> 128, k5, s2, p2) on
  * channels in_coff..in_coff+2 of a float32 NCHW tensor, GDN, result in F16K [B][8][Ho*Wo][16]. */
+/* ------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3fn) operand path -- BASELINE.json configs[4] ("fp8 MFMA conv path + int32 symbol quantise").  No reference
+ * counterpart (the reference computes in float32): a declared-budget approximation of the layers above, gated against the
+ * oracle in tests/test_gpu_fp8.py.  Activations: F8K = [B][C/32][H*W][32] fp8, stored as fp8(x / scale) with one scale per
+ * tensor; weights: one scale per output channel, written by the pack calls.  Contraction:
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, float32 accumulate; dequantisation (wscale[co] = weight scale x
+ * input scale) in the epilogue (masic_amd/csrc/conv_f16k.hip, fp8.hip).
+ *   masic_nchw_to_f8k            float32 NCHW channel view -> F8K (in_op as masic_nchw_to_f16k_op), x * inv_scale, saturating
+ *   masic_absmax                 *out = max(*out, max|x|) over n float32 (bf16 = 0) or bf16 (bf16 = 1) values: calibration
+ *   masic_conv_f8k_pack_weight   d->prec = MASIC_PREC_FP8: fp8 slab stream + wscale[Cout] (max|W[co]| / 448)
+ *   masic_conv_f8k_fwd           d->prec = MASIC_PREC_FP8: x is F8K, wscale required; d->prec = MASIC_PREC_BF16: x is F16K, wscale NULL
+ *                                (= masic_conv_f16k_gdn_fwd).  Exactly one of y_nchw / y_f16k / y_f8k (fp8(y * out_inv_scale)).
+ *   masic_gemm_f8k_*             the 1x1 layers (masic_gemm_f16k_*) with fp8 operands
+ *   masic_conv_a_gdn_fwd_ex      masic_conv_a_gdn_fwd with the option of an F8K output */
+size_t masic_f8k_bytes(int B, int C, int HW);
+int masic_nchw_to_f8k(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int in_op, float inv_scale, void* stream);
+int masic_absmax(const void* x, size_t n, int bf16, float* out, void* stream);
+int masic_conv_f8k_pack_weight(const float* w, void* w_packed, float* wscale, const masic_conv_desc_t* d, void* stream);
+int masic_conv_f8k_fwd(const void* x, const void* w_packed, const float* wscale, const float* bias, const float* gate,
+                       const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k, void* y_f8k, float out_inv_scale,
+                       const masic_conv_desc_t* d, void* stream);
+size_t masic_gemm_f8k_packed_bytes(int Cin, int Cout);
+int masic_gemm_f8k_pack_weight(const float* w, void* wp, float* wscale, int Cin, int Cout, int transposed, void* stream);
+int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const float* wscale, const float* bias, void* y_f16k, void* y_f8k,
+                       float* y_nchw, float out_inv_scale, int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
+int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                            void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
+
 size_t masic_conv_a_packed_bytes(void);
 int masic_conv_a_pack_weight(const float* w, void* w_packed, void* stream);
 int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,

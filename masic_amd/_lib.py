@@ -14,7 +14,7 @@ c_int, c_float, c_double, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, cty
 EB_PARAMS_PER_CHANNEL = 58
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SOFTMAX_C = 0, 1, 2, 3
 INOP_NONE, INOP_ABS, INOP_ROUND = 0, 1, 2
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_FP8 = 0, 1, 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -67,6 +67,16 @@ SIGNATURES = {
     "masic_gdn_f16k_packed_bytes": (c_size_t, []),
     "masic_gdn_pack_f16k": (c_int, [_P, _P, _P, c_int, c_double, _P]),
     "masic_conv_f16k_gdn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    # fp8 operand path
+    "masic_f8k_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "masic_nchw_to_f8k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "masic_absmax": (c_int, [_P, c_size_t, c_int, _P, _P]),
+    "masic_conv_f8k_pack_weight": (c_int, [_P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_conv_f8k_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, ctypes.POINTER(ConvDesc), _P]),
+    "masic_gemm_f8k_packed_bytes": (c_size_t, [c_int, c_int]),
+    "masic_gemm_f8k_pack_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "masic_gemm_f8k_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float] + [c_int] * 7 + [_P]),
+    "masic_conv_a_gdn_fwd_ex": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_gemm1x1_packed_bytes": (c_size_t, [c_int, c_int]),
     "masic_gemm1x1_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "masic_gemm1x1_bf16_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),

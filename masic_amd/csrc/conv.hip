@@ -1006,6 +1006,7 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
                                    const float* res1, const float* res2, float* y, const masic_conv_desc_t* d, void* stream) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(d->prec != MASIC_PREC_FP8, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: fp8 operands exist on the F8K entry points only (masic_conv_f8k_fwd)");
     MASIC_REQUIRE(x && w_packed && y, MASIC_ERR_ARG, "conv2d_fwd: null pointer");
     ConvGeom g[4];
     const int np = build_geoms(*d, g);

@@ -62,6 +62,31 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e, v4u& f, v4u& g, v4u& h, v4u& i, v4u& j) {
+    asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j) : "n"(N) : "memory");
+}
+
+// ---- fp8 (OCP e4m3fn) operands: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127) = a plain fp8 MFMA at
+// twice the bf16 rate (MI355X_MICROARCH.md, Matrix cores).  A lane's operand is 32 consecutive k (two ds_read_b128 that the
+// register coalescer places in one 8-register tuple); lanes 0-31 / 32-63 hold the two 32-k halves of the instruction's K = 64.
+typedef int v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v8i cat8(const v4u& lo, const v4u& hi) {
+    return __builtin_bit_cast(v8i, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x16 mfma_f8(const v8i& a, const v8i& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+}
+__device__ __forceinline__ unsigned pack4f8(float a, float b, float c, float d, float inv) {
+    // saturating: e4m3fn has no infinity, its largest finite value is 448
+    a = __builtin_amdgcn_fmed3f(a * inv, -448.0f, 448.0f);
+    b = __builtin_amdgcn_fmed3f(b * inv, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c * inv, -448.0f, 448.0f);
+    d = __builtin_amdgcn_fmed3f(d * inv, -448.0f, 448.0f);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -91,6 +116,21 @@ __device__ __forceinline__ void store_f16k_tile(const f32x16& t, unsigned short*
     }
 }
 
+// F8K store (fp8 activations [B][C/32][H*W][32]: a pixel's 32 channels are one 32-byte record) of accumulator tile `t` = one
+// whole record per pixel: lane (j, h) holds channels 8q + 4h + i; after two v_permlane32_swap it holds the 16 consecutive
+// channels 16h .. 16h+15 and writes them with one 16-byte store.  rec: address of the lane's pixel record + 16h bytes.
+__device__ __forceinline__ unsigned pack4f8(float a, float b, float c, float d, float inv);
+__device__ __forceinline__ void store_f8k_tile(const f32x16& t, unsigned char* rec, float inv) {
+    unsigned q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = pack4f8(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3], inv);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);     // h = 0: channels 0-3, 4-7;   h = 1: 16-19, 20-23
+    const auto s1 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);     // h = 0: 8-11, 12-15;         h = 1: 24-27, 28-31
+    uint4 st;
+    st.x = s0[0]; st.y = s0[1]; st.z = s1[0]; st.w = s1[1];
+    *reinterpret_cast<uint4*>(rec) = st;
+}
+
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v;
@@ -107,6 +147,9 @@ struct F16kArgs {
     float* y32;                   // float32 NCHW view, or null
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
     const uint4* gdn_img;         // GDN epilogue: gamma^ fragments (gdn.hip: gdn_pack_f16k_kernel), then beta^[128] floats
+    const float* wscale;          // fp8 operands: per-output-channel dequantisation factor (weight scale x input scale), else null
+    unsigned char* y8;            // F8K [B][out_c32tot][Ho*Wo][32] fp8 output (quantised with out_inv_scale), or null
+    float out_inv_scale;
     int gdn_inverse;
     int d2s;                      // > 0: channel 4c + phase (2x2 phases, c < d2s); y32 is [B][out_ctot][2Ho][2Wo] (depth-to-space store)
     int in_c16tot, in_c16off, Cin16;
@@ -169,6 +212,52 @@ __global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* 
     }
 }
 
+// fp8 operands: the same stream with 32-channel blocks -- slab (tap, block) = LDS image [k-half hh][co 128][16 ci] of
+// fp8(W[co, (c*KS+ks)*32 + hh*16 + e, tap] / wscale[co]); wscale[co] = max |W[co]| / 448 (per-output-channel scaling).
+__global__ void wscale_f8k_kernel(const float* __restrict__ w, float* __restrict__ ws, int Cin, int Cout, int taps, int transposed) {
+    const int co = blockIdx.x;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < Cin * taps; i += blockDim.x) {
+        const int ci = i / taps, t = i - ci * taps;
+        m = fmaxf(m, fabsf(transposed ? w[((size_t)ci * Cout + co) * taps + t] : w[((size_t)co * Cin + ci) * taps + t]));
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ws[co] = red[0] > 0.0f ? red[0] / 448.0f : 1.0f;
+}
+
+__global__ void pack_f8k_stream_kernel(const PackStreamArgs a, const float* __restrict__ ws, unsigned char* __restrict__ wp) {
+    const int spc = (a.g.ntaps + a.T - 1) / a.T;
+    const size_t total = (size_t)a.ncb * a.nchunks * spc * a.T * a.KS * 4096;        // fp8 elements = bytes
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = (int)(r & 15); r >>= 4;
+        const int co = (int)(r & 127); r >>= 7;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r % a.KS); r /= a.KS;
+        const int tt = (int)(r % a.T); r /= a.T;
+        const int t = (int)(r % spc); r /= spc;
+        const int c = (int)(r % a.nchunks); r /= a.nchunks;
+        const int cb = (int)r;
+        const int tap = t * a.T + tt;
+        const int ci = (c * a.KS + ks) * 32 + hh * 16 + e, cog = cb * 128 + co;
+        float v = 0.0f;
+        if (tap < a.g.ntaps && ci < a.Cin && cog < a.Cout) {
+            const int ta = tap / a.g.ntw, tb = tap - ta * a.g.ntw;
+            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const size_t src = a.transposed ? (((size_t)ci * a.Cout + cog) * a.KH + kh) * a.KW + kw
+                                            : (((size_t)cog * a.Cin + ci) * a.KH + kh) * a.KW + kw;
+            v = a.w[src] / ws[cog];
+        }
+        wp[a.phase_off + i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff);
+    }
+}
+
 __device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_wave_base, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
@@ -227,9 +316,13 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
 // NM: 32-channel accumulator tiles per wave -- 4 (a 128-channel block) or 1 (layers with <= 32 output channels).
 // NP: 32-pixel sub-tiles per wave (tile = 256 NP pixels): larger tiles for the large stride-1-walk layers, whose
 // per-workgroup fixed cost (launch, first DMA, epilogue) would otherwise rival their K loop.
-template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP>
+// F8: fp8 (e4m3) operands -- the input is F8K (32-channel records), a slab is (tap, 32-channel block) and one MFMA (K = 64)
+// consumes two consecutive slabs of the step, one per lane half: with KS = 2 the two channel blocks of a tap, with KS = 1
+// two consecutive taps.  DMA, LDS images, ring and geometry are the bf16 kernel's (a record is 32 bytes in both layouts).
+template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP, bool F8 = false>
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
+    static_assert(!F8 || (NM == 4 && NP == 1 && (T * KS) % 2 == 0 && T <= 4), "fp8 operands: 128-channel blocks, 256-pixel tiles, slab pairs");
     static_assert(NM + NP == 2 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 5 and 6 fragments per k-step");
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
@@ -323,7 +416,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         const int PWe = g.is == 2 ? a.PWh : a.PW;             // row pitch (records) of the LDS patch image
         const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
 #pragma unroll
-        for (int n = 0; n < NP; ++n) bl[n] = (h * a.NPIXp + (((wave * NP + n) * a.SR + jr) * g.is) * PWe + jc) * 16;
+        for (int n = 0; n < NP; ++n) {
+            if constexpr (F8) bl[n] = ((((wave * NP + n) * a.SR + jr) * g.is) * PWe + jc) * 16 + (KS == 2 ? h * gpk * 1024 : 0);   // both k-half planes are read; lane half = channel block (KS = 2) or tap (KS = 1)
+            else bl[n] = (h * a.NPIXp + (((wave * NP + n) * a.SR + jr) * g.is) * PWe + jc) * 16;
+        }
         // tap table: byte offset of each tap's record inside the LDS patch image (padding taps alias tap 0; their weights are zero)
         if (tid < MAXTAPS) {                                   // [step][TP] entries, TP = T rounded up to a power of two
             constexpr int TP = T == 5 ? 8 : T;
@@ -337,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     }
     const int ninstr = KS * gpk;
     const int wvoff = wq * 1024 + lane * 16;                  // weight waves: this lane's record inside a 4 KiB slab
-    const int al = (h * 128 + j) * 16;                        // lane part of the A-fragment address
+    const int al = F8 ? j * 16 + h * 4096 : (h * 128 + j) * 16;   // lane part of the A-fragment address (fp8: lane half = odd / even slab of the pair)
     int pdst[NPI];                                            // patch waves: LDS offset inside a patch buffer (or the sink)
 #pragma unroll
     for (int k = 0; k < NPI; ++k) pdst[k] = (k * 4 + wq) < ninstr ? (k * 4 + wq) * 1024 : -1;
@@ -404,36 +500,67 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv), "+v"(tv4)::"memory");
         const unsigned wst = ldsb + al + cslot;
-        v4u af[2][NM], bfr[2][NP];
+        constexpr int NQ = F8 ? 2 : 1;                            // ds_read_b128 per fragment
+        constexpr int NKS = F8 ? (T * KS) / 2 : T * KS;           // MFMA k-steps per step
+        v4u af[2][NM][NQ], bfr[2][NP][NQ];
         auto request = [&](auto ic, auto bc) {
-            constexpr int i = decltype(ic)::value, buf = decltype(bc)::value, tt = i / KS, ks = i % KS;
-            const unsigned toff = ldsb + cb + (tt < 4 ? tvv[tt < 4 ? tt : 0] : tv4) + ks * gpk * 1024;
-            static_for<0, NP>([&](auto nc) {
-                constexpr int n = decltype(nc)::value;
-                ds_read128<0>(bfr[buf][n], toff + bl[n]);
-            });
-            static_for<0, NM>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                ds_read128<i * 4096 + m * 512>(af[buf][m], wst);
-            });
+            constexpr int i = decltype(ic)::value, buf = decltype(bc)::value;
+            if constexpr (F8) {
+                // slabs 2i (lanes 0-31) and 2i+1 (lanes 32-63) of the step; a fragment = the 16-byte records of both k-half planes
+                unsigned toff = ldsb + cb;
+                if constexpr (KS == 2) toff += tvv[i];                                   // same tap, the two channel blocks (lane part of bl)
+                else toff += h ? tvv[2 * i + 1] : tvv[2 * i];                            // taps 2i / 2i+1
+                const unsigned plane = (unsigned)a.NPIXp * 16;
+                static_for<0, NP>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    ds_read128<0>(bfr[buf][n][0], toff + bl[n]);
+                    ds_read128<0>(bfr[buf][n][1], toff + bl[n] + plane);
+                });
+                static_for<0, NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    ds_read128<i * 8192 + m * 512>(af[buf][m][0], wst);
+                    ds_read128<i * 8192 + m * 512 + 2048>(af[buf][m][1], wst);
+                });
+            } else {
+                constexpr int tt = i / KS, ks = i % KS;
+                const unsigned toff = ldsb + cb + (tt < 4 ? tvv[tt < 4 ? tt : 0] : tv4) + ks * gpk * 1024;
+                static_for<0, NP>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    ds_read128<0>(bfr[buf][n][0], toff + bl[n]);
+                });
+                static_for<0, NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    ds_read128<i * 4096 + m * 512>(af[buf][m][0], wst);
+                });
+            }
         };
         if (F16K_ABLATE != 3) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, T * KS>([&](auto ic) {
+        static_for<0, NKS>([&](auto ic) {
             constexpr int i = decltype(ic)::value, buf = i & 1;
-            if constexpr (i + 1 < T * KS && F16K_ABLATE != 3) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
-            constexpr int pending = i + 1 < T * KS ? NM + NP : 0;         // LDS returns in order: what was requested for i+1 may stay out
-            if constexpr (NM == 4 && NP == 1) lgkm_wait<pending>(bfr[buf][0], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
-            else if constexpr (NM == 4 && NP == 2) lgkm_wait<pending>(bfr[buf][0], bfr[buf][1], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
-            else if constexpr (NM == 1 && NP == 4) lgkm_wait<pending>(bfr[buf][0], bfr[buf][1], bfr[buf][2], bfr[buf][3], af[buf][0]);
-            else lgkm_wait<pending>(bfr[buf][0], af[buf][0]);
+            if constexpr (i + 1 < NKS && F16K_ABLATE != 3) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+            constexpr int pending = i + 1 < NKS ? (NM + NP) * NQ : 0;     // LDS returns in order: what was requested for i+1 may stay out
+            if constexpr (F8) {
+                lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][0][1], af[buf][0][0], af[buf][0][1], af[buf][1][0], af[buf][1][1],
+                                   af[buf][2][0], af[buf][2][1], af[buf][3][0], af[buf][3][1]);
+                const v8i b8 = cat8(bfr[buf][0][0], bfr[buf][0][1]);
+                static_for<0, NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    acc[0][m] = mfma_f8(cat8(af[buf][m][0], af[buf][m][1]), b8, acc[0][m]);
+                });
+            } else {
+            if constexpr (NM == 4 && NP == 1) lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0], af[buf][1][0], af[buf][2][0], af[buf][3][0]);
+            else if constexpr (NM == 4 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0], af[buf][2][0], af[buf][3][0]);
+            else if constexpr (NM == 1 && NP == 4) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], bfr[buf][2][0], bfr[buf][3][0], af[buf][0][0]);
+            else lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0]);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 static_for<0, NP>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     if (F16K_ABLATE != 4 || m == 0)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf][n]), acc[n][m], 0, 0, 0);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m][0]), __builtin_bit_cast(bf16x8, bfr[buf][n][0]), acc[n][m], 0, 0, 0);
                 });
             });
+            }
         });
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
         // weight waves: the slab group of the next step has landed, the D-1 groups after it stay in flight.
@@ -459,6 +586,20 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
     const size_t oplane = (size_t)a.Ho * a.Wo;
     // bias, then (inverse) GDN or the activation.  Cout is a multiple of 32, so a 32-channel block is valid or not as a whole.
+    if constexpr (F8) {                      // dequantise: per-output-channel weight scale x the input tensor's scale
+        const float* sp = a.wscale + m0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float sv = sp[m * 32 + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) acc[n][m][e] *= sv;
+                }
+            }
+        }
+    }
     if (a.bias != nullptr) {
         const float* bp = a.bias + m0 + 4 * h;
 #pragma unroll
@@ -527,6 +668,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * op] = acc[n][m][e];
                     }
+            } else if (a.y8 != nullptr) {
+                // fp8 output for an fp8-operand consumer: tile m = record m of this 128-channel block (out_coff, m0 multiples of 32)
+                const int c32 = (a.out_coff + m0) >> 5;
+                unsigned char* yb = a.y8 + (((size_t)b * (a.out_ctot >> 5) + c32) * oplane + opix) * 32 + 16 * h;
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+                    if (m0 + m * 32 < a.Cout) store_f8k_tile(acc[n][m], yb + (size_t)m * oplane * 32, a.out_inv_scale);
             } else {
                 // tile m = records 2m, 2m+1 of this 128-channel block (out_coff and m0 are multiples of 16)
                 const int c16 = (a.out_coff + m0) >> 4;
@@ -554,6 +702,8 @@ struct ConvAArgs {
     const uint4* gdn_img;         // gdn_pack_f16k_kernel image, then beta^[128]
     unsigned short* y16;          // F16K [B][8][Ho*Wo][16]
     int gdn_inverse, Hi, Wi, in_ctot, in_coff, Ho, Wo, tiles_w, tiles_per_img, ntiles;
+    unsigned char* y8;            // instead of y16: F8K [B][4][Ho*Wo][32] fp8, quantised with out_inv_scale
+    float out_inv_scale;
 };
 
 constexpr int CA_PH = 19, CA_PW = 67, CA_PITCH = 68, CA_NEL = 3 * CA_PH * CA_PW;     // patch of an 8 x 32 tile, stride 2, 5 x 5
@@ -675,10 +825,16 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
             if (oh < a.Ho && ow < a.Wo) {
-                unsigned short* yb = a.y16 + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 8 * h;
-                const unsigned op16 = (unsigned)oplane * 16;
+                if (a.y8 != nullptr) {
+                    unsigned char* yb = a.y8 + (((size_t)b * 4) * oplane + (size_t)oh * a.Wo + ow) * 32 + 16 * h;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
+                    for (int m = 0; m < 4; ++m) store_f8k_tile(acc[m], yb + (size_t)m * oplane * 32, a.out_inv_scale);
+                } else {
+                    unsigned short* yb = a.y16 + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 8 * h;
+                    const unsigned op16 = (unsigned)oplane * 16;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yb + (size_t)(2 * m) * op16, op16);
+                }
             }
         }
         if (next < a.ntiles) stash(buf ^ 1);
@@ -699,7 +855,10 @@ constexpr int F16K_D = 3;
 
 F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     F16kCfg c{};
-    if (d.Cout < 32 || d.Cout % 32 != 0 || d.Cin < 16 || d.Cin % 16 != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    const bool f8 = d.prec == MASIC_PREC_FP8;       // fp8 operands: 32-channel blocks, 128-channel co-blocks only, 256-pixel tiles
+    const int cblk = f8 ? 32 : 16;
+    if (d.Cout < 32 || d.Cout % 32 != 0 || d.Cin < cblk || d.Cin % cblk != 0 || d.in_op != MASIC_INOP_NONE || d.act == MASIC_ACT_SOFTMAX_C) return c;
+    if (f8 && d.Cout < 64) return c;
     int span_h = 0, span_w = 0, min_taps = 1 << 30, max_taps = 0;
     for (int p = 0; p < nphase; ++p) {
         span_h = span_h > g[p].nth ? span_h : g[p].nth;
@@ -717,9 +876,9 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     // takes 5 barriers instead of 7; the 20-KiB slab groups leave room for a 3-slot ring only (look-ahead 2 steps = 40 MFMAs per
     // wave).  MASIC_F16K_T5=0 keeps 4 taps per step (A/B timing).
     static const bool t5 = !(getenv("MASIC_F16K_T5") && getenv("MASIC_F16K_T5")[0] == '0');
-    if (t5 && is == 2 && min_taps == 25 && max_taps == 25) { c.T = 5; c.D = 2; }
+    if (!f8 && t5 && is == 2 && min_taps == 25 && max_taps == 25) { c.T = 5; c.D = 2; }
     // large stride-1-walk layers: 512- (128-channel blocks) or 1024-pixel tiles (<= 32 channels), 16-channel chunks
-    if (is == 1 && Wp >= 32) {
+    if (!f8 && is == 1 && Wp >= 32) {
         const int np = d.Cout <= 32 ? 4 : 2;
         const long tiles = (long)ceil_div(Wp, 32) * ceil_div(Hp, 8 * np) * nphase * d.B * ceil_div(d.Cout, 128);
         if (tiles >= 512 && ceil_div(min_taps, 2) >= 2) { c.NP = np; c.KS = 1; c.T = 2; c.L = 2; NPI = np == 4 ? 10 : 6; }
@@ -729,7 +888,7 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         if (ks2 && c.NP == 2 && d.Cin % 32 == 0) { c.KS = 2; c.D = 2; c.L = 1; NPI = 10; }
     }
     if (ceil_div(max_taps, c.T) * (c.T == 5 ? 8 : c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
-    c.Cin16 = d.Cin / 16;
+    c.Cin16 = d.Cin / cblk;                                   // channel blocks (records) per pixel
     if (c.Cin16 % c.KS != 0) return c;                        // whole chunks only
     c.TW = Wp > 16 ? 32 : (Wp > 8 ? 16 : 8);
     c.TWlog = 0;
@@ -778,7 +937,8 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
-    if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2>", gdn ? "true" : "false");
+    if (d->prec == MASIC_PREC_FP8) snprintf(buf, n, "conv_f16k<%d, %d, %d, %d, %d, %s, 4, 1, true>", c.KS, c.T, F16K_D, c.KS == 1 ? 6 : 4, c.L, gdn ? "true" : "false");
+    else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2>", gdn ? "true" : "false");
     else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
     else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1>", c.T, c.D, gdn ? "true" : "false");
     else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
@@ -814,7 +974,41 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
 namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
-                const masic_conv_desc_t* d, void* stream);
+                const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f);
+}
+
+// fp8 (e4m3) operand form (BASELINE configs[4]): d->prec = MASIC_PREC_FP8 -- the input is F8K, weights come from
+// masic_conv_f8k_pack_weight, wscale[Cout] = that call's per-channel weight scales times the input tensor's scale.  With
+// d->prec = MASIC_PREC_BF16 this is masic_conv_f16k_gdn_fwd plus the option of an fp8 output (y_f8k, quantised with
+// out_inv_scale = 1 / scale of the produced tensor) for an fp8-operand consumer.  Exactly one of y_nchw / y_f16k / y_f8k.
+extern "C" int masic_conv_f8k_fwd(const void* x, const void* w_packed, const float* wscale, const float* bias, const float* gate,
+                                  const void* gdn_packed, int gdn_inverse, float* y_nchw, void* y_f16k, void* y_f8k, float out_inv_scale,
+                                  const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(d != nullptr, MASIC_ERR_ARG, "conv_f8k_fwd: null descriptor");
+    MASIC_REQUIRE((d->prec == MASIC_PREC_FP8) == (wscale != nullptr), MASIC_ERR_ARG, "conv_f8k_fwd: wscale goes with fp8 operands (prec = MASIC_PREC_FP8)");
+    MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "conv_f8k_fwd: an fp8 output needs out_inv_scale > 0");
+    return f16k_launch(x, w_packed, bias, gate, gdn_packed, gdn_inverse, 0, y_nchw, y_f16k, d, stream, wscale, y_f8k, out_inv_scale);
+}
+
+extern "C" size_t masic_f8k_bytes(int B, int C, int HW) { return (size_t)B * round_up(C, 32) * HW; }
+
+extern "C" int masic_conv_f8k_pack_weight(const float* w, void* w_packed, float* wscale, const masic_conv_desc_t* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MASIC_OK) return rc;
+    MASIC_REQUIRE(w && w_packed && wscale && d->prec == MASIC_PREC_FP8, MASIC_ERR_ARG, "conv_f8k_pack_weight: null pointer or prec != MASIC_PREC_FP8");
+    ConvGeom g[4];
+    const int np = build_geoms(*d, g);
+    const F16kCfg c = choose_f16k(*d, g, np);
+    MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f8k: layer shape has no fp8 configuration");
+    hipLaunchKernelGGL(wscale_f8k_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, w, wscale, d->Cin, d->Cout, d->KH * d->KW, d->transposed);
+    for (int p = 0; p < np; ++p) {
+        PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, g[p], c.phase_off[p]};
+        const size_t tot = (size_t)c.stream_bytes[p] * c.ncb;
+        int nb = (int)((tot + 255) / 256);
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(pack_f8k_stream_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (const float*)wscale, (unsigned char*)w_packed);
+    }
+    return masic_launch_status("conv_f8k_pack_weight");
 }
 
 extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
@@ -846,17 +1040,22 @@ extern "C" int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed,
 namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
-                const masic_conv_desc_t* d, void* stream) {
+                const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
-    MASIC_REQUIRE(x_f16k && w_packed && ((y_nchw != nullptr) != (y_f16k != nullptr)), MASIC_ERR_ARG,
+    const bool f8 = d->prec == MASIC_PREC_FP8;
+    const int cblk = f8 ? 32 : 16;
+    MASIC_REQUIRE(x_f16k && w_packed && ((y_nchw != nullptr) + (y_f16k != nullptr) + (y_f8k != nullptr) == 1), MASIC_ERR_ARG,
                   "conv_f16k_fwd: need input, weights and exactly one output");
+    MASIC_REQUIRE(y_f8k == nullptr || (d->out_ctot % 32 == 0 && d->out_coff % 32 == 0 && gate == nullptr && d2s == 0), MASIC_ERR_SHAPE,
+                  "conv_f16k: an fp8 output needs a 32-aligned channel view and no gate");
+    MASIC_REQUIRE(!f8 || (wscale != nullptr && d2s == 0), MASIC_ERR_ARG, "conv_f16k: fp8 operands need the dequantisation scales");
     MASIC_REQUIRE(d->Cout > 32 || d->KH * d->KW > 1, MASIC_ERR_UNSUPPORTED, "conv_f16k: no 1x1 configuration");
     ConvGeom g[4];
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
-    MASIC_REQUIRE(d->in_ctot % 16 == 0 && d->in_coff % 16 == 0, MASIC_ERR_SHAPE, "conv_f16k: input channel view must be 16-aligned");
+    MASIC_REQUIRE(d->in_ctot % cblk == 0 && d->in_coff % cblk == 0, MASIC_ERR_SHAPE, "conv_f16k: input channel view must be 16-aligned (32 for fp8)");
     MASIC_REQUIRE(y_f16k == nullptr || (d->out_ctot % 16 == 0 && d->out_coff % 16 == 0 && d->Cout % 4 == 0 && gate == nullptr),
                   MASIC_ERR_SHAPE, "conv_f16k: F16K output needs a 16-aligned channel view, Cout % 4 == 0 and no gate");
     MASIC_REQUIRE(gdn_packed == nullptr || (d->Cout == 128 && d->act == MASIC_ACT_NONE && gate == nullptr), MASIC_ERR_UNSUPPORTED,
@@ -864,7 +1063,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, gdn_inverse, d2s & 0xff, d->in_ctot / 16, d->in_coff / 16, c.Cin16,
+               (const uint4*)gdn_packed, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : d->out_ctot, d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
@@ -887,6 +1086,25 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     } while (0)
 #define F16K_LAUNCH(KSV, TV, PSPV, LV, GDNV, NMV, NPV) F16K_LAUNCH_D(KSV, TV, F16K_D, PSPV, LV, GDNV, NMV, NPV)
     MASIC_REQUIRE(c.NP == 1 || (d->Cout <= 32) == (c.NP == 4), MASIC_ERR_UNSUPPORTED, "conv_f16k: tile configuration");
+#define F8K_LAUNCH(KSV, TV, PSPV, LV, GDNV)                                                                          \
+    do {                                                                                                             \
+        auto kfn = conv_f16k<KSV, TV, F16K_D, PSPV, LV, GDNV, 4, 1, true>;                                           \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), c.lds_bytes, st, a);                                                \
+    } while (0)
+    if (f8) {
+        if (c.KS == 1) {
+            if (gdn_packed) F8K_LAUNCH(1, 4, 6, 1, true);
+            else F8K_LAUNCH(1, 4, 6, 1, false);
+        } else {
+            if (gdn_packed) F8K_LAUNCH(2, 2, 4, 2, true);
+            else F8K_LAUNCH(2, 2, 4, 2, false);
+        }
+    } else
     if (c.NP == 4) {
         F16K_LAUNCH(1, 2, 5, 2, false, 1, 4);
     } else if (c.NP == 2) {
@@ -908,6 +1126,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     }
 #undef F16K_LAUNCH
 #undef F16K_LAUNCH_D
+#undef F8K_LAUNCH
     return masic_launch_status("conv_f16k_fwd");
 }
 }  // namespace
@@ -919,14 +1138,22 @@ extern "C" int masic_conv_a_pack_weight(const float* w, void* w_packed, void* st
     hipLaunchKernelGGL(pack_conv_a_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, w, (uint4*)w_packed);
     return masic_launch_status("conv_a_pack_weight");
 }
+extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                       void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
 extern "C" int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                                     void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
-    MASIC_REQUIRE(x && w_packed && gdn_packed && y_f16k, MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer");
+    return masic_conv_a_gdn_fwd_ex(x, w_packed, bias, gdn_packed, gdn_inverse, y_f16k, nullptr, 0.0f, B, Hi, Wi, in_ctot, in_coff, stream);
+}
+// the same with the result optionally written as F8K fp8 (y_f8k, quantised with out_inv_scale) for an fp8-operand second layer
+extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                       void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
+    MASIC_REQUIRE(x && w_packed && gdn_packed && ((y_f16k != nullptr) != (y_f8k != nullptr)), MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer / exactly one output");
+    MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "conv_a_gdn_fwd: an fp8 output needs out_inv_scale > 0");
     MASIC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && in_coff >= 0 && in_coff + 3 <= in_ctot, MASIC_ERR_SHAPE, "conv_a_gdn_fwd: bad shape");
     const int Ho = (Hi + 4 - 5) / 2 + 1, Wo = (Wi + 4 - 5) / 2 + 1;
     const int tiles_w = ceil_div(Wo, 32), tiles_per_img = tiles_w * ceil_div(Ho, 8), ntiles = tiles_per_img * B;
     ConvAArgs a{x, (const uint4*)w_packed, bias, (const uint4*)gdn_packed, (unsigned short*)y_f16k, gdn_inverse, Hi, Wi, in_ctot, in_coff,
-                Ho, Wo, tiles_w, tiles_per_img, ntiles};
+                Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale};
     static bool attr_set = false;
     const size_t lds_bytes = 65536 + 20480 + 1024 + 2 * CA_PATCH_BYTES;
     if (!attr_set) {
@@ -953,7 +1180,35 @@ struct GemmF16kArgs {
     unsigned short* y16;          // F16K [B][out_ctot/16][HW][16] or null
     float* y32;                   // float32 NCHW view or null
     int Cin16, nchunks, Cout, HW, out_ctot, out_coff, act;
+    const float* wscale;          // fp8 operands: per-output-channel dequantisation factor, else null
+    unsigned char* y8;            // F8K output [B][out_ctot/32][HW][32] (quantised with out_inv_scale) or null
+    float out_inv_scale;
 };
+
+// fp8 operands: [co block][k32][hh][co 128][16 fp8] with per-output-channel scales ws[co] = max|W[co]| / 448
+__global__ void wscale_gemm_f8k_kernel(const float* __restrict__ w, float* __restrict__ ws, int Cin, int Cout, int transposed) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    float m = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) m = fmaxf(m, fabsf(transposed ? w[(size_t)ci * Cout + co] : w[(size_t)co * Cin + ci]));
+    ws[co] = m > 0.0f ? m / 448.0f : 1.0f;
+}
+__global__ void pack_gemm_f8k_kernel(const float* __restrict__ w, const float* __restrict__ ws, unsigned char* __restrict__ wp, int Cin, int Cout,
+                                     int nk32, int ncb, int transposed) {
+    const size_t total = (size_t)ncb * nk32 * 4096;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = (int)(r & 15); r >>= 4;
+        const int co = (int)(r & 127); r >>= 7;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int k32 = (int)(r % nk32);
+        const int cb = (int)(r / nk32);
+        const int ci = k32 * 32 + hh * 16 + e, cog = cb * 128 + co;
+        float v = 0.0f;
+        if (ci < Cin && cog < Cout) v = (transposed ? w[(size_t)ci * Cout + cog] : w[(size_t)cog * Cin + ci]) / ws[cog];
+        wp[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff);
+    }
+}
 
 __global__ void pack_gemm_f16k_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int nk16,
                                       int ncb, int transposed) {
@@ -977,8 +1232,10 @@ __global__ void pack_gemm_f16k_kernel(const float* __restrict__ w, unsigned shor
 
 // KC: 16-channel blocks per chunk.  KC = 2 keeps a stage at 24 KiB: two workgroups per CU, which is what a grid of
 // 288 workgroups (nine 128-channel blocks x 32 pixel tiles) on 256 CUs needs.
-template <int KC>
+// F8: fp8 operands (F8K input, 32-channel blocks; one MFMA = two consecutive blocks of the chunk, one per lane half)
+template <int KC, bool F8 = false>
 __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16kArgs a) {
+    static_assert(!F8 || KC % 2 == 0, "fp8 operands consume channel blocks in pairs");
     constexpr int ACT0 = KC * 4096, STAGE = KC * 12288, NS = 3;
     constexpr int WPW = KC, APW = 2 * KC;                                    // weight / activation DMA pieces per wave per chunk
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -1019,30 +1276,52 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16k
     if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW) : "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned al = ldsb + (h * 128 + j) * 16, bl = ldsb + ACT0 + (h * 256 + wave * 32 + j) * 16;
+    const unsigned al = ldsb + (F8 ? j * 16 + h * 4096 : (h * 128 + j) * 16);
+    const unsigned bl = ldsb + ACT0 + (F8 ? (wave * 32 + j) * 16 + h * 8192 : (h * 256 + wave * 32 + j) * 16);
     int cs = 0, ps = 2;                                                      // consumer / producer stage
     for (int c = 0; c < a.nchunks; ++c) {
         issue(c + 2, ps);                                                     // past the end: reads as zeros into a free stage
         ps = ps == NS - 1 ? 0 : ps + 1;
         const unsigned wa = al + cs * STAGE, ba = bl + cs * STAGE;
-        v4u af[2][4], bfr[2];
+        constexpr int NQ = F8 ? 2 : 1, NKS = F8 ? KC / 2 : KC;
+        v4u af[2][4][NQ], bfr[2][NQ];
         auto request = [&](auto ic, auto bc) {
             constexpr int i = decltype(ic)::value, buf = decltype(bc)::value;
-            ds_read128<i * 8192>(bfr[buf], ba);
-            static_for<0, 4>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                ds_read128<i * 4096 + m * 512>(af[buf][m], wa);
-            });
+            if constexpr (F8) {
+                ds_read128<i * 16384>(bfr[buf][0], ba);
+                ds_read128<i * 16384 + 4096>(bfr[buf][1], ba);
+                static_for<0, 4>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    ds_read128<i * 8192 + m * 512>(af[buf][m][0], wa);
+                    ds_read128<i * 8192 + m * 512 + 2048>(af[buf][m][1], wa);
+                });
+            } else {
+                ds_read128<i * 8192>(bfr[buf][0], ba);
+                static_for<0, 4>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    ds_read128<i * 4096 + m * 512>(af[buf][m][0], wa);
+                });
+            }
         };
         request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, KC>([&](auto ic) {
+        static_for<0, NKS>([&](auto ic) {
             constexpr int i = decltype(ic)::value, buf = i & 1;
-            if constexpr (i + 1 < KC) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
-            lgkm_wait<(i + 1 < KC ? 5 : 0)>(bfr[buf], af[buf][0], af[buf][1], af[buf][2], af[buf][3]);
-            static_for<0, 4>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m]), __builtin_bit_cast(bf16x8, bfr[buf]), acc[m], 0, 0, 0);
-            });
+            if constexpr (i + 1 < NKS) request(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+            if constexpr (F8) {
+                lgkm_wait<(i + 1 < NKS ? 10 : 0)>(bfr[buf][0], bfr[buf][1], af[buf][0][0], af[buf][0][1], af[buf][1][0], af[buf][1][1],
+                                                   af[buf][2][0], af[buf][2][1], af[buf][3][0], af[buf][3][1]);
+                const v8i b8 = cat8(bfr[buf][0], bfr[buf][1]);
+                static_for<0, 4>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    acc[m] = mfma_f8(cat8(af[buf][m][0], af[buf][m][1]), b8, acc[m]);
+                });
+            } else {
+                lgkm_wait<(i + 1 < NKS ? 5 : 0)>(bfr[buf][0], af[buf][0][0], af[buf][1][0], af[buf][2][0], af[buf][3][0]);
+                static_for<0, 4>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[buf][m][0]), __builtin_bit_cast(bf16x8, bfr[buf][0]), acc[m], 0, 0, 0);
+                });
+            }
         });
         cs = cs == NS - 1 ? 0 : cs + 1;
         if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");   // chunk c+1 has landed, chunk c+2 may stay in flight
@@ -1050,7 +1329,16 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16k
         __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- epilogue: bias + activation -> F16K or float32 NCHW view
+    // ---- epilogue: (dequantisation) + bias + activation -> F16K, F8K or float32 NCHW view
+    if constexpr (F8) {
+        const float* sp = a.wscale + m0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] *= sp[m * 32 + (e & 3) + 8 * (e >> 2)];
+            }
+    }
     if (a.bias != nullptr) {
         const float* bp = a.bias + m0 + 4 * h;
 #pragma unroll
@@ -1077,6 +1365,12 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16k
 #pragma unroll
                 for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)a.HW] = acc[m][e];
             }
+    } else if (a.y8 != nullptr) {
+        const int c32 = (a.out_coff + m0) >> 5;
+        unsigned char* yb = a.y8 + (((size_t)b * (a.out_ctot >> 5) + c32) * a.HW + p) * 32 + 16 * h;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) store_f8k_tile(acc[m], yb + (size_t)m * a.HW * 32, a.out_inv_scale);
     } else {
         const int c16 = (a.out_coff + m0) >> 4;
         unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * a.HW + p) * 16 + 8 * h;
@@ -1118,7 +1412,7 @@ extern "C" int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, con
     const long blocks = (long)grid.x * grid.y * grid.z;
     const bool kc2 = blocks % 256 != 0 || blocks < 256;
     GemmF16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (unsigned short*)y_f16k, y_nchw,
-                   Cin16, nk16 / (kc2 ? 2 : 4), Cout, HW, out_ctot, out_coff, act};
+                   Cin16, nk16 / (kc2 ? 2 : 4), Cout, HW, out_ctot, out_coff, act, nullptr, nullptr, 0.0f};
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_f16k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1128,4 +1422,44 @@ extern "C" int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, con
     if (kc2) hipLaunchKernelGGL(gemm_f16k<2>, grid, dim3(512), 3 * 2 * 12288, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gemm_f16k<4>, grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
     return masic_launch_status("gemm_f16k_fwd");
+}
+
+// fp8 (e4m3) operand form of masic_gemm_f16k_*: x in F8K (Cin % 32 == 0), weights from masic_gemm_f8k_pack_weight (which also
+// writes the per-output-channel weight scales); wscale[Cout] = those scales x the input tensor's scale.  Exactly one output:
+// y_f16k (bf16, next layer runs bf16 operands), y_f8k (fp8, quantised with out_inv_scale) or y_nchw (float32 view).
+extern "C" size_t masic_gemm_f8k_packed_bytes(int Cin, int Cout) {
+    return (size_t)ceil_div(Cout, 128) * round_up(ceil_div(Cin, 32), 4) * 4096;
+}
+
+extern "C" int masic_gemm_f8k_pack_weight(const float* w, void* wp, float* wscale, int Cin, int Cout, int transposed, void* stream) {
+    MASIC_REQUIRE(w && wp && wscale && Cin > 0 && Cout > 0, MASIC_ERR_ARG, "gemm_f8k_pack_weight: bad argument");
+    const int nk32 = round_up(ceil_div(Cin, 32), 4), ncb = ceil_div(Cout, 128);
+    hipLaunchKernelGGL(wscale_gemm_f8k_kernel, dim3(ceil_div(Cout, 128)), dim3(128), 0, (hipStream_t)stream, w, wscale, Cin, Cout, transposed);
+    const size_t total = (size_t)ncb * nk32 * 4096;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_gemm_f8k_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (const float*)wscale, (unsigned char*)wp, Cin, Cout, nk32, ncb, transposed);
+    return masic_launch_status("gemm_f8k_pack_weight");
+}
+
+extern "C" int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const float* wscale, const float* bias, void* y_f16k, void* y_f8k,
+                                  float* y_nchw, float out_inv_scale, int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream) {
+    MASIC_REQUIRE(x_f8k && w_packed && wscale && ((y_f16k != nullptr) + (y_f8k != nullptr) + (y_nchw != nullptr) == 1), MASIC_ERR_ARG,
+                  "gemm_f8k_fwd: need input, weights, scales and exactly one output");
+    MASIC_REQUIRE(B > 0 && HW > 0 && Cin % 32 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED, "gemm_f8k_fwd: needs Cin %% 32 == 0 and Cout %% 32 == 0");
+    MASIC_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot && (y_nchw != nullptr || (out_ctot % 32 == 0 && out_coff % 32 == 0)), MASIC_ERR_SHAPE,
+                  "gemm_f8k_fwd: output channel view");
+    MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "gemm_f8k_fwd: an fp8 output needs out_inv_scale > 0");
+    MASIC_REQUIRE((long)(Cin / 32) * HW * 32 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_f8k_fwd: activation plane too large for 32-bit offsets");
+    const int Cin32 = Cin / 32, nk32 = round_up(Cin32, 4);
+    dim3 grid(ceil_div(HW, 256), ceil_div(Cout, 128), B);
+    GemmF16kArgs a{(const unsigned short*)x_f8k, (const unsigned short*)w_packed, bias, (unsigned short*)y_f16k, y_nchw,
+                   Cin32, nk32 / 4, Cout, HW, out_ctot, out_coff, act, wscale, (unsigned char*)y_f8k, out_inv_scale};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_f16k<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16k<4, true>), grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
+    return masic_launch_status("gemm_f8k_fwd");
 }

@@ -124,7 +124,7 @@ inline int check_desc(const masic_conv_desc_t* d) {
     }
     MASIC_REQUIRE(ho == d->Ho && wo == d->Wo, MASIC_ERR_SHAPE, "conv: output size %dx%d given, %dx%d expected", d->Ho, d->Wo, ho, wo);
     MASIC_REQUIRE(d->act != MASIC_ACT_SOFTMAX_C || d->Cout <= 8, MASIC_ERR_UNSUPPORTED, "conv: channel softmax needs Cout <= 8");
-    MASIC_REQUIRE(d->prec == MASIC_PREC_F32 || d->prec == MASIC_PREC_BF16, MASIC_ERR_UNSUPPORTED, "conv: precision %d not built", d->prec);
+    MASIC_REQUIRE(d->prec == MASIC_PREC_F32 || d->prec == MASIC_PREC_BF16 || d->prec == MASIC_PREC_FP8, MASIC_ERR_UNSUPPORTED, "conv: precision %d not built", d->prec);
     return MASIC_OK;
 }
 

@@ -14,20 +14,29 @@ import torch.nn as nn
 import os
 
 from . import ops
-from ._lib import PREC_BF16, PREC_F32
+from ._lib import PREC_BF16, PREC_F32, PREC_FP8
 
-_PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16}[os.environ.get("MASIC_PRECISION", "f32")]
+_PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16, "fp8": PREC_BF16}[os.environ.get("MASIC_PRECISION", "f32")]
+_FP8 = os.environ.get("MASIC_PRECISION", "f32") == "fp8"
 
 
 def set_precision(name):
-    """Operand precision of the forward MFMA contractions: "f32" (parity path, exact float32 MFMA) or "bf16"
-    (bf16 operands, float32 accumulate; BASELINE's headline dtype). Backward contractions stay float32."""
-    global _PRECISION
-    _PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16}[name]
+    """Operand precision of the forward MFMA contractions: "f32" (parity path, exact float32 MFMA), "bf16" (bf16 operands,
+    float32 accumulate; BASELINE's headline dtype) or "fp8" (BASELINE configs[4]: the bf16 path with OCP e4m3 operands on the
+    128 -> 128 5x5 layers of the analysis / synthesis transforms and the first two layers of the entropy-parameter stacks of
+    modules calibrated with masic_amd.fp8.calibrate; inference only).  Backward contractions are float32 or bf16."""
+    global _PRECISION, _FP8
+    _PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16, "fp8": PREC_BF16}[name]
+    _FP8 = name == "fp8"
 
 
 def get_precision():
-    return "bf16" if _PRECISION == PREC_BF16 else "f32"
+    return "fp8" if _FP8 else ("bf16" if _PRECISION == PREC_BF16 else "f32")
+
+
+def reduced_precision():
+    """bf16 or fp8 operands (the F16K chains apply)."""
+    return _PRECISION == PREC_BF16
 
 
 def _pair(v):
@@ -141,6 +150,51 @@ class _PackedWeightMixin:
         w = self.weight
         return _cached(self, "_packed_f16k_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi),
                        lambda: ops.pack_conv_f16k_weight(w.detach().contiguous(), desc))
+
+    # ---- fp8 operands (masic_amd/csrc/conv_f16k.hip: conv_f16k<..., F8>; activations F8K [B][C/32][H*W][32] fp8)
+    def _desc_f8k(self, B, Hi, Wi, out_ctot=None, out_coff=0, act=ops.ACT_NONE, gate_ctot=0, gate_c=0):
+        kh, kw, s, p = self._geometry()
+        cin32 = (self.in_channels + 31) // 32 * 32
+        return ops.make_conv_desc(B, self.in_channels, Hi, Wi, self.out_channels, kh, kw, s, p,
+                                  transposed=self.transposed_conv, masked=self.masked_conv, in_ctot=cin32,
+                                  out_ctot=out_ctot, out_coff=out_coff, act=act, gate_ctot=gate_ctot, gate_c=gate_c, prec=PREC_FP8)
+
+    def f8k_supported(self, B, Hi, Wi):
+        return self.in_channels % 32 == 0 and ops.conv_f16k_supported(self._desc_f8k(B, Hi, Wi))
+
+    def _out_desc(self, make, B, Hi, Wi, act, out, out_nchw, out_coff, gate, gate_c):
+        if out_nchw is not None:
+            return make(B, Hi, Wi, out_ctot=out_nchw.shape[1], out_coff=out_coff, act=act, gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
+        if out == "nchw":
+            return make(B, Hi, Wi, act=act)
+        blk = 32 if out == "f8k" else 16
+        return make(B, Hi, Wi, out_ctot=(self.out_channels + blk - 1) // blk * blk, act=act)
+
+    def run_f8k(self, x8, in_scale, B, Hi, Wi, act=ops.ACT_NONE, out="f16k", out_scale=None, out_nchw=None, out_coff=0, gate=None, gate_c=0, gdn=None):
+        """Inference-only: the convolution with fp8 operands on an F8K input holding fp8(x / in_scale).  Returns (y, Ho, Wo);
+        y: F16K bf16 ("f16k"), F8K fp8(y / out_scale) ("f8k") or float32 NCHW ("nchw" / a view of `out_nchw`)."""
+        desc = self._out_desc(self._desc_f8k, B, Hi, Wi, act, out, out_nchw, out_coff, gate, gate_c)
+        w = self.weight
+        vkey = (w._version, w.data_ptr(), str(w.device))
+        wp, ws = _cached(self, "_packed_f8k_cache", vkey, (desc.B, desc.Hi, desc.Wi), lambda: ops.pack_conv_f8k_weight(w.detach().contiguous(), desc))
+        wscale = _cached(self, "_wscale_f8k_cache", vkey, (desc.B, desc.Hi, desc.Wi, float(in_scale)), lambda: (ws * float(in_scale)).contiguous())
+        y = ops.conv2d_f8k(x8, wp, wscale, None if self.bias is None else self.bias.detach(), desc, out=out, out_scale=out_scale, out_nchw=out_nchw,
+                           gate=gate, gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
+        return y, desc.Ho, desc.Wo
+
+    def run_f16k_f8out(self, x16, B, Hi, Wi, out_scale, act=ops.ACT_NONE, gdn=None):
+        """bf16 operands on an F16K input, result stored as F8K fp8(y / out_scale) for an fp8-operand consumer."""
+        desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 31) // 32 * 32, act=act)
+        y = ops.conv2d_f8k(x16, self.packed_f16k_weight(desc), None, None if self.bias is None else self.bias.detach(), desc, out="f8k",
+                           out_scale=out_scale, gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
+        return y, desc.Ho, desc.Wo
+
+    def packed_gemm_f8k_weight(self, in_scale):
+        """(fp8 pack, dequantisation scales = per-channel weight scale x in_scale) of a 1x1 layer for gemm_f8k."""
+        w = self.weight
+        vkey = (w._version, w.data_ptr(), str(w.device))
+        wp, ws = _cached(self, "_packed_gemm_f8k_cache", vkey, (), lambda: ops.pack_gemm_f8k_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))
+        return wp, _cached(self, "_wscale_gemm_f8k_cache", vkey, (float(in_scale),), lambda: (ws * float(in_scale)).contiguous())
 
     def packed_first_layer_weight(self):
         """Fragment image of a Conv2d(3, 128, 5, stride 2) weight for the fused conv + GDN kernel of the first analysis layer."""

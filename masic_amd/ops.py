@@ -709,3 +709,132 @@ def gemm_f16k(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_coff
     check(lib.masic_gemm_f16k_fwd(_p(x_f16k), _p(wp), _p(bias), _p(y16), _p(y32), B, Cin, Cout, HW, out_ctot, out_coff, int(act), _stream()),
           "gemm_f16k_fwd")
     return y32 if y32 is not None else y16
+
+
+# --------------------------------------------------------------------------------------------- fp8 operand path (F8K)
+def f8k_to_nchw(y8, B, C, H, W, scale):
+    """F8K uint8 buffer -> float32 NCHW (torch ops; tests only)."""
+    c32 = (C + 31) // 32
+    t = y8.cpu().view(torch.float8_e4m3fn).float().view(B, c32, H * W, 32).permute(0, 1, 3, 2).reshape(B, c32 * 32, H, W)
+    return (t[:, :C] * scale).contiguous().to(y8.device)
+
+
+def nchw_to_f8k(x, scale, C=None, coff=0, in_op=INOP_NONE):
+    """float32 NCHW (channel view) -> F8K fp8 [B][ceil32(C)/32][HW][32] holding fp8(x / scale) (saturating)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    C = ctot if C is None else C
+    y = torch.empty(lib.masic_f8k_bytes(B, C, H * W), dtype=torch.uint8, device=x.device)
+    check(lib.masic_nchw_to_f8k(_p(x), _p(y), B, C, H * W, ctot, coff, int(in_op), 1.0 / float(scale), _stream()), "nchw_to_f8k")
+    return y
+
+
+def absmax(t, into=None):
+    """Device float32 scalar max(|t|) (float32 tensors, or F16K int16 buffers read as bf16); `into`: running maximum."""
+    if not t.is_cuda:
+        raise RuntimeError("masic_amd.absmax: device tensors only")
+    out = into if into is not None else torch.zeros(1, dtype=torch.float32, device=t.device)
+    bf16 = t.dtype in (torch.int16, torch.bfloat16)
+    if not bf16 and t.dtype != torch.float32:
+        raise RuntimeError("masic_amd.absmax: float32 or bf16 (F16K) data")
+    check(lib.masic_absmax(_p(t), t.numel(), int(bf16), _p(out), _stream()), "absmax")
+    return out
+
+
+def pack_conv_f8k_weight(weight, desc):
+    """-> (fp8 slab stream, per-output-channel weight scales [Cout]) for masic_conv_f8k_fwd (desc.prec = PREC_FP8)."""
+    _dev(weight, "weight")
+    nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+    if nbytes == 0:
+        check(-1, "conv_f8k_packed_bytes")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    ws = torch.empty(desc.Cout, dtype=torch.float32, device=weight.device)
+    check(lib.masic_conv_f8k_pack_weight(_p(weight), _p(packed), _p(ws), ctypes.byref(desc), _stream()), "conv_f8k_pack_weight")
+    return packed, ws
+
+
+def conv2d_f8k(x, packed, wscale, bias, desc, out="f16k", out_scale=None, out_nchw=None, gate=None, gdn=None):
+    """Conv on an F8K (desc.prec = PREC_FP8, `wscale` = weight scales x input scale) or F16K (PREC_BF16, wscale None) input.
+    out: "nchw" (float32, or the channel view `out_nchw`), "f16k" (bf16) or "f8k" (fp8 of y / out_scale)."""
+    if not x.is_cuda or x.dtype not in (torch.uint8, torch.int16):
+        raise RuntimeError("masic_amd.conv2d_f8k: input must be an F8K uint8 / F16K int16 CUDA buffer")
+    f8 = desc.prec == _lib.PREC_FP8
+    if (x.dtype == torch.uint8) != f8:
+        raise RuntimeError("masic_amd.conv2d_f8k: input format does not match desc.prec")
+    per_rec = 32 if f8 else 16
+    if x.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
+        raise RuntimeError(f"masic_amd.conv2d_f8k: input buffer of {x.numel()} elements does not match the descriptor (records of {per_rec} channels)")
+    if f8:
+        _dev(wscale, "wscale")
+        if wscale.numel() != desc.Cout:
+            raise RuntimeError("masic_amd.conv2d_f8k: wscale must have Cout entries")
+    if bias is not None:
+        _dev(bias, "bias")
+    y32 = y16 = y8 = None
+    inv = 0.0
+    if out == "nchw" or out_nchw is not None:
+        y32 = out_nchw if out_nchw is not None else torch.empty((desc.B, desc.out_ctot, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
+        if tuple(y32.shape) != (desc.B, desc.out_ctot, desc.Ho, desc.Wo):
+            raise RuntimeError("masic_amd.conv2d_f8k: output buffer does not match the descriptor")
+    elif out == "f8k":
+        if not out_scale or out_scale <= 0:
+            raise RuntimeError("masic_amd.conv2d_f8k: an fp8 output needs out_scale > 0")
+        y8 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.uint8, device=x.device)
+        inv = 1.0 / float(out_scale)
+    else:
+        y16 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.int16, device=x.device)
+    gp, ginv = (None, 0) if gdn is None else (gdn[0], int(gdn[1]))
+    timed = None
+    if _timer is not None:
+        buf = ctypes.create_string_buffer(96)
+        lib.masic_conv_f16k_kernel_name(ctypes.byref(desc), int(gdn is not None), buf, 96)
+        variant = buf.value.decode()
+        if _timer.only is None or variant == _timer.only:
+            timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timed[1].record()
+    check(lib.masic_conv_f8k_fwd(_p(x), _p(packed), _p(wscale) if f8 else None, _p(bias), _p(gate), _p(gp), ginv, _p(y32), _p(y16), _p(y8),
+                                 float(inv), ctypes.byref(desc), _stream()), "conv_f8k_fwd")
+    if timed is not None:
+        timed[2].record()
+        flops, nbytes = conv_algorithmic_work(desc)
+        _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
+    return y32 if y32 is not None else (y8 if y8 is not None else y16)
+
+
+def conv_a_gdn_f8k(x, packed, bias, gdn, out_scale, in_coff=0):
+    """conv_a_gdn_f16k with the result stored as F8K fp8(y / out_scale)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B * 128 * Ho * Wo, dtype=torch.uint8, device=x.device)
+    check(lib.masic_conv_a_gdn_fwd_ex(_p(x), _p(packed), _p(bias), _p(gdn[0]), int(gdn[1]), None, _p(y), 1.0 / float(out_scale), B, H, W, ctot, in_coff,
+                                      _stream()), "conv_a_gdn_fwd_ex")
+    return y, Ho, Wo
+
+
+def pack_gemm_f8k_weight(weight, Cin, Cout, transposed):
+    _dev(weight, "weight")
+    wp = torch.empty(lib.masic_gemm_f8k_packed_bytes(Cin, Cout), dtype=torch.uint8, device=weight.device)
+    ws = torch.empty(Cout, dtype=torch.float32, device=weight.device)
+    check(lib.masic_gemm_f8k_pack_weight(_p(weight), _p(wp), _p(ws), Cin, Cout, int(transposed), _stream()), "gemm_f8k_pack_weight")
+    return wp, ws
+
+
+def gemm_f8k(x_f8k, wp, wscale, bias, B, Cin, Cout, H, W, act, out="f16k", out_scale=None, out_nchw=None, out_coff=0):
+    """y = act(W x + b) on F8K activations with fp8 weights; out: "f16k" (bf16), "f8k" (fp8 of y / out_scale) or "nchw"."""
+    HW = H * W
+    y32 = y16 = y8 = None
+    inv = 0.0
+    if out == "nchw" or out_nchw is not None:
+        y32 = out_nchw if out_nchw is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_f8k.device)
+        out_ctot = y32.shape[1]
+    elif out == "f8k":
+        out_ctot = (Cout + 31) // 32 * 32
+        y8 = torch.empty(B * out_ctot * HW, dtype=torch.uint8, device=x_f8k.device)
+        inv = 1.0 / float(out_scale)
+    else:
+        out_ctot = (Cout + 15) // 16 * 16
+        y16 = torch.empty(B * out_ctot * HW, dtype=torch.int16, device=x_f8k.device)
+    check(lib.masic_gemm_f8k_fwd(_p(x_f8k), _p(wp), _p(_dev(wscale, "wscale")), _p(bias), _p(y16), _p(y8), _p(y32), float(inv), B, Cin, Cout, HW,
+                                 out_ctot, out_coff, int(act), _stream()), "gemm_f8k_fwd")
+    return y32 if y32 is not None else (y8 if y8 is not None else y16)
