@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
+FP8_MFMA_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: dense fp8 peak (block-scaled v_mfma_scale_f32_32x32x64_f8f6f4: 2x bf16 per clock)
 HBM_PEAK_GBS = 8000.0
 HSIC_GFLOP_PER_PAIR_512 = 161.12   # SURVEY.md 8(d), forward, 512x512; proportional to H*W
 CQE_GFLOP_PER_PAIR_512 = 817.5
@@ -157,6 +158,9 @@ def pmc_child(args):
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100))
     net = net.to(dev).eval()
     x1, x2, hm = (t.to(dev) for t in synth.synth_inputs(args.batch, args.height, args.width, seed=100))
+    if args.precision == "fp8":
+        from masic_amd import fp8
+        fp8.calibrate(net, [tuple(t.to(dev) for t in synth.synth_inputs(2, args.height, args.width, seed=1100))])
     with torch.no_grad():
         for _ in range(3):
             net(x1, x2, hm)
@@ -228,8 +232,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("MASIC_PRECISION", "bf16"),
-                    help="operand precision of the forward MFMA contractions (float32 accumulate either way)")
+    ap.add_argument("--precision", choices=["bf16", "f32", "fp8"], default=os.environ.get("MASIC_PRECISION", "bf16"),
+                    help="operand precision of the forward MFMA contractions (float32 accumulate either way); fp8 = BASELINE configs[4]: e4m3 "
+                         "operands on the 128->128 5x5 layers and the first two layers of the entropy-parameter stacks (masic_amd/fp8.py)")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the fp8-operand timing / accuracy extras of a bf16 run (extras.fp8_path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed forward eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-codec", action="store_true", help="skip the compress / decompress timing of one pair (extras.bitstream)")
@@ -285,6 +291,11 @@ def main():
     net = net.to(dev).eval()
     x1h, x2h, hmh = synth.synth_inputs(B, H, W, seed=100 + rank)
     x1, x2, hm = x1h.to(dev), x2h.to(dev), hmh.to(dev)
+    fp8_table = None
+    if args.precision == "fp8" or (args.precision == "bf16" and not args.no_fp8):
+        # activation scales of the fp8 mode from ONE calibration batch that is not the measured one (same on every rank)
+        from masic_amd import fp8
+        fp8_table = fp8.calibrate(net, [tuple(t.to(dev) for t in synth.synth_inputs(2, H, W, seed=1100))])
 
     def barrier():
         if world > 1:
@@ -401,11 +412,11 @@ def main():
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
-    peak = BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS
+    peak = FP8_MFMA_PEAK_TFLOPS if dom.endswith(", true>") else (BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS)
     traffic, traffic_source = traffic_for(dom, pmc, pmc_reason)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": a["bytes"] / a["launches"] / (2.0 if peak == BF16_MFMA_PEAK_TFLOPS else 1.0),
+                "algorithmic_bytes_per_launch": a["bytes"] / a["launches"] / (4.0 if peak == FP8_MFMA_PEAK_TFLOPS else 2.0 if peak == BF16_MFMA_PEAK_TFLOPS else 1.0),
                 "launches_per_step": a["launches"] / args.steps, "avg_launch_ms": avg_ms,
                 "flops_per_launch": a["flops"] / a["launches"],
                 "share_of_step_time": a["ms"] / (elapsed * 1e3),
@@ -433,7 +444,7 @@ def main():
         accuracy_ref = {"sample": f"1x3x{H}x{W} pair (synth seed 100), oracle = oracle/hsic_oracle.py on the host (pinned to the reference)",
                         "oracle": {"bpp": ref["bpp"], "psnr1": ref["psnr1"], "psnr2": ref["psnr2"]}}
         with torch.no_grad():
-            for mode in (["bf16", "f32"] if args.precision == "bf16" else ["f32"]):
+            for mode in ((["fp8"] if fp8_table is not None else []) + ["bf16", "f32"] if args.precision != "f32" else ["f32"]):
                 mnn.set_precision(mode)
                 o = net(r1, r2, rh)
                 s = net.symbol_streams(r1, r2, rh)
@@ -446,7 +457,28 @@ def main():
                                       "x1_hat_max_rel_err": float((o["x1_hat"].cpu() - ref["x1_hat"]).abs().max() / ref["x1_hat"].abs().max()),
                                       "x2_hat_max_rel_err": float((o["x2_hat"].cpu() - ref["x2_hat"]).abs().max() / ref["x2_hat"].abs().max())}
             mnn.set_precision(args.precision)
-    if args.precision == "bf16" and not args.no_f32_compare:
+    fp8_info = None
+    if args.precision == "bf16" and fp8_table is not None:
+        # the same step with fp8 operands (BASELINE configs[4]): its own graph, same batch, same timing protocol
+        mnn.set_precision("fp8")
+        with torch.no_grad():
+            g8 = GraphedHSIC(net, x1, x2, hm)
+            a8, b8 = g8.inputs
+            for _ in range(args.warmup):
+                g8(a8, b8, hm)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g8(a8, b8, hm)
+            barrier()
+            t8 = max_over_ranks(time.perf_counter() - t0)
+            del g8
+        mnn.set_precision("bf16")
+        fp8_info = {"value": world * B * args.steps / t8, "unit": "stereo pairs/s", "steps": args.steps, "ms_per_step": t8 / args.steps * 1e3, "dtype": "fp8",
+                    "what": "the headline step with e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4) on g_a_conv2/3, g_s_conv2/3 and the first two layers of the "
+                            "entropy-parameter stacks (67 % of the forward's FLOPs), per-tensor activation scales from one calibration batch; accuracy against "
+                            "the oracle under extras.accuracy_vs_ref.fp8; `bench.py --precision fp8` makes it the headline with its own roofline"}
+    if args.precision in ("bf16", "fp8") and not args.no_f32_compare:
         with torch.no_grad():
             sym_b = net.symbol_streams(x1, x2, hm)
             crit_b = rate_distortion(out, x1, x2, 0.01)
@@ -461,15 +493,15 @@ def main():
                 net(x1, x2, hm)
             barrier()
             tf = max_over_ranks(time.perf_counter() - t0)
-            mnn.set_precision("bf16")
+            mnn.set_precision(args.precision)
         nsym = sum(v.numel() for v in sym_f.values())
         nbad = sum(int((sym_b[k] != sym_f[k]).sum()) for k in sym_f)
         accuracy = {"bpp_bf16": float(crit_b["bpp_loss"]), "bpp_f32": float(crit_f["bpp_loss"]),
                     "bpp_rel_delta": float(crit_b["bpp_loss"]) / float(crit_f["bpp_loss"]) - 1.0,
                     "psnr1_delta_db": crit_b["psnr1"] - crit_f["psnr1"], "psnr2_delta_db": crit_b["psnr2"] - crit_f["psnr2"],
                     "symbol_mismatch_rate": nbad / nsym, "symbols": nsym,
-                    "note": "bf16-operand forward vs the float32 parity path on the whole bench batch, rank 0 (the comparison against the ORACLE "
-                            "is extras.accuracy_vs_ref)"}
+                    "note": f"{args.precision}-operand forward (keys say bf16) vs the float32 parity path on the whole bench batch, rank 0 (the comparison "
+                            "against the ORACLE is extras.accuracy_vs_ref)"}
         f32_info = {"value": world * B * nf / tf, "unit": "stereo pairs/s", "steps": nf, "ms_per_step": tf / nf * 1e3, "dtype": "f32"}
 
     # ---- Independent_EN (CQE): forward rate + its dominant kernel, and the CQE training step (BASELINE configs[2] stage)
@@ -544,7 +576,7 @@ def main():
         train_info = {"value": world * B * args.train_steps / tt, "unit": "stereo pairs/s", "steps": args.train_steps,
                       "ms_per_step": tt / args.train_steps * 1e3, "loss_after": float(crit["loss"]),
                       "achieved_tflops": gf / 1e3 / (tt / args.train_steps),
-                      "frac_of_mfma_peak": gf / 1e3 / (tt / args.train_steps) / (BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS),
+                      "frac_of_mfma_peak": gf / 1e3 / (tt / args.train_steps) / (F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else BF16_MFMA_PEAK_TFLOPS),
                       "what": f"forward ({args.precision} operands) + RD loss + backward ({args.precision} operands, f32 accumulate)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                               " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146); algorithmic work = 3 x the forward's (SURVEY 8d)"}
 
@@ -587,6 +619,8 @@ def main():
         extras = {}
         if train_info is not None:
             extras["train_step"] = train_info
+        if fp8_info is not None:
+            extras["fp8_path"] = fp8_info
         if f32_info is not None:
             extras["f32_parity_path"] = f32_info
             extras["accuracy_vs_f32"] = accuracy

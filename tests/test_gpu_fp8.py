@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 # fp8-operand forward vs the CPU oracle, HSIC(128,192,5), bench weights: what the mode may cost
-BUDGET = {"bpp_rel": 0.03, "psnr_db": 0.25, "symbol_mismatch": 0.35, "symbol_max_abs": 3}
+BUDGET = {"bpp_rel": 0.01, "psnr_db": 0.05, "symbol_mismatch": 0.35, "symbol_max_abs": 3}
 
 
 def _exact(shape, values, seed):
