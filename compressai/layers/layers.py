@@ -68,3 +68,13 @@ class ResidualBlock(nn.Module):
         identity = x if self.skip is None else self.skip.run(x)
         t = self.conv1.run(x, act=_hip.ACT_LEAKY)
         return self.conv2.run(t, act=_hip.ACT_LEAKY, res1=identity, res2=extra_identity)
+
+    def f16k_supported(self, B, H, W):
+        return self.skip is None and self.conv1.f16k_supported(B, H, W) and self.conv2.f16k_supported(B, H, W)
+
+    def forward_f16k(self, x16, B, H, W, extra16=None, out16=None, out_ctot=None, out_coff=0):
+        """The same block on F16K activations (bf16 operands, masic_amd/csrc/conv_f16k.hip): both LeakyReLUs and both adds in the
+        epilogues; the result may go straight into a channel slice of a wider F16K buffer (the reference's torch.cat target)."""
+        C = self.conv1.in_channels
+        t = self.conv1.run_f16k_res(x16, B, H, W, act=_hip.ACT_LEAKY)
+        return self.conv2.run_f16k_res(t, B, H, W, act=_hip.ACT_LEAKY, res1=x16, res2=extra16, res_ctot=C, out16=out16, out_ctot=out_ctot, out_coff=out_coff)

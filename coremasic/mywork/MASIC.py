@@ -995,6 +995,13 @@ class Enhancement_Block(nn.Module):
         t = self.RB2(self.RB1(x))
         return self.RB3(t, extra_identity=x)        # (RB3(t)) + x, the outer add fused into RB3's last conv
 
+    def f16k_supported(self, B, H, W):
+        return all(rb.f16k_supported(B, H, W) for rb in (self.RB1, self.RB2, self.RB3))
+
+    def forward_f16k(self, x16, B, H, W, out16=None, out_ctot=None, out_coff=0):
+        t = self.RB2.forward_f16k(self.RB1.forward_f16k(x16, B, H, W), B, H, W)
+        return self.RB3.forward_f16k(t, B, H, W, extra16=x16, out16=out16, out_ctot=out_ctot, out_coff=out_coff)
+
 
 class mask2weights_EN(nn.Module):
     """mask -> Kw softmax-normalised gate maps at full resolution (reference :1411-1434)."""
@@ -1065,6 +1072,45 @@ class Independent_EN(nn.Module):
         out2 = self.EBr3(_ag.cat(out2, x2c))
         return {"x1_hat": self.conv2.run(out1, res1=x1_hat), "x2_hat": self.conv2.run(out2, res1=x2_hat)}
 
+    def _forward_f16k(self, x1_hat, x2_hat, h_matrix):
+        """Inference with bf16 operands: the 32 / 64 / 96-channel full-resolution activations stay in F16K bf16 between the 36
+        3x3 convolutions (DMA-staged MFMA kernels, LeakyReLU and residual adds in their epilogues); every gated / warped concat
+        operand of :1470-1482 is written straight into its channel slice (masic_f16k_gate: whole 32-byte records per tap)."""
+        B, _, H, W = x1_hat.shape
+        dev = x1_hat.device
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+        mask_L = _hip.warp_perspective(mask_R, m_back, (H, W))
+        w_R = self.mask2weights_unit(mask_R)
+        w_L = self.mask2weights_unit(mask_L)
+        x1_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))
+        x2_warp = _hip.warp_perspective(x2_hat, m_back, (H, W))
+        outs = []
+        feats = []
+        for x_own, x_other_warp, w, EB1 in ((x1_hat, x2_warp, w_L, self.EBl1), (x2_hat, x1_warp, w_R, self.EBr1)):
+            inp = torch.empty((B, 6, H, W), dtype=torch.float32, device=dev)                  # other_warp * w0 | own * w1   (:1470-1471)
+            _hip.quantize(x_other_warp, "copy", out=inp, out_coff=0, gate=w, gate_c=0)
+            _hip.quantize(x_own, "copy", out=inp, out_coff=3, gate=w, gate_c=1)
+            t16 = _hip.nchw_to_f16k(self.conv1.run(inp))
+            feats.append(EB1.forward_f16k(t16, B, H, W))
+        # stage 2: own * w1 | warp(other) * w0   (:1481-1482)
+        c1 = _hip.f16k_empty(B, 64, H, W, dev)
+        c2 = _hip.f16k_empty(B, 64, H, W, dev)
+        _hip.f16k_gate(feats[0], B, 32, H, W, c1, 64, 0, gate=w_L, gate_c=1)
+        _hip.f16k_gate(feats[1], B, 32, H, W, c1, 64, 32, gate=w_L, gate_c=0, minv=m_back)
+        _hip.f16k_gate(feats[1], B, 32, H, W, c2, 64, 0, gate=w_R, gate_c=1)
+        _hip.f16k_gate(feats[0], B, 32, H, W, c2, 64, 32, gate=w_R, gate_c=0, minv=m_fwd)
+        for x_own, c, EB2, EB3 in ((x1_hat, c1, self.EBl2, self.EBl3), (x2_hat, c2, self.EBr2, self.EBr3)):
+            d = _hip.f16k_empty(B, 96, H, W, dev)                                             # stage-2 output | conv0(x_hat)   (:1486-1487)
+            EB2.forward_f16k(c, B, H, W, out16=d, out_ctot=96, out_coff=0)
+            _hip.nchw_to_f16k_view(self.conv0.run(x_own), d, 96, 64)
+            o = _hip.f16k_to_nchw_dev(EB3.forward_f16k(d, B, H, W), B, 96, H, W)
+            outs.append(self.conv2.run(o, res1=x_own))
+        return {"x1_hat": outs[0], "x2_hat": outs[1]}
+
+    def _f16k_ok(self, B, H, W):
+        return all(eb.f16k_supported(B, H, W) for eb in (self.EBl1, self.EBl2, self.EBl3, self.EBr1, self.EBr2, self.EBr3))
+
     def forward(self, x1_hat, x2_hat, h_matrix):
         if self._needs_graph(x1_hat, x2_hat):
             return self._forward_graph(x1_hat, x2_hat, h_matrix)
@@ -1072,6 +1118,8 @@ class Independent_EN(nn.Module):
         x2_hat = x2_hat.contiguous()
         B, _, H, W = x1_hat.shape
         dev, dt = x1_hat.device, x1_hat.dtype
+        if _bf16_inference(x1_hat, x2_hat) and self._f16k_ok(B, H, W):
+            return self._forward_f16k(x1_hat, x2_hat, h_matrix)
         m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
         mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
         mask_L = _hip.warp_perspective(mask_R, m_back, (H, W))

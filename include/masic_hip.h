@@ -182,6 +182,21 @@ int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const float* wsc
 int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                             void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
 
+/* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
+ * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
+ * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */
+int masic_conv_f16k_res_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                            void* y_f16k, const masic_conv_desc_t* d, void* stream);
+/* layout-side helpers of those chains (masic_amd/csrc/f16k_ops.hip):
+ *   masic_f16k_gate           dst[:, dst_coff : dst_coff+C] = (minv ? warp_perspective(src, minv) : src) * (gate ? gate[:, gate_c] : 1)
+ *                             -- the gated concats of MASIC.py:1470-1482 written straight into their slice of the F16K buffer
+ *   masic_nchw_to_f16k_view   float32 NCHW channel view -> a channel slice of an F16K buffer
+ *   masic_f16k_to_nchw        F16K channel slice -> float32 NCHW channel view */
+int masic_f16k_gate(const void* src, const float* gate, const float* minv, void* dst, int B, int C, int H, int W,
+                    int dst_ctot, int dst_coff, int gate_ctot, int gate_c, void* stream);
+int masic_nchw_to_f16k_view(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, void* stream);
+int masic_f16k_to_nchw(const void* x, float* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream);
+
 size_t masic_conv_a_packed_bytes(void);
 int masic_conv_a_pack_weight(const float* w, void* w_packed, void* stream);
 int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,

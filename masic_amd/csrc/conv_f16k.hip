@@ -63,6 +63,10 @@ __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e, v4u& f, v4u& g, v4u& h, v4u& i, v4u& j) {
     asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j) : "n"(N) : "memory");
 }
@@ -103,6 +107,19 @@ __device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); 
 // whole 32-byte records (full sectors; 1 KiB contiguous when the pixels are adjacent) instead of scattered 8-byte pieces.
 // rec: address of the lane's pixel in the first of the two records, + 8h elements; rec_stride: elements between records.
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi);
+// residual add in float32 BEFORE the rounding to bf16: lane (j, h) holds channels 8q + 4h + i of tile t, i.e. 4 consecutive
+// bf16 (8 bytes) at element offset 8(q & 1) + 4h of record q >> 1 of the residual's tile.  res: address of the lane's pixel in
+// the first record of the tile (element units), + 4h.
+__device__ __forceinline__ void add_f16k_residual(f32x16& t, const unsigned short* res, unsigned rec_stride) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint2 r = *reinterpret_cast<const uint2*>(res + (size_t)(q >> 1) * rec_stride + 8 * (q & 1));
+        t[4 * q + 0] += __builtin_bit_cast(float, r.x << 16);
+        t[4 * q + 1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
+        t[4 * q + 2] += __builtin_bit_cast(float, r.y << 16);
+        t[4 * q + 3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
+    }
+}
 __device__ __forceinline__ void store_f16k_tile(const f32x16& t, unsigned short* rec, unsigned rec_stride) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -147,6 +164,9 @@ struct F16kArgs {
     float* y32;                   // float32 NCHW view, or null
     unsigned short* y16;          // F16K [B][out_c16tot][Ho*Wo][16], or null
     const uint4* gdn_img;         // GDN epilogue: gamma^ fragments (gdn.hip: gdn_pack_f16k_kernel), then beta^[128] floats
+    const unsigned short* res1;   // F16K output only: up to two residual tensors [B][res_ctot/16][Ho*Wo][16] added after the activation
+    const unsigned short* res2;   //   (ResidualBlock / Enhancement_Block identities, compressai/layers/layers.py:189, MASIC.py:163)
+    int res_ctot;
     const float* wscale;          // fp8 operands: per-output-channel dequantisation factor (weight scale x input scale), else null
     unsigned char* y8;            // F8K [B][out_c32tot][Ho*Wo][32] fp8 output (quantised with out_inv_scale), or null
     float out_inv_scale;
@@ -323,7 +343,7 @@ template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP, bool F
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
     static_assert(!F8 || (NM == 4 && NP == 1 && (T * KS) % 2 == 0 && T <= 4), "fp8 operands: 128-channel blocks, 256-pixel tiles, slab pairs");
-    static_assert(NM + NP == 2 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 5 and 6 fragments per k-step");
+    static_assert(NM + NP == 2 || NM + NP == 4 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 4, 5 and 6 fragments per k-step");
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
     constexpr int WST = T * KS * 4096;           // bytes per step of weights
@@ -551,6 +571,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             if constexpr (NM == 4 && NP == 1) lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0], af[buf][1][0], af[buf][2][0], af[buf][3][0]);
             else if constexpr (NM == 4 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0], af[buf][2][0], af[buf][3][0]);
             else if constexpr (NM == 1 && NP == 4) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], bfr[buf][2][0], bfr[buf][3][0], af[buf][0][0]);
+            else if constexpr (NM == 3 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0], af[buf][2][0]);
+            else if constexpr (NM == 2 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0]);
             else lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0]);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
@@ -680,6 +702,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 const int c16 = (a.out_coff + m0) >> 4;
                 unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
                 const unsigned op16 = (unsigned)oplane * 16;
+                if (a.res1 != nullptr) {
+                    const size_t ro = (((size_t)b * (a.res_ctot >> 4) + (m0 >> 4)) * oplane + opix) * 16 + 4 * h;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m)
+                        if (m0 + m * 32 < a.Cout) {
+                            add_f16k_residual(acc[n][m], a.res1 + ro + (size_t)(2 * m) * op16, op16);
+                            if (a.res2 != nullptr) add_f16k_residual(acc[n][m], a.res2 + ro + (size_t)(2 * m) * op16, op16);
+                        }
+                }
 #pragma unroll
                 for (int m = 0; m < NM; ++m)
                     if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[n][m], yb + (size_t)(2 * m) * op16, op16);
@@ -938,6 +969,7 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
     if (d->prec == MASIC_PREC_FP8) snprintf(buf, n, "conv_f16k<%d, %d, %d, %d, %d, %s, 4, 1, true>", c.KS, c.T, F16K_D, c.KS == 1 ? 6 : 4, c.L, gdn ? "true" : "false");
+    else if (c.NP == 2 && c.KS == 2 && !gdn && d->Cout <= 96) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, false, %d, 2, false>", d->Cout <= 64 ? 2 : 3);
     else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2>", gdn ? "true" : "false");
     else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
     else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1>", c.T, c.D, gdn ? "true" : "false");
@@ -974,7 +1006,19 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
 namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
-                const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f);
+                const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f,
+                const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0);
+}
+
+// F16K in, F16K out (a channel view per d->out_ctot / out_coff) with up to two F16K residual tensors of res_ctot channels added
+// after the activation: out = act(conv(x) + bias) + res1 [+ res2] -- the ResidualBlock / Enhancement_Block form of Independent_EN
+// (compressai/layers/layers.py:160-190, MASIC.py:149-164) with bf16 operands.
+extern "C" int masic_conv_f16k_res_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                                       void* y_f16k, const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(d != nullptr && y_f16k != nullptr, MASIC_ERR_ARG, "conv_f16k_res_fwd: null pointer");
+    MASIC_REQUIRE(res1 != nullptr || res2 == nullptr, MASIC_ERR_ARG, "conv_f16k_res_fwd: res2 without res1");
+    MASIC_REQUIRE(res1 == nullptr || (res_ctot % 16 == 0 && res_ctot >= d->Cout), MASIC_ERR_SHAPE, "conv_f16k_res_fwd: residual tensors need >= Cout channels, a multiple of 16");
+    return f16k_launch(x_f16k, w_packed, bias, nullptr, nullptr, 0, 0, nullptr, y_f16k, d, stream, nullptr, nullptr, 0.0f, res1, res2, res_ctot);
 }
 
 // fp8 (e4m3) operand form (BASELINE configs[4]): d->prec = MASIC_PREC_FP8 -- the input is F8K, weights come from
@@ -1040,7 +1084,8 @@ extern "C" int masic_conv_f16k_d2s_fwd(const void* x_f16k, const void* w_packed,
 namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
-                const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale) {
+                const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale,
+                const void* res1, const void* res2, int res_ctot) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     const bool f8 = d->prec == MASIC_PREC_FP8;
@@ -1063,7 +1108,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
+               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : d->out_ctot, d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
@@ -1110,6 +1155,8 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     } else if (c.NP == 2) {
         if (c.KS == 2) {
             if (gdn_packed) F16K_LAUNCH_D(2, 2, 2, 5, 1, true, 4, 2);
+            else if (d->Cout <= 64) F16K_LAUNCH_D(2, 2, 2, 5, 1, false, 2, 2);       // 64 / 96 output channels (Independent_EN): 2 / 3 accumulator
+            else if (d->Cout <= 96) F16K_LAUNCH_D(2, 2, 2, 5, 1, false, 3, 2);       // tiles per pixel sub-tile instead of 4 with idle MFMAs
             else F16K_LAUNCH_D(2, 2, 2, 5, 1, false, 4, 2);
         } else if (gdn_packed) F16K_LAUNCH(1, 2, 3, 2, true, 4, 2);
         else F16K_LAUNCH(1, 2, 3, 2, false, 4, 2);

@@ -1,0 +1,144 @@
+// f16k_ops.hip -- layout-side helpers of the F16K ([B][C/16][H*W][16] bf16) chains of Independent_EN (gfx950 / MI355X).
+//
+// The CQE network (reference coremasic/mywork/MASIC.py:1436-1501) works at full picture resolution on 32 / 64 / 96 channels;
+// with bf16 operands its 3x3 convolutions run on conv_f16k.hip with the activations in F16K between them.  What the reference
+// writes as `torch.cat((a * w[:, 1:2], warp(b) * w[:, 0:1]), dim=-3)` (:1470-1482) is done here by writing each operand
+// straight into its channel slice of the concatenated F16K buffer:
+//   f16k_gate_kernel   dst[:, coff : coff+C] = (warp?)(src) * gate[:, gc]    (src F16K; gate float32 [B, G, H, W] or none;
+//                      warp = kornia warp_perspective with the sampling arithmetic of warp.hip, 4 taps x one 32-byte record
+//                      per 16-channel block: whole records, no strided gathers)
+//   nchw_to_f16k_view  float32 NCHW -> a channel slice of an F16K buffer
+//   f16k_to_nchw       F16K channel slice -> float32 NCHW (for the 96 -> 3 output layer, which runs on the NCHW kernels)
+// All HBM-bound: bytes in + bytes out.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// one thread per (pixel, 8-channel half record)
+__global__ __launch_bounds__(256) void f16k_gate_kernel(const unsigned short* __restrict__ src, const float* __restrict__ gate,
+                                                        const float* __restrict__ minv, unsigned short* __restrict__ dst,
+                                                        int C, int H, int W, int dst_ctot, int dst_coff, int gate_ctot, int gate_c) {
+    const int b = blockIdx.z, c8 = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (pix >= HW) return;
+    const float g = gate != nullptr ? gate[((size_t)b * gate_ctot + gate_c) * HW + pix] : 1.0f;
+    const uint4* sb = reinterpret_cast<const uint4*>(src + (((size_t)b * (C >> 4) + (c8 >> 1)) * HW) * 16) + (c8 & 1);   // + 2 * pixel
+    float v[8];
+    if (minv == nullptr) {
+        const uint4 q = sb[2 * (size_t)pix];
+        v[0] = bf_lo(q.x); v[1] = bf_hi(q.x); v[2] = bf_lo(q.y); v[3] = bf_hi(q.y);
+        v[4] = bf_lo(q.z); v[5] = bf_hi(q.z); v[6] = bf_lo(q.w); v[7] = bf_hi(q.w);
+    } else {
+        // the sampling location: warp.hip's float32 arithmetic, operation for operation (no FMA contraction)
+        const int oy = pix / W, ox = pix - oy * W;
+        const float* m = minv + b * 9;
+        const float gx = __fmul_rn(__fsub_rn(__fdiv_rn((float)ox, (float)(W - 1)), 0.5f), 2.0f);
+        const float gy = __fmul_rn(__fsub_rn(__fdiv_rn((float)oy, (float)(H - 1)), 0.5f), 2.0f);
+        const float X = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[0]), __fmul_rn(gy, m[1])), m[2]);
+        const float Y = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[3]), __fmul_rn(gy, m[4])), m[5]);
+        const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
+        const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
+        const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
+        const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(W - 1), 2.0f));
+        const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(H - 1), 2.0f));
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const float wx = __fsub_rn(fx, x0f), wy = __fsub_rn(fy, y0f);
+        const float ex = __fsub_rn(1.0f, wx), ey = __fsub_rn(1.0f, wy);
+        const float wt[4] = {__fmul_rn(ex, ey), __fmul_rn(wx, ey), __fmul_rn(ex, wy), __fmul_rn(wx, wy)};
+        const float lim = 1.0e9f;
+        const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+        const bool finite = (fx == fx) && (fy == fy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {          // nw, ne, sw, se in warp.hip's accumulation order
+            const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+            if (finite && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                const uint4 q = sb[2 * ((size_t)yy * W + xx)];
+                const float s[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __fadd_rn(v[i], __fmul_rn(s[i], wt[t]));
+            }
+        }
+    }
+    uint4 o;
+    o.x = pack2(v[0] * g, v[1] * g); o.y = pack2(v[2] * g, v[3] * g); o.z = pack2(v[4] * g, v[5] * g); o.w = pack2(v[6] * g, v[7] * g);
+    const int dc8 = (dst_coff >> 3) + c8;
+    reinterpret_cast<uint4*>(dst + (((size_t)b * (dst_ctot >> 4) + (dc8 >> 1)) * HW) * 16)[2 * (size_t)pix + (dc8 & 1)] = o;
+}
+
+__global__ __launch_bounds__(256) void nchw_to_f16k_view_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int C, int HW,
+                                                                int ctot, int coff, int dst_ctot, int dst_coff) {
+    const int b = blockIdx.z, c8 = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* xb = x + ((size_t)b * ctot + coff) * HW + p;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        v[i] = c < C ? xb[(size_t)c * HW] : 0.0f;
+    }
+    uint4 q;
+    q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
+    const int dc8 = (dst_coff >> 3) + c8;
+    reinterpret_cast<uint4*>(y + (((size_t)b * (dst_ctot >> 4) + (dc8 >> 1)) * HW) * 16)[2 * (size_t)p + (dc8 & 1)] = q;
+}
+
+__global__ __launch_bounds__(256) void f16k_to_nchw_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int C, int HW,
+                                                           int src_ctot, int src_coff, int ctot, int coff) {
+    const int b = blockIdx.z, c8 = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int sc8 = (src_coff >> 3) + c8;
+    const uint4 q = reinterpret_cast<const uint4*>(x + (((size_t)b * (src_ctot >> 4) + (sc8 >> 1)) * HW) * 16)[2 * (size_t)p + (sc8 & 1)];
+    const float v[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
+    float* yb = y + ((size_t)b * ctot + coff) * HW + p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (c8 * 8 + i < C) yb[(size_t)(c8 * 8 + i) * HW] = v[i];
+}
+
+}  // namespace
+
+// dst[:, dst_coff : dst_coff + C] = (minv ? warp(src, minv) : src) * (gate ? gate[:, gate_c] : 1); src: F16K of exactly C channels,
+// C % 8 == 0 and dst_coff % 8 == 0; minv: the [B,3,3] normalised sampling matrices of masic_warp_matrix / masic_amd.homography.
+extern "C" int masic_f16k_gate(const void* src, const float* gate, const float* minv, void* dst, int B, int C, int H, int W,
+                               int dst_ctot, int dst_coff, int gate_ctot, int gate_c, void* stream) {
+    MASIC_REQUIRE(src && dst, MASIC_ERR_ARG, "f16k_gate: null pointer");
+    MASIC_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && H > 0 && W > 0 && dst_ctot % 16 == 0 && dst_coff % 8 == 0 && dst_coff >= 0 && dst_coff + C <= dst_ctot,
+                  MASIC_ERR_SHAPE, "f16k_gate: channel views (C %% 16, dst_coff %% 8, inside dst_ctot)");
+    MASIC_REQUIRE(gate == nullptr || (gate_c >= 0 && gate_c < gate_ctot), MASIC_ERR_SHAPE, "f16k_gate: gate channel out of range");
+    hipLaunchKernelGGL(f16k_gate_kernel, dim3(ceil_div(H * W, 256), C / 8, B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, gate, minv, (unsigned short*)dst, C, H, W, dst_ctot, dst_coff, gate_ctot, gate_c);
+    return masic_launch_status("f16k_gate");
+}
+
+extern "C" int masic_nchw_to_f16k_view(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, void* stream) {
+    MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "nchw_to_f16k_view: null pointer");
+    MASIC_REQUIRE(coff >= 0 && coff + C <= ctot && dst_ctot % 16 == 0 && dst_coff % 8 == 0 && dst_coff >= 0 && dst_coff + round_up(C, 8) <= dst_ctot,
+                  MASIC_ERR_SHAPE, "nchw_to_f16k_view: view out of range");
+    hipLaunchKernelGGL(nchw_to_f16k_view_kernel, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
+                       x, (unsigned short*)y, C, HW, ctot, coff, dst_ctot, dst_coff);
+    return masic_launch_status("nchw_to_f16k_view");
+}
+
+extern "C" int masic_f16k_to_nchw(const void* x, float* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream) {
+    MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "f16k_to_nchw: null pointer");
+    MASIC_REQUIRE(coff >= 0 && coff + C <= ctot && src_ctot % 16 == 0 && src_coff % 8 == 0 && src_coff >= 0 && src_coff + C <= src_ctot,
+                  MASIC_ERR_SHAPE, "f16k_to_nchw: view out of range");
+    hipLaunchKernelGGL(f16k_to_nchw_kernel, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, y, C, HW, src_ctot, src_coff, ctot, coff);
+    return masic_launch_status("f16k_to_nchw");
+}

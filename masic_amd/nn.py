@@ -241,6 +241,13 @@ class _PackedWeightMixin:
                             gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
         return y, desc.Ho, desc.Wo
 
+    def run_f16k_res(self, x16, B, Hi, Wi, act=ops.ACT_NONE, res1=None, res2=None, res_ctot=0, out16=None, out_ctot=None, out_coff=0):
+        """Inference-only: F16K -> F16K (optionally a channel view of `out16`) with F16K residual tensors added after the activation."""
+        oc = (self.out_channels + 15) // 16 * 16 if out_ctot is None else out_ctot
+        desc = self._desc_f16k(B, Hi, Wi, out_ctot=oc, out_coff=out_coff, act=act)
+        return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc, y16=out16,
+                                   res1=res1, res2=res2, res_ctot=res_ctot)
+
     def packed_gemm_dma_weight(self):
         """Per-128-channel-block k16-major pack of a 1x1 layer for the DMA-staged GEMM (conv_f16k.hip: gemm_f16k)."""
         w = self.weight

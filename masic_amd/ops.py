@@ -838,3 +838,78 @@ def gemm_f8k(x_f8k, wp, wscale, bias, B, Cin, Cout, H, W, act, out="f16k", out_s
     check(lib.masic_gemm_f8k_fwd(_p(x_f8k), _p(wp), _p(_dev(wscale, "wscale")), _p(bias), _p(y16), _p(y8), _p(y32), float(inv), B, Cin, Cout, HW,
                                  out_ctot, out_coff, int(act), _stream()), "gemm_f8k_fwd")
     return y32 if y32 is not None else (y8 if y8 is not None else y16)
+
+
+# --------------------------------------------------------------------------------------------- F16K chains of Independent_EN
+def f16k_empty(B, C, H, W, device):
+    """Uninitialised F16K buffer of C (multiple of 16) channels."""
+    if C % 16:
+        raise RuntimeError("masic_amd.f16k_empty: channels must be a multiple of 16")
+    return torch.empty(B * C * H * W, dtype=torch.int16, device=device)
+
+
+def f16k_gate(src16, B, C, H, W, dst16, dst_ctot, dst_coff, gate=None, gate_c=0, minv=None):
+    """dst[:, dst_coff:dst_coff+C] = (warp(src, minv) if minv is not None else src) * (gate[:, gate_c] if gate is not None else 1)."""
+    if src16.dtype != torch.int16 or dst16.dtype != torch.int16 or src16.numel() != B * C * H * W or dst16.numel() != B * dst_ctot * H * W:
+        raise RuntimeError("masic_amd.f16k_gate: F16K buffer sizes do not match (B, C, H, W)")
+    gct = 0
+    if gate is not None:
+        _dev(gate, "gate")
+        if gate.shape[0] != B or tuple(gate.shape[-2:]) != (H, W):
+            raise RuntimeError("masic_amd.f16k_gate: gate shape mismatch")
+        gct = gate.shape[1]
+    if minv is not None:
+        _dev(minv, "warp matrix")
+        if tuple(minv.shape) != (B, 3, 3):
+            raise RuntimeError("masic_amd.f16k_gate: matrix batch mismatch")
+    check(lib.masic_f16k_gate(_p(src16), _p(gate), _p(minv), _p(dst16), B, C, H, W, dst_ctot, dst_coff, gct, gate_c, _stream()), "f16k_gate")
+    return dst16
+
+
+def nchw_to_f16k_view(x, dst16, dst_ctot, dst_coff, C=None, coff=0):
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    C = ctot if C is None else C
+    if dst16.dtype != torch.int16 or dst16.numel() != B * dst_ctot * H * W:
+        raise RuntimeError("masic_amd.nchw_to_f16k_view: destination buffer size mismatch")
+    check(lib.masic_nchw_to_f16k_view(_p(x), _p(dst16), B, C, H * W, ctot, coff, dst_ctot, dst_coff, _stream()), "nchw_to_f16k_view")
+    return dst16
+
+
+def f16k_to_nchw_dev(x16, B, C, H, W, src_ctot=None, src_coff=0):
+    """F16K channel slice -> float32 NCHW (HIP kernel; `f16k_to_nchw` above is the torch-op form the tests use as a checker)."""
+    src_ctot = C if src_ctot is None else src_ctot
+    if x16.dtype != torch.int16 or x16.numel() != B * src_ctot * H * W:
+        raise RuntimeError("masic_amd.f16k_to_nchw_dev: source buffer size mismatch")
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x16.device)
+    check(lib.masic_f16k_to_nchw(_p(x16), _p(y), B, C, H * W, src_ctot, src_coff, C, 0, _stream()), "f16k_to_nchw")
+    return y
+
+
+def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res_ctot=0):
+    """F16K in -> F16K out (channel view desc.out_ctot / out_coff of `y16`, or a fresh buffer) + residual F16K tensors."""
+    if x16.dtype != torch.int16 or x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
+        raise RuntimeError("masic_amd.conv2d_f16k_res: input buffer does not match the descriptor")
+    n_out = desc.B * desc.out_ctot * desc.Ho * desc.Wo
+    if y16 is None:
+        y16 = torch.empty(n_out, dtype=torch.int16, device=x16.device)
+    elif y16.dtype != torch.int16 or y16.numel() != n_out:
+        raise RuntimeError("masic_amd.conv2d_f16k_res: output buffer does not match the descriptor")
+    for r in (res1, res2):
+        if r is not None and (r.dtype != torch.int16 or r.numel() != desc.B * res_ctot * desc.Ho * desc.Wo):
+            raise RuntimeError("masic_amd.conv2d_f16k_res: residual buffer does not match (B, res_ctot, Ho, Wo)")
+    timed = None
+    if _timer is not None:
+        buf = ctypes.create_string_buffer(96)
+        lib.masic_conv_f16k_kernel_name(ctypes.byref(desc), 0, buf, 96)
+        variant = buf.value.decode()
+        if _timer.only is None or variant == _timer.only:
+            timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timed[1].record()
+    check(lib.masic_conv_f16k_res_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(y16), ctypes.byref(desc), _stream()),
+          "conv_f16k_res_fwd")
+    if timed is not None:
+        timed[2].record()
+        flops, nbytes = conv_algorithmic_work(desc)
+        _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
+    return y16

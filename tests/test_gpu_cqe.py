@@ -224,3 +224,91 @@ def test_capture_guard_raises_before_end_capture_on_hardware():
     g.replay()
     torch.cuda.synchronize()
     assert float(buf[0]) == 2.0
+
+
+# ------------------------------------------------------------------------------------------ F16K kernels of the bf16-operand CQE forward
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("C", [32, 64, 96])
+def test_conv_f16k_residual_block_kernels(C):
+    """3x3 stride-1 convolutions on F16K with 1 / 2 / 3 accumulator tiles per pixel sub-tile (32 / 64 / 96 channels), LeakyReLU and two
+    F16K residual tensors in the epilogue, output into a channel slice of a wider buffer -- against torch on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from masic_amd import nn as mnn, ops
+    B, H, W = 2, 40, 72                        # ragged against the 8 x 32 pixel sub-tiles
+    g = torch.Generator().manual_seed(C)
+    x, r1, r2 = (torch.randn(B, C, H, W, generator=g) for _ in range(3))
+    conv = mnn.Conv2d(C, C, 3, stride=1, padding=1).to(DEV)
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+    assert conv.f16k_supported(B, H, W)
+    x16, r116, r216 = (ops.nchw_to_f16k(t.to(DEV)) for t in (x, r1, r2))
+    ref = F.leaky_relu(F.conv2d(_bf(x), _bf(conv.weight.detach().cpu()), conv.bias.detach().cpu(), padding=1), 0.01) + _bf(r1) + _bf(r2)
+    y16 = conv.run_f16k_res(x16, B, H, W, act=ops.ACT_LEAKY, res1=r116, res2=r216, res_ctot=C)
+    got = ops.f16k_to_nchw(y16, B, C, H, W)
+    assert_close(got, ref, f"conv_f16k_res C={C}", 2 ** -8 + 1e-4)
+    assert torch.equal(ops.f16k_to_nchw_dev(y16, B, C, H, W), got)                 # the HIP conversion == the torch-op checker
+    # one residual, written into channels [0, C) of a buffer of C + 32 channels whose other channels must stay untouched
+    wide = ops.nchw_to_f16k(torch.full((B, C + 32, H, W), 7.0).to(DEV))
+    conv.run_f16k_res(x16, B, H, W, act=ops.ACT_LEAKY, res1=r116, res_ctot=C, out16=wide, out_ctot=C + 32, out_coff=0)
+    w = ops.f16k_to_nchw(wide, B, C + 32, H, W)
+    ref1 = F.leaky_relu(F.conv2d(_bf(x), _bf(conv.weight.detach().cpu()), conv.bias.detach().cpu(), padding=1), 0.01) + _bf(r1)
+    assert_close(w[:, :C], ref1, f"conv_f16k_res view C={C}", 2 ** -8 + 1e-4)
+    assert float((w[:, C:] - 7.0).abs().max()) == 0.0
+
+
+def test_f16k_gate_warp_and_views():
+    """masic_f16k_gate (copy / warp, gated, into a channel slice) against the oracle's warp_perspective on the bf16-rounded source;
+    masic_nchw_to_f16k_view / masic_f16k_to_nchw slices."""
+    from masic_amd import ops, synth
+    from masic_amd.homography import warp_matrices
+    B, C, H, W = 2, 32, 48, 80
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    gate = torch.rand(B, 2, H, W, generator=g)
+    _, _, hm = synth.synth_inputs(B, H, W, seed=5)
+    m_fwd, m_back = warp_matrices(hm.to(DEV), (H, W), (H, W), want_inverse=True)
+    x16 = ops.nchw_to_f16k(x.to(DEV))
+    dst = ops.nchw_to_f16k(torch.zeros(B, 64, H, W).to(DEV))
+    ops.f16k_gate(x16, B, C, H, W, dst, 64, 0, gate=gate.to(DEV), gate_c=1)
+    ops.f16k_gate(x16, B, C, H, W, dst, 64, 32, gate=gate.to(DEV), gate_c=0, minv=m_back)
+    got = ops.f16k_to_nchw(dst, B, 64, H, W).cpu()
+    assert_close(got[:, :32], _bf(x) * gate[:, 1:2], "f16k_gate copy", 2 ** -8)
+    ref_w = O.warp_perspective(_bf(x), torch.inverse(hm), (H, W)) * gate[:, 0:1]
+    assert_close(got[:, 32:], ref_w, "f16k_gate warp", 2 ** -8 + 1e-4)
+    # ungated warp with the forward matrix == warp.hip on the same (bf16-rounded) source, up to the output rounding
+    d2 = ops.f16k_empty(B, 32, H, W, DEV)
+    ops.f16k_gate(x16, B, C, H, W, d2, 32, 0, minv=m_fwd)
+    assert_close(ops.f16k_to_nchw(d2, B, 32, H, W), ops.warp_perspective(_bf(x).to(DEV), m_fwd, (H, W)), "f16k_gate warp vs warp.hip", 2 ** -8)
+    # views
+    y = torch.randn(B, 24, H, W, generator=g)
+    buf = ops.nchw_to_f16k(torch.zeros(B, 64, H, W).to(DEV))
+    ops.nchw_to_f16k_view(y.to(DEV), buf, 64, 40)
+    back = ops.f16k_to_nchw(buf, B, 64, H, W).cpu()
+    assert torch.equal(back[:, 40:64], _bf(y)) and float(back[:, :40].abs().max()) == 0.0
+    assert torch.equal(ops.f16k_to_nchw_dev(buf, B, 24, H, W, src_ctot=64, src_coff=40).cpu(), _bf(y))
+
+
+def test_independent_en_f16k_path_vs_oracle_and_nchw_path():
+    """The bf16-operand inference forward of Independent_EN (F16K chains) against the oracle (bounded: bf16 operands through 18
+    convolutions per view) and against the NCHW bf16 kernels it replaces (same operand rounding, different accumulation order)."""
+    from masic_amd import nn as mnn, synth
+    net, sd = _en(12)
+    net.eval()
+    xa, xb, hm = synth.synth_inputs(2, 128, 192, seed=12)
+    with torch.no_grad():
+        ref = O.independent_en_forward(sd, xa, xb, hm)
+        mnn.set_precision("bf16")
+        try:
+            out = net(xa.to(DEV), xb.to(DEV), hm.to(DEV))
+            net._f16k_ok = lambda *a: False                   # the round-1 path: NCHW float32 activations, bf16 operands
+            old = net(xa.to(DEV), xb.to(DEV), hm.to(DEV))
+        finally:
+            del net._f16k_ok
+            mnn.set_precision("f32")
+    for k in ("x1_hat", "x2_hat"):
+        e = assert_close(out[k], ref[k], "cqe f16k vs oracle:" + k, 2e-2)
+        e2 = assert_close(out[k], old[k], "cqe f16k vs NCHW bf16 path:" + k, 2e-2)
+        print(f"Independent_EN F16K path, {k}: {e:.2e} from the oracle, {e2:.2e} from the NCHW bf16-operand path")
