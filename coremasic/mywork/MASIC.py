@@ -1104,8 +1104,11 @@ class Independent_EN(nn.Module):
             d = _hip.f16k_empty(B, 96, H, W, dev)                                             # stage-2 output | conv0(x_hat)   (:1486-1487)
             EB2.forward_f16k(c, B, H, W, out16=d, out_ctot=96, out_coff=0)
             _hip.nchw_to_f16k_view(self.conv0.run(x_own), d, 96, 64)
-            o = _hip.f16k_to_nchw_dev(EB3.forward_f16k(d, B, H, W), B, 96, H, W)
-            outs.append(self.conv2.run(o, res1=x_own))
+            o16 = EB3.forward_f16k(d, B, H, W)
+            if self.conv2.few_supported(B, H, W):
+                outs.append(self.conv2.run_f16k_few(o16, B, H, W, res32=x_own))               # 96 -> 3 on the MFMA kernel + the picture (:1495-1496)
+            else:
+                outs.append(self.conv2.run(_hip.f16k_to_nchw_dev(o16, B, 96, H, W), res1=x_own))
         return {"x1_hat": outs[0], "x2_hat": outs[1]}
 
     def _f16k_ok(self, B, H, W):

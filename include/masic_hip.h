@@ -187,6 +187,10 @@ int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* b
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */
 int masic_conv_f16k_res_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
                             void* y_f16k, const masic_conv_desc_t* d, void* stream);
+/* a layer with few output channels (Independent_EN.conv2: 96 -> 3 + the picture as residual, MASIC.py:1492-1496) on the same kernels:
+ * `d` describes the convolution with its weight zero-padded to Cout = 32; y_nchw / res32 are float32 [B][cout_store][Ho][Wo]. */
+int masic_conv_f16k_few_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* res32, float* y_nchw,
+                            int cout_store, const masic_conv_desc_t* d, void* stream);
 /* layout-side helpers of those chains (masic_amd/csrc/f16k_ops.hip):
  *   masic_f16k_gate           dst[:, dst_coff : dst_coff+C] = (minv ? warp_perspective(src, minv) : src) * (gate ? gate[:, gate_c] : 1)
  *                             -- the gated concats of MASIC.py:1470-1482 written straight into their slice of the F16K buffer

@@ -167,6 +167,8 @@ struct F16kArgs {
     const unsigned short* res1;   // F16K output only: up to two residual tensors [B][res_ctot/16][Ho*Wo][16] added after the activation
     const unsigned short* res2;   //   (ResidualBlock / Enhancement_Block identities, compressai/layers/layers.py:189, MASIC.py:163)
     int res_ctot;
+    const float* res32;           // float32 NCHW output only: residual [B][cout_store][Ho][Wo] added after the activation, or null
+    int cout_store;               // float32 NCHW output: channels actually stored (< Cout when the weight was zero-padded to a multiple of 32)
     const float* wscale;          // fp8 operands: per-output-channel dequantisation factor (weight scale x input scale), else null
     unsigned char* y8;            // F8K [B][out_c32tot][Ho*Wo][32] fp8 output (quantised with out_inv_scale), or null
     float out_inv_scale;
@@ -681,7 +683,20 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 }
             }
         } else if (pok) {
-            if (a.y32 != nullptr) {
+            if (a.y32 != nullptr && a.cout_store < a.Cout) {
+                // zero-padded output channels (a 96 -> 3 layer run as 96 -> 32): store the real ones, with the float32 residual
+                const int cbase = m0 + 4 * h;
+                float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + cbase) * oplane + opix;
+                const float* rb = a.res32 != nullptr ? a.res32 + ((size_t)b * a.cout_store + cbase) * oplane + opix : nullptr;
+                const unsigned op = (unsigned)oplane;
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int cc = m * 32 + (e & 3) + 8 * (e >> 2);
+                        if (cbase + cc < a.cout_store) yb[(unsigned)cc * op] = acc[n][m][e] + (rb != nullptr ? rb[(unsigned)cc * op] : 0.0f);
+                    }
+            } else if (a.y32 != nullptr) {
                 float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * oplane + opix;
                 const unsigned op = (unsigned)oplane;
 #pragma unroll
@@ -1007,7 +1022,17 @@ namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f,
-                const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0);
+                const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0, const float* res32 = nullptr, int cout_store = 0);
+}
+
+// A layer with few output channels (conv2 of Independent_EN: 96 -> 3, MASIC.py:1492-1496) on the MFMA path: `d` describes the
+// convolution with its weight zero-padded to Cout = 32 (packed by the caller), y_nchw is [B][cout_store][Ho][Wo] float32 and
+// receives channels 0 .. cout_store-1 of act(conv(x) + bias) + res32 (res32: float32 [B][cout_store][Ho][Wo] or NULL).
+extern "C" int masic_conv_f16k_few_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* res32, float* y_nchw,
+                                       int cout_store, const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(d != nullptr && y_nchw != nullptr && cout_store > 0 && cout_store <= d->Cout && d->Cout == 32 && d->out_coff == 0, MASIC_ERR_ARG,
+                  "conv_f16k_few_fwd: needs a 32-channel (zero-padded) descriptor and 0 < cout_store <= 32");
+    return f16k_launch(x_f16k, w_packed, bias, nullptr, nullptr, 0, 0, y_nchw, nullptr, d, stream, nullptr, nullptr, 0.0f, nullptr, nullptr, 0, res32, cout_store);
 }
 
 // F16K in, F16K out (a channel view per d->out_ctot / out_coff) with up to two F16K residual tensors of res_ctot channels added
@@ -1085,7 +1110,7 @@ namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale,
-                const void* res1, const void* res2, int res_ctot) {
+                const void* res1, const void* res2, int res_ctot, const float* res32, int cout_store) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     const bool f8 = d->prec == MASIC_PREC_FP8;
@@ -1108,8 +1133,8 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
-               d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : d->out_ctot, d2s ? (d2s >> 20) : d->out_coff,
+               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
+               d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : (cout_store > 0 ? cout_store : d->out_ctot), d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
                c.PH, c.PW, c.PWh, c.NPIXp, c.PB,

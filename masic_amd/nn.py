@@ -248,6 +248,29 @@ class _PackedWeightMixin:
         return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc, y16=out16,
                                    res1=res1, res2=res2, res_ctot=res_ctot)
 
+    def few_supported(self, B, Hi, Wi):
+        kh, kw, s_, p_ = self._geometry()
+        return (not self.transposed_conv and self.out_channels <= 32 and self.in_channels % 16 == 0
+                and ops.conv_f16k_supported(ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, kh, kw, s_, p_, prec=PREC_BF16)))
+
+    def run_f16k_few(self, x16, B, Hi, Wi, res32=None):
+        """Inference-only, Conv2d to <= 32 channels on an F16K input -> float32 NCHW (+ float32 residual): the weight is zero-padded
+        to 32 output channels for the MFMA tile and only the real channels are stored (masic_conv_f16k_few_fwd)."""
+        kh, kw, s_, p_ = self._geometry()
+        desc = ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, kh, kw, s_, p_, prec=PREC_BF16)
+        w = self.weight
+        vkey = (w._version, w.data_ptr(), str(w.device), None if self.bias is None else self.bias._version)
+
+        def build():
+            wpad = torch.zeros((32,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+            wpad[:self.out_channels] = w.detach()
+            bpad = torch.zeros(32, dtype=torch.float32, device=w.device)
+            if self.bias is not None:
+                bpad[:self.out_channels] = self.bias.detach()
+            return ops.pack_conv_f16k_weight(wpad, desc), bpad
+        wp, bp = _cached(self, "_packed_few_cache", vkey, (B, Hi, Wi), build)
+        return ops.conv2d_f16k_few(x16, wp, bp, desc, self.out_channels, res32=res32)
+
     def packed_gemm_dma_weight(self):
         """Per-128-channel-block k16-major pack of a 1x1 layer for the DMA-staged GEMM (conv_f16k.hip: gemm_f16k)."""
         w = self.weight

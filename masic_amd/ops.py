@@ -913,3 +913,16 @@ def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res
         flops, nbytes = conv_algorithmic_work(desc)
         _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
     return y16
+
+
+def conv2d_f16k_few(x16, packed, bias32, desc, C, res32=None):
+    """Convolution to C <= 32 channels (desc: the zero-padded 32-channel form) on an F16K input -> float32 NCHW [B, C, Ho, Wo] (+ res32)."""
+    if x16.dtype != torch.int16 or x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
+        raise RuntimeError("masic_amd.conv2d_f16k_few: input buffer does not match the descriptor")
+    y = torch.empty((desc.B, C, desc.Ho, desc.Wo), dtype=torch.float32, device=x16.device)
+    if res32 is not None:
+        _dev(res32, "residual")
+        if tuple(res32.shape) != tuple(y.shape):
+            raise RuntimeError("masic_amd.conv2d_f16k_few: residual shape mismatch")
+    check(lib.masic_conv_f16k_few_fwd(_p(x16), _p(packed), _p(bias32), _p(res32), _p(y), int(C), ctypes.byref(desc), _stream()), "conv_f16k_few_fwd")
+    return y
