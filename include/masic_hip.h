@@ -128,7 +128,10 @@ int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* b
                         float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream);
 /* The same with the (inverse) GDN that follows the 128-channel convolutions of the analysis / synthesis transforms
  * (MASIC.py:521-531, :544-554; compressai/layers/gdn.py:77-92) fused into the epilogue: y = GDN(conv(x) + bias).
- * gdn_packed: masic_gdn_pack_f16k of that GDN's stored beta/gamma (masic_gdn_f16k_packed_bytes bytes). */
+ * gdn_packed: masic_gdn_pack_f16k of that GDN's stored beta/gamma (masic_gdn_f16k_packed_bytes bytes).
+ * gdn_inverse (here and in masic_conv_f8k_fwd / masic_conv_a_gdn_fwd*): bit 0 = inverse GDN; bit 1 = contract gamma^ x x^2 as the
+ * three-product bf16 hi/lo split (~2^-16 of the result) instead of ONE bf16 product (~2^-10: the order of the bf16 rounding the
+ * result gets when it is stored for the next bf16-operand layer; a third of the epilogue's MFMAs). */
 size_t masic_gdn_f16k_packed_bytes(void);
 int masic_gdn_pack_f16k(const float* beta, const float* gamma, void* packed, int C, double beta_min, void* stream);
 int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,

@@ -291,6 +291,9 @@ __device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t r, unsigned cha
 // 8 accumulator registers acc[s>>1][8(s&1) + c] the lane already holds for its pixel, so the B operand needs no data
 // movement; the gamma^ fragments lie in LDS pre-arranged in that order (gdn.hip: gdn_pack_f16k_kernel).
 // gimg: LDS address of the fragment image + lane * 16;  bet: LDS address of beta^[128] + 4h (read late: no registers held).
+// X3 = false: one product (bf16 gamma^ x bf16 x^2, error ~2^-10 of the result -- the order of the bf16 rounding the result gets
+// anyway when it is stored as F16K / fed to a bf16-operand layer): a third of the MFMAs, half the fragment reads, no lo split.
+template <bool X3>
 __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigned char* gimg, const float* bet, int inverse) {
     f32x16 nrm[4];
 #pragma unroll
@@ -306,14 +309,16 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
             const float sq = __fmul_rn(xv, xv);
             const __bf16 hi = (__bf16)sq;
             bh[cc] = hi;
-            blo[cc] = (__bf16)(sq - (float)hi);
+            if constexpr (X3) blo[cc] = (__bf16)(sq - (float)hi);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const bf16x8 gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 0) * 1024));
-            const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 1) * 1024));
-            nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, bh, nrm[m], 0, 0, 0);
-            nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, blo, nrm[m], 0, 0, 0);
+            if constexpr (X3) {
+                const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gimg + ((m * 8 + sx) * 2 + 1) * 1024));
+                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, bh, nrm[m], 0, 0, 0);
+                nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, blo, nrm[m], 0, 0, 0);
+            }
             nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, bh, nrm[m], 0, 0, 0);
         }
     }
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             }
         }
     }
-    if constexpr (GDN) {
+    if constexpr (GDN && F16K_ABLATE != 10) {
         // The 64 KiB fragment image (+ beta^) is shared by the 8 waves through LDS (ring and patch buffers are free now): one
         // DMA, one barrier.
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
@@ -657,7 +662,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
         const size_t opix = (size_t)oh * a.Wo + ow;
         if constexpr (GDN) {
-            gdn_in_registers(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse);
+            if (F16K_ABLATE != 9 && F16K_ABLATE != 10) {
+                if (a.gdn_inverse & 2) gdn_in_registers<true>(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse & 1);
+                else gdn_in_registers<false>(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse & 1);
+            }
         } else {
             float gv = 1.0f;
             if (a.y32 != nullptr && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
@@ -866,7 +874,8 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 const float4 bv = *reinterpret_cast<const float4*>(vec + m * 32 + 8 * q + 4 * h);
                 acc[m][4 * q] += bv.x; acc[m][4 * q + 1] += bv.y; acc[m][4 * q + 2] += bv.z; acc[m][4 * q + 3] += bv.w;
             }
-        gdn_in_registers(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse);
+        if (a.gdn_inverse & 2) gdn_in_registers<true>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
+        else gdn_in_registers<false>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
         {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;

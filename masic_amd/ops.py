@@ -14,6 +14,24 @@ from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SOFTMAX_C, INOP_ABS, INOP_
 LIK_BOUND = 1e-9
 SCALE_BOUND = 0.11
 
+import os as _os
+
+# GDN fused into the epilogue of a bf16-operand convolution: 1 = one bf16 product gamma^ x x^2 (error ~2^-10 of the result, the order
+# of the bf16 rounding the result gets when it is stored; the default), 3 = the bf16 hi/lo split product (~2^-16).
+_FUSED_GDN_PRODUCTS = 3 if _os.environ.get("MASIC_GDN_X3", "0") == "1" else 1
+
+
+def set_fused_gdn_products(n):
+    global _FUSED_GDN_PRODUCTS
+    if n not in (1, 3):
+        raise ValueError("fused GDN: 1 or 3 bf16 products")
+    _FUSED_GDN_PRODUCTS = n
+
+
+def _gdn_flags(inverse):
+    """the gdn_inverse argument of the fused kernels: bit 0 = inverse GDN, bit 1 = three-product contraction"""
+    return int(bool(inverse)) | (2 if _FUSED_GDN_PRODUCTS == 3 else 0)
+
 
 def _dev(t, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -613,7 +631,7 @@ def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=No
         if _timer.only is None or variant == _timer.only:
             timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             timed[1].record()
-    gp, ginv = (None, 0) if gdn is None else (gdn[0], int(gdn[1]))       # gdn = (pack_gdn_f16k(...), inverse)
+    gp, ginv = (None, 0) if gdn is None else (gdn[0], _gdn_flags(gdn[1]))       # gdn = (pack_gdn_f16k(...), inverse)
     check(lib.masic_conv_f16k_gdn_fwd(_p(x16), _p(packed), _p(bias), _p(gate), _p(gp), ginv, _p(y32), _p(y16), ctypes.byref(desc), _stream()),
           "conv_f16k_fwd")
     if timed is not None:
@@ -638,7 +656,7 @@ def conv_a_gdn_f16k(x, packed, bias, gdn, in_coff=0):
     B, ctot, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
-    check(lib.masic_conv_a_gdn_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), int(gdn[1]), _p(y), B, H, W, ctot, in_coff, _stream()), "conv_a_gdn_fwd")
+    check(lib.masic_conv_a_gdn_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), _gdn_flags(gdn[1]), _p(y), B, H, W, ctot, in_coff, _stream()), "conv_a_gdn_fwd")
     return y, Ho, Wo
 
 
@@ -783,7 +801,7 @@ def conv2d_f8k(x, packed, wscale, bias, desc, out="f16k", out_scale=None, out_nc
         inv = 1.0 / float(out_scale)
     else:
         y16 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.int16, device=x.device)
-    gp, ginv = (None, 0) if gdn is None else (gdn[0], int(gdn[1]))
+    gp, ginv = (None, 0) if gdn is None else (gdn[0], _gdn_flags(gdn[1]))
     timed = None
     if _timer is not None:
         buf = ctypes.create_string_buffer(96)
@@ -807,7 +825,7 @@ def conv_a_gdn_f8k(x, packed, bias, gdn, out_scale, in_coff=0):
     B, ctot, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B * 128 * Ho * Wo, dtype=torch.uint8, device=x.device)
-    check(lib.masic_conv_a_gdn_fwd_ex(_p(x), _p(packed), _p(bias), _p(gdn[0]), int(gdn[1]), None, _p(y), 1.0 / float(out_scale), B, H, W, ctot, in_coff,
+    check(lib.masic_conv_a_gdn_fwd_ex(_p(x), _p(packed), _p(bias), _p(gdn[0]), _gdn_flags(gdn[1]), None, _p(y), 1.0 / float(out_scale), B, H, W, ctot, in_coff,
                                       _stream()), "conv_a_gdn_fwd_ex")
     return y, Ho, Wo
 

@@ -87,6 +87,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "hyper":
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":      # timing only (results of ablated builds are garbage)
     run("B  conv5s2 128->128 256^2", 8, 128, 256, 256, 128, 5, 2, reps=10)
     run("B' deconv 128->128 128^2", 8, 128, 128, 128, 128, 5, 2, transposed=True, reps=10)
+    run_gdn("B  conv+gdn 256^2", 8, 128, 256, 256, 5, 2, reps=10)
+    run_gdn("C  conv+gdn 128^2", 8, 128, 128, 128, 5, 2, reps=10)
+    run_gdn("B' deconv+igdn 128^2", 8, 128, 128, 128, 5, 2, transposed=True, inverse=True, reps=10)
     sys.exit(0)
 run("conv5s2 128->128 64x64", 2, 128, 64, 64, 128, 5, 2)
 run("conv5s2 128->192 40x24", 1, 128, 40, 24, 192, 5, 2, act=ops.ACT_RELU)
