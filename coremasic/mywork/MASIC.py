@@ -429,6 +429,13 @@ class Encoder1(nn.Module):
                 return y
         return self.forward(x)[0]
 
+    def latent_train(self, x):
+        """forward(x)[0] inside the training graph: in the bf16-operand mode ONE node that runs the DMA-staged inference kernels and
+        keeps bf16 activations for its backward (masic_amd/autograd.py: AnalysisFn); otherwise the per-layer nodes."""
+        if _ag.analysis_supported(self, x):
+            return _ag.analysis(self, x)
+        return self.forward(x)[0]
+
 
 class Decoder1(nn.Module):
     """Left synthesis transform (reference :533-554)."""
@@ -455,6 +462,11 @@ class Decoder1(nn.Module):
             x_hat = _synthesis_f16k(self, y_hat)
             if x_hat is not None:
                 return x_hat
+        return self.forward(y_hat)[0]
+
+    def reconstruct_train(self, y_hat):
+        if _ag.synthesis_supported(self, y_hat):
+            return _ag.synthesis(self, y_hat)
         return self.forward(y_hat)[0]
 
 
@@ -492,6 +504,8 @@ class Encoder2(nn.Module):
                                (self.g_a_gdn1, self.g_a_gdn2, self.g_a_gdn3), t)
             if y is not None:
                 return y
+        if torch.is_grad_enabled() and _ag.analysis_supported(self, t):
+            return _ag.analysis(self, t)
         t = self.g_a_gdn1(self.g_a_conv1(t))
         t = self.g_a_gdn2(self.g_a_conv2(t))
         t = self.g_a_gdn3(self.g_a_conv3(t))
@@ -515,6 +529,8 @@ class Decoder2(nn.Module):
 
     def forward(self, y_hat, x1_hat_warp):
         t = _synthesis_f16k(self, y_hat) if _bf16_inference(y_hat, self.g_s_conv1.weight) else None
+        if t is None and torch.is_grad_enabled() and _ag.synthesis_supported(self, y_hat):
+            t = _ag.synthesis(self, y_hat)
         if t is None:
             t = self.g_s_gdn1(self.g_s_conv1(y_hat))
             t = self.g_s_gdn2(self.g_s_conv2(t))
@@ -609,14 +625,14 @@ class HSIC(CompressionModel):
         x2 = x2.contiguous()
         B, _, H, W = x1.shape
         m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
-        y1 = self.encoder1(x1)[0]
+        y1 = self.encoder1.latent_train(x1)
         z1 = self._h_a1(y1)
         z1_hat, z1_lik = self.entropy_bottleneck1(z1)                                   # draw 1
         params1 = self._hyper_up(self.h_s1_up, z1_hat, None, 0)
         ctx1 = self.context_prediction1.run(self.gaussian1._quantize(y1, "noise"))     # draw 2
         s1, m1, l1 = self._h_s1_same_resolution.heads(_ag.cat(params1, ctx1))
         y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)       # draw 3
-        x1_hat = self.decoder1(y1_hat)[0]
+        x1_hat = self.decoder1.reconstruct_train(y1_hat)
 
         x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
         y2 = self.encoder2(x1_warp, x2)
@@ -628,7 +644,7 @@ class HSIC(CompressionModel):
         x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
         gates = self.mask2weights_unit(x1_mask_R)
         x1_hat_warp = _ag.WarpFn.apply(x1_hat, m_fwd, (H, W))
-        y1_warp = self.encoder1(x1_hat_warp)[0]
+        y1_warp = self.encoder1.latent_train(x1_hat_warp)
         y1_warp_hat = self.gaussian1._quantize(y1_warp, "noise")                        # draw 6
         cat2 = _ag.cat(_ag.GateFn.apply(params2, gates, 0), _ag.GateFn.apply(ctx2, gates, 1),
                        _ag.GateFn.apply(y1_warp_hat, gates, 2))

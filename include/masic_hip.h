@@ -185,6 +185,13 @@ int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const float* wsc
 int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                             void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
 
+/* training-mode forms of the two fused conv + GDN entry points: F16K output plus the convolution's result BEFORE the GDN
+ * (y_pre_f16k, same layout) -- the GDN backward needs its input, the next layer's weight gradient its output
+ * (masic_amd/autograd.py: AnalysisFn / SynthesisFn run the inference kernels in the training step and keep bf16 activations) */
+int masic_conv_f16k_gdn_dual_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                 void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream);
+int masic_conv_a_gdn_dual_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                              void* y_pre_f16k, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
 /* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
  * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */

@@ -41,34 +41,39 @@ class ConvFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
-        mod = ctx.mod
-        g = _c(g)
-        if ctx.act != ops.ACT_NONE:
-            g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=ctx.act)
-        kh, kw, s, p = mod._geometry()
-        B, Cin, Hi, Wi = x.shape
-        Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
-        gx = gw = gb = None
-        from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
-        if ctx.needs_input_grad[0]:
-            d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
-            if (d.Ho, d.Wo) != (Hi, Wi):
-                raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
-            gx = None
-            if _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
-                # bf16 mode: the DMA-staged F16K kernel of the inference path (conv_f16k.hip) -- g converted once to the channel-blocked
-                # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
-                d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)
-                if ops.conv_f16k_supported(d16):
-                    gx = ops.conv2d_f16k(ops.nchw_to_f16k(g), ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
-            if gx is None:
-                gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
-        if ctx.needs_input_grad[1]:
-            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
-            gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = ops.channel_sum(g)
+        gx, gw, gb = conv_backward(ctx.mod, x, weight, y, g, ctx.act, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                   ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None, None
+
+
+def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True):
+    """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW."""
+    g = _c(g)
+    if act != ops.ACT_NONE:
+        g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=act)
+    kh, kw, s, p = mod._geometry()
+    B, Cin, Hi, Wi = x.shape
+    Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
+    gx = gw = gb = None
+    from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
+    if need_gx:
+        d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
+        if (d.Ho, d.Wo) != (Hi, Wi):
+            raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
+        if _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
+            # bf16 mode: the DMA-staged F16K kernel of the inference path (conv_f16k.hip) -- g converted once to the channel-blocked
+            # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
+            d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)
+            if ops.conv_f16k_supported(d16):
+                gx = ops.conv2d_f16k(ops.nchw_to_f16k(g), ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
+        if gx is None:
+            gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
+    if need_gw:
+        d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
+        gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
+    if need_gb:
+        gb = ops.channel_sum(g)
+    return gx, gw, gb
 
 
 def conv(mod, x, act=ops.ACT_NONE):
@@ -93,30 +98,35 @@ class GdnFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, beta, gamma = ctx.saved_tensors
-        g = _c(g)
-        B, C, H, W = x.shape
-        from . import nn as _mnn
-        if C == 128 and _mnn._PRECISION != PREC_F32:       # bf16-operand mode: the whole backward in one kernel
-            return ops.gdn_bwd_fused(x, g, beta.detach(), gamma.detach(), ctx.inverse, ctx.beta_min) + (None, None)
-        b_bound = float(torch.tensor((ctx.beta_min + PEDESTAL) ** 0.5, dtype=torch.float32))
-        g_bound = float(torch.tensor(PEDESTAL ** 0.5, dtype=torch.float32))
-        ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))
-        gam = ops.elementwise(ops.EW_REPARAM, gamma.detach().contiguous(), None, g_bound, ped)
-        bet = ops.elementwise(ops.EW_REPARAM, beta.detach().contiguous(), None, b_bound, ped)
-        x2 = ops.elementwise(ops.EW_SQUARE, x)
-        d_f = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0)
-        w4 = gam.view(C, C, 1, 1)
-        nrm = ops.conv2d(x2, ops.pack_conv_weight(w4, d_f), bet, d_f)
-        s, t = ops.gdn_bwd_pre(x, nrm, g, ctx.inverse)
-        d_t = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, transposed=True)
-        u = ops.conv2d(t, ops.pack_conv_weight(w4, d_t), None, d_t)
-        gx = ops.gdn_bwd_post(x, s, u) if ctx.needs_input_grad[0] else None
-        d_w = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, prec=_mnn._PRECISION)
-        g_gam = ops.conv2d_wgrad(x2, t, d_w, (C, C, 1, 1)).view(C, C)
-        g_bet = ops.channel_sum(t)
-        g_gamma = ops.elementwise(ops.EW_REPARAM_BWD, g_gam, gamma.detach().contiguous(), g_bound)
-        g_beta = ops.elementwise(ops.EW_REPARAM_BWD, g_bet, beta.detach().contiguous(), b_bound)
-        return gx, g_beta, g_gamma, None, None
+        return gdn_backward(x, g, beta, gamma, ctx.inverse, ctx.beta_min, ctx.needs_input_grad[0]) + (None, None)
+
+
+def gdn_backward(x, g, beta, gamma, inverse, beta_min, need_gx=True):
+    """(dx, d beta, d gamma) of the (inverse) GDN; x, g float32 NCHW."""
+    g = _c(g)
+    B, C, H, W = x.shape
+    from . import nn as _mnn
+    if C == 128 and _mnn._PRECISION != PREC_F32:       # bf16-operand mode: the whole backward in one kernel
+        return ops.gdn_bwd_fused(x, g, beta.detach(), gamma.detach(), inverse, beta_min)
+    b_bound = float(torch.tensor((beta_min + PEDESTAL) ** 0.5, dtype=torch.float32))
+    g_bound = float(torch.tensor(PEDESTAL ** 0.5, dtype=torch.float32))
+    ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))
+    gam = ops.elementwise(ops.EW_REPARAM, gamma.detach().contiguous(), None, g_bound, ped)
+    bet = ops.elementwise(ops.EW_REPARAM, beta.detach().contiguous(), None, b_bound, ped)
+    x2 = ops.elementwise(ops.EW_SQUARE, x)
+    d_f = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0)
+    w4 = gam.view(C, C, 1, 1)
+    nrm = ops.conv2d(x2, ops.pack_conv_weight(w4, d_f), bet, d_f)
+    s, t = ops.gdn_bwd_pre(x, nrm, g, inverse)
+    d_t = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, transposed=True)
+    u = ops.conv2d(t, ops.pack_conv_weight(w4, d_t), None, d_t)
+    gx = ops.gdn_bwd_post(x, s, u) if need_gx else None
+    d_w = ops.make_conv_desc(B, C, H, W, C, 1, 1, 1, 0, prec=_mnn._PRECISION)
+    g_gam = ops.conv2d_wgrad(x2, t, d_w, (C, C, 1, 1)).view(C, C)
+    g_bet = ops.channel_sum(t)
+    g_gamma = ops.elementwise(ops.EW_REPARAM_BWD, g_gam, gamma.detach().contiguous(), g_bound)
+    g_beta = ops.elementwise(ops.EW_REPARAM_BWD, g_bet, beta.detach().contiguous(), b_bound)
+    return gx, g_beta, g_gamma
 
 
 class EntropyBottleneckFn(Function):
@@ -325,3 +335,136 @@ class RateDistortionFn(Function):
         g2 = ops.elementwise(ops.EW_DIFF_SCALE, x2_hat, x2, s0=gs * ctx.cm * 2.0 / x2.numel())
         gl = [ops.elementwise(ops.EW_RECIP_SCALE, l, None, s0=gs * ctx.cb) for l in liks]
         return (None, None, None, g1, g2, *gl)
+
+
+# ------------------------------------------------------------------------------------------ fused transforms (bf16-operand training)
+# In the bf16-operand mode the training step runs the SAME DMA-staged kernels as inference for the analysis / synthesis transforms
+# (conv_f16k.hip: both operands by DMA, (I)GDN in the epilogue) instead of one NCHW float32 launch per convolution and per GDN: the
+# kernels store, per layer, the convolution's result before the GDN and the GDN's result, both F16K bf16 -- half the bytes of the
+# float32 activations the per-layer nodes keep -- and the backward converts each to float32 NCHW right before the kernel that
+# needs it (weight gradient: the layer's input; GDN backward: the GDN's input).  Gradients are those of the same function evaluated
+# on bf16-rounded activations; the float32 mode keeps the per-layer nodes (the parity path).
+class AnalysisFn(Function):
+    """conv(3->128)+GDN, conv+GDN, conv+GDN, conv(128->M) of Encoder1 / Encoder2 (reference MASIC.py:510-531): x float32 NCHW -> y float32 NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, enc, *params):
+        from . import nn as _mnn
+        x = _c(x)
+        convs = (enc.g_a_conv1, enc.g_a_conv2, enc.g_a_conv3, enc.g_a_conv4)
+        gdns = (enc.g_a_gdn1, enc.g_a_gdn2, enc.g_a_gdn3)
+        B, _, H, W = x.shape
+        c1 = convs[0]
+        u1, a1, h1, w1 = ops.conv_a_gdn_dual(x, c1.packed_first_layer_weight(), None if c1.bias is None else c1.bias.detach(),
+                                             (_mnn.packed_gdn_f16k(gdns[0]), gdns[0].inverse))
+        u2, a2, h2, w2 = convs[1].run_f16k_dual(a1, B, h1, w1, gdns[1])
+        u3, a3, h3, w3 = convs[2].run_f16k_dual(a2, B, h2, w2, gdns[2])
+        y = convs[3].run_f16k(a3, B, h3, w3, want_nchw=True)[0]
+        ctx.enc, ctx.sizes = enc, ((h1, w1), (h2, w2), (h3, w3))
+        ctx.save_for_backward(x, u1, a1, u2, a2, u3, a3, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, u1, a1, u2, a2, u3, a3, *params = ctx.saved_tensors
+        enc = ctx.enc
+        convs = (enc.g_a_conv1, enc.g_a_conv2, enc.g_a_conv3, enc.g_a_conv4)
+        gdns = (enc.g_a_gdn1, enc.g_a_gdn2, enc.g_a_gdn3)
+        B = x.shape[0]
+        nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
+        grads = {}
+        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE)
+        for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
+            gu, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = gdn_backward(nchw(u, hw), gx, gdns[i].beta, gdns[i].gamma, gdns[i].inverse, gdns[i].beta_min)
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE)
+        gu, grads["beta1"], grads["gamma1"] = gdn_backward(nchw(u1, ctx.sizes[0]), gx, gdns[0].beta, gdns[0].gamma, gdns[0].inverse, gdns[0].beta_min)
+        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0])
+        return (gimg, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
+                grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
+
+
+def analysis(enc, x):
+    c, g = (enc.g_a_conv1, enc.g_a_conv2, enc.g_a_conv3, enc.g_a_conv4), (enc.g_a_gdn1, enc.g_a_gdn2, enc.g_a_gdn3)
+    return AnalysisFn.apply(x, enc, c[0].weight, c[0].bias, g[0].beta, g[0].gamma, c[1].weight, c[1].bias, g[1].beta, g[1].gamma,
+                            c[2].weight, c[2].bias, g[2].beta, g[2].gamma, c[3].weight, c[3].bias)
+
+
+def analysis_supported(enc, x):
+    """bf16-operand mode, the reference's layer shapes, every layer with an F16K configuration at this size."""
+    from . import nn as _mnn
+    if _mnn._PRECISION == PREC_F32 or _mnn._FP8:
+        return False
+    B, C, H, W = x.shape
+    c = (enc.g_a_conv1, enc.g_a_conv2, enc.g_a_conv3, enc.g_a_conv4)
+    if (C, c[0].out_channels, tuple(c[0].kernel_size), tuple(c[0].stride), tuple(c[0].padding)) != (3, 128, (5, 5), (2, 2), (2, 2)):
+        return False
+    if c[1].out_channels != 128 or c[2].out_channels != 128 or any(m.bias is None for m in c):
+        return False
+    h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    for m in c[1:]:
+        if not m.f16k_supported(B, h, w):
+            return False
+        d = m._desc_f16k(B, h, w)
+        h, w = d.Ho, d.Wo
+    return True
+
+
+class SynthesisFn(Function):
+    """deconv+IGDN x3, deconv(128->3) of Decoder1 / Decoder2 (reference MASIC.py:533-554): y_hat float32 NCHW -> float32 NCHW."""
+
+    @staticmethod
+    def forward(ctx, y_hat, dec, *params):
+        y_hat = _c(y_hat)
+        convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3, dec.g_s_conv4)
+        gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
+        B, _, H, W = y_hat.shape
+        t16 = ops.nchw_to_f16k(y_hat)
+        saved, sizes, hw = [], [], (H, W)
+        for i in range(3):
+            u, t16, ho, wo = convs[i].run_f16k_dual(t16, B, hw[0], hw[1], gdns[i])
+            hw = (ho, wo)
+            saved += [u, t16]
+            sizes.append(hw)
+        x_hat = convs[3].run_f16k_d2s(t16, B, hw[0], hw[1])
+        ctx.dec, ctx.sizes = dec, sizes
+        ctx.save_for_backward(y_hat, *saved, *params)
+        return x_hat
+
+    @staticmethod
+    def backward(ctx, g):
+        y_hat, u1, a1, u2, a2, u3, a3, *params = ctx.saved_tensors
+        dec = ctx.dec
+        convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3, dec.g_s_conv4)
+        gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
+        B = y_hat.shape[0]
+        nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
+        grads = {}
+        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE)
+        for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
+            gu, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = gdn_backward(nchw(u, hw), gx, gdns[i].beta, gdns[i].gamma, gdns[i].inverse, gdns[i].beta_min)
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE)
+        gu, grads["beta1"], grads["gamma1"] = gdn_backward(nchw(u1, ctx.sizes[0]), gx, gdns[0].beta, gdns[0].gamma, gdns[0].inverse, gdns[0].beta_min)
+        gy, grads["w1"], grads["b1"] = conv_backward(convs[0], y_hat, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0])
+        return (gy, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
+                grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
+
+
+def synthesis(dec, y_hat):
+    c, g = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3, dec.g_s_conv4), (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
+    return SynthesisFn.apply(y_hat, dec, c[0].weight, c[0].bias, g[0].beta, g[0].gamma, c[1].weight, c[1].bias, g[1].beta, g[1].gamma,
+                             c[2].weight, c[2].bias, g[2].beta, g[2].gamma, c[3].weight, c[3].bias)
+
+
+def synthesis_supported(dec, y_hat):
+    from . import nn as _mnn
+    if _mnn._PRECISION == PREC_F32 or _mnn._FP8:
+        return False
+    B, _, H, W = y_hat.shape
+    c = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3)
+    hw = (H, W)
+    for m in c:
+        if m.out_channels != 128 or m.bias is None or not m.f16k_supported(B, *hw):
+            return False
+        d = m._desc_f16k(B, *hw)
+        hw = (d.Ho, d.Wo)
+    return dec.g_s_conv4.bias is not None and dec.g_s_conv4.d2s_supported(B, *hw)

@@ -167,6 +167,8 @@ struct F16kArgs {
     const unsigned short* res1;   // F16K output only: up to two residual tensors [B][res_ctot/16][Ho*Wo][16] added after the activation
     const unsigned short* res2;   //   (ResidualBlock / Enhancement_Block identities, compressai/layers/layers.py:189, MASIC.py:163)
     int res_ctot;
+    unsigned short* y16_pre;      // fused GDN + F16K output: also store the convolution's result BEFORE the GDN (same view), or null --
+                                  //   what the GDN backward of a training step needs (masic_amd/autograd.py: AnalysisFn / SynthesisFn)
     const float* res32;           // float32 NCHW output only: residual [B][cout_store][Ho][Wo] added after the activation, or null
     int cout_store;               // float32 NCHW output: channels actually stored (< Cout when the weight was zero-padded to a multiple of 32)
     const float* wscale;          // fp8 operands: per-output-channel dequantisation factor (weight scale x input scale), else null
@@ -662,6 +664,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
         const size_t opix = (size_t)oh * a.Wo + ow;
         if constexpr (GDN) {
+            if (a.y16_pre != nullptr && pok) {
+                const int c16 = (a.out_coff + m0) >> 4;
+                unsigned short* yp = a.y16_pre + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
+                const unsigned op16 = (unsigned)oplane * 16;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) store_f16k_tile(acc[n][m], yp + (size_t)(2 * m) * op16, op16);
+            }
             if (F16K_ABLATE != 9 && F16K_ABLATE != 10) {
                 if (a.gdn_inverse & 2) gdn_in_registers<true>(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse & 1);
                 else gdn_in_registers<false>(acc[n], lds + lane * 16, reinterpret_cast<const float*>(lds + 65536) + 4 * h, a.gdn_inverse & 1);
@@ -758,6 +767,7 @@ struct ConvAArgs {
     int gdn_inverse, Hi, Wi, in_ctot, in_coff, Ho, Wo, tiles_w, tiles_per_img, ntiles;
     unsigned char* y8;            // instead of y16: F8K [B][4][Ho*Wo][32] fp8, quantised with out_inv_scale
     float out_inv_scale;
+    unsigned short* y16_pre;      // also store conv + bias before the GDN (F16K), or null
 };
 
 constexpr int CA_PH = 19, CA_PW = 67, CA_PITCH = 68, CA_NEL = 3 * CA_PH * CA_PW;     // patch of an 8 x 32 tile, stride 2, 5 x 5
@@ -874,6 +884,16 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 const float4 bv = *reinterpret_cast<const float4*>(vec + m * 32 + 8 * q + 4 * h);
                 acc[m][4 * q] += bv.x; acc[m][4 * q + 1] += bv.y; acc[m][4 * q + 2] += bv.z; acc[m][4 * q + 3] += bv.w;
             }
+        if (a.y16_pre != nullptr) {
+            const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
+            const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
+            if (oh < a.Ho && ow < a.Wo) {
+                unsigned short* yp = a.y16_pre + (((size_t)b * 8) * oplane + (size_t)oh * a.Wo + ow) * 16 + 8 * h;
+                const unsigned op16 = (unsigned)oplane * 16;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yp + (size_t)(2 * m) * op16, op16);
+            }
+        }
         if (a.gdn_inverse & 2) gdn_in_registers<true>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
         else gdn_in_registers<false>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
         {
@@ -1031,7 +1051,18 @@ namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f,
-                const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0, const float* res32 = nullptr, int cout_store = 0);
+                const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0, const float* res32 = nullptr, int cout_store = 0,
+                void* y_pre = nullptr);
+}
+
+// masic_conv_f16k_gdn_fwd with F16K output that ALSO stores the convolution's result before the GDN (y_pre_f16k, same layout as
+// y_f16k): the training-mode forward keeps both for the backward pass (GDN backward needs its input, the next layer's weight
+// gradient its output).
+extern "C" int masic_conv_f16k_gdn_dual_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                            void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(gdn_packed && y_pre_f16k && y_f16k, MASIC_ERR_ARG, "conv_f16k_gdn_dual_fwd: null pointer");
+    return f16k_launch(x_f16k, w_packed, bias, nullptr, gdn_packed, gdn_inverse, 0, nullptr, y_f16k, d, stream, nullptr, nullptr, 0.0f, nullptr, nullptr, 0,
+                       nullptr, 0, y_pre_f16k);
 }
 
 // A layer with few output channels (conv2 of Independent_EN: 96 -> 3, MASIC.py:1492-1496) on the MFMA path: `d` describes the
@@ -1119,7 +1150,7 @@ namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale,
-                const void* res1, const void* res2, int res_ctot, const float* res32, int cout_store) {
+                const void* res1, const void* res2, int res_ctot, const float* res32, int cout_store, void* y_pre) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     const bool f8 = d->prec == MASIC_PREC_FP8;
@@ -1142,7 +1173,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
+               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, (unsigned short*)y_pre, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : (cout_store > 0 ? cout_store : d->out_ctot), d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
@@ -1221,6 +1252,14 @@ extern "C" int masic_conv_a_pack_weight(const float* w, void* w_packed, void* st
 }
 extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                                        void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
+namespace { int conv_a_launch(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse, void* y_f16k, void* y_f8k,
+                              float out_inv_scale, void* y_pre, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream); }
+// training-mode form: F16K output plus the pre-GDN result (see masic_conv_f16k_gdn_dual_fwd)
+extern "C" int masic_conv_a_gdn_dual_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
+                                         void* y_pre_f16k, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
+    MASIC_REQUIRE(y_pre_f16k && y_f16k, MASIC_ERR_ARG, "conv_a_gdn_dual_fwd: null pointer");
+    return conv_a_launch(x, w_packed, bias, gdn_packed, gdn_inverse, y_f16k, nullptr, 0.0f, y_pre_f16k, B, Hi, Wi, in_ctot, in_coff, stream);
+}
 extern "C" int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                                     void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
     return masic_conv_a_gdn_fwd_ex(x, w_packed, bias, gdn_packed, gdn_inverse, y_f16k, nullptr, 0.0f, B, Hi, Wi, in_ctot, in_coff, stream);
@@ -1228,13 +1267,18 @@ extern "C" int masic_conv_a_gdn_fwd(const float* x, const void* w_packed, const 
 // the same with the result optionally written as F8K fp8 (y_f8k, quantised with out_inv_scale) for an fp8-operand second layer
 extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                                        void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
+    return conv_a_launch(x, w_packed, bias, gdn_packed, gdn_inverse, y_f16k, y_f8k, out_inv_scale, nullptr, B, Hi, Wi, in_ctot, in_coff, stream);
+}
+namespace {
+int conv_a_launch(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse, void* y_f16k, void* y_f8k,
+                  float out_inv_scale, void* y_pre, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
     MASIC_REQUIRE(x && w_packed && gdn_packed && ((y_f16k != nullptr) != (y_f8k != nullptr)), MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer / exactly one output");
     MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "conv_a_gdn_fwd: an fp8 output needs out_inv_scale > 0");
     MASIC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && in_coff >= 0 && in_coff + 3 <= in_ctot, MASIC_ERR_SHAPE, "conv_a_gdn_fwd: bad shape");
     const int Ho = (Hi + 4 - 5) / 2 + 1, Wo = (Wi + 4 - 5) / 2 + 1;
     const int tiles_w = ceil_div(Wo, 32), tiles_per_img = tiles_w * ceil_div(Ho, 8), ntiles = tiles_per_img * B;
     ConvAArgs a{x, (const uint4*)w_packed, bias, (const uint4*)gdn_packed, (unsigned short*)y_f16k, gdn_inverse, Hi, Wi, in_ctot, in_coff,
-                Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale};
+                Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale, (unsigned short*)y_pre};
     static bool attr_set = false;
     const size_t lds_bytes = 65536 + 20480 + 1024 + 2 * CA_PATCH_BYTES;
     if (!attr_set) {
@@ -1244,6 +1288,7 @@ extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, con
     hipLaunchKernelGGL(conv_a_gdn_f16k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, (hipStream_t)stream, a);
     return masic_launch_status("conv_a_gdn_fwd");
 }
+}  // namespace
 
 // ------------------------------------------------------------------------------------------ 1x1 layers as DMA-staged GEMMs
 // The nine 1x1 (transposed) convolutions of each GMM head (MASIC.py:330-468) with the K-loop machinery of conv_f16k: the

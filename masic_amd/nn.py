@@ -241,6 +241,13 @@ class _PackedWeightMixin:
                             gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
         return y, desc.Ho, desc.Wo
 
+    def run_f16k_dual(self, x16, B, Hi, Wi, gdn, products=3):
+        """Training-mode forward of conv + (I)GDN on F16K: returns (pre-GDN F16K, post-GDN F16K, Ho, Wo)."""
+        desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 15) // 16 * 16)
+        pre, y = ops.conv2d_f16k_gdn_dual(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc,
+                                          (packed_gdn_f16k(gdn), gdn.inverse), products=products)
+        return pre, y, desc.Ho, desc.Wo
+
     def run_f16k_res(self, x16, B, Hi, Wi, act=ops.ACT_NONE, res1=None, res2=None, res_ctot=0, out16=None, out_ctot=None, out_coff=0):
         """Inference-only: F16K -> F16K (optionally a channel view of `out16`) with F16K residual tensors added after the activation."""
         oc = (self.out_channels + 15) // 16 * 16 if out_ctot is None else out_ctot

@@ -28,9 +28,9 @@ def set_fused_gdn_products(n):
     _FUSED_GDN_PRODUCTS = n
 
 
-def _gdn_flags(inverse):
+def _gdn_flags(inverse, products=None):
     """the gdn_inverse argument of the fused kernels: bit 0 = inverse GDN, bit 1 = three-product contraction"""
-    return int(bool(inverse)) | (2 if _FUSED_GDN_PRODUCTS == 3 else 0)
+    return int(bool(inverse)) | (2 if (products or _FUSED_GDN_PRODUCTS) == 3 else 0)
 
 
 def _dev(t, name="tensor"):
@@ -944,3 +944,28 @@ def conv2d_f16k_few(x16, packed, bias32, desc, C, res32=None):
             raise RuntimeError("masic_amd.conv2d_f16k_few: residual shape mismatch")
     check(lib.masic_conv_f16k_few_fwd(_p(x16), _p(packed), _p(bias32), _p(res32), _p(y), int(C), ctypes.byref(desc), _stream()), "conv_f16k_few_fwd")
     return y
+
+
+# --------------------------------------------------------------------------------------------- training-mode fused forward (dual outputs)
+def conv2d_f16k_gdn_dual(x16, packed, bias, desc, gdn, products=3):
+    """F16K in -> (conv + bias before the GDN, GDN result), both F16K of desc.out_ctot channels.  gdn = (pack_gdn_f16k(..), inverse)."""
+    if x16.dtype != torch.int16 or x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
+        raise RuntimeError("masic_amd.conv2d_f16k_gdn_dual: input buffer does not match the descriptor")
+    n = desc.B * desc.out_ctot * desc.Ho * desc.Wo
+    pre = torch.empty(n, dtype=torch.int16, device=x16.device)
+    y = torch.empty(n, dtype=torch.int16, device=x16.device)
+    check(lib.masic_conv_f16k_gdn_dual_fwd(_p(x16), _p(packed), _p(bias), _p(gdn[0]), _gdn_flags(gdn[1], products), _p(pre), _p(y), ctypes.byref(desc), _stream()),
+          "conv_f16k_gdn_dual_fwd")
+    return pre, y
+
+
+def conv_a_gdn_dual(x, packed, bias, gdn, in_coff=0, products=3):
+    """First analysis layer + GDN -> (pre-GDN F16K, post-GDN F16K, Ho, Wo)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    pre = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
+    y = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
+    check(lib.masic_conv_a_gdn_dual_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), _gdn_flags(gdn[1], products), _p(pre), _p(y), B, H, W, ctot, in_coff, _stream()),
+          "conv_a_gdn_dual_fwd")
+    return pre, y, Ho, Wo
