@@ -24,6 +24,15 @@ def _c(t):
 _DGRAD_F16K = os.environ.get("MASIC_DGRAD_F16K", "1") != "0"      # 0: input gradients on the implicit-GEMM kernel only (A/B timing)
 
 
+def _gemm_1x1(mod, act=0):
+    from . import nn as _mnn
+    return (_GEMM_1X1 and _mnn._PRECISION != PREC_F32 and tuple(mod.kernel_size) == (1, 1) and tuple(mod.stride) == (1, 1) and tuple(mod.padding) == (0, 0)
+            and mod.in_channels % 32 == 0 and mod.out_channels % 32 == 0 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY))
+
+
+_GEMM_1X1 = os.environ.get("MASIC_TRAIN_GEMM_1X1", "1") != "0"      # 0: 1x1 layers of the training step on the implicit-GEMM kernel (A/B timing)
+
+
 class ConvFn(Function):
     """y = act(conv(x, W) + b) for the module's Conv2d / ConvTranspose2d / MaskedConv2d.
     dx: the forward kernel run as the opposite layer kind on the same weight tensor (a Conv2d's input gradient is a
@@ -32,7 +41,14 @@ class ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mod, act):
         x = _c(x)
-        y = mod.run(x, act=act)
+        if _gemm_1x1(mod, act):
+            # bf16-operand mode, 1x1 layers of the entropy-parameter stacks: the DMA-staged GEMM of the inference path (conv_f16k.hip:
+            # gemm_f16k, 4x the rate of the NCHW implicit-GEMM kernel at these shapes); x is converted once to F16K
+            B, _, H, W = x.shape
+            y = ops.gemm_f16k(ops.nchw_to_f16k(x), mod.packed_gemm_dma_weight(), None if bias is None else bias.detach(), B, mod.in_channels,
+                              mod.out_channels, H, W, act, want_nchw=True)
+        else:
+            y = mod.run(x, act=act)
         ctx.mod, ctx.act = mod, act
         ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
         ctx.has_bias = bias is not None
@@ -60,7 +76,11 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
         d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
         if (d.Ho, d.Wo) != (Hi, Wi):
             raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
-        if _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
+        if _gemm_1x1(mod):
+            # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
+            wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
+            gx = ops.gemm_f16k(ops.nchw_to_f16k(g), wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
+        elif _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
             # bf16 mode: the DMA-staged F16K kernel of the inference path (conv_f16k.hip) -- g converted once to the channel-blocked
             # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
             d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)

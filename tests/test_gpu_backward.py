@@ -75,7 +75,7 @@ def test_conv_backward(case):
     assert_close(mod.bias.grad, br.grad, name + ":db", GTOL)
 
 
-@pytest.mark.parametrize("case", [c for c in CONV_BWD_CASES if c[0] in ("conv5s2", "conv5s1", "conv3s1", "deconv5s2", "masked5", "conv1x1", "ragged", "deconv_to3")],
+@pytest.mark.parametrize("case", [c for c in CONV_BWD_CASES if c[0] in ("conv5s2", "conv5s1", "conv3s1", "deconv5s2", "masked5", "conv1x1", "deconv1x1", "ragged", "deconv_to3")],
                          ids=lambda c: c[0])
 def test_conv_backward_bf16_mode(case):
     """set_precision("bf16"): forward, input gradient and weight gradient with bf16 operands / float32 accumulation, against
