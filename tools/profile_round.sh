@@ -1,20 +1,23 @@
 #!/bin/bash
-# One GPU-box pass that produces everything tools/refresh_profiles.py turns into profiles/: the bench line, the rocprofv3
-# kernel trace of the same command (minus the CPU leg and the one-pair bitstream extra) and the two PMC passes.
-# usage (from the repo root, through gpurun): bash tools/profile_round.sh
-set -e -o pipefail
+# One GPU-box pass that produces everything tools/refresh_profiles.py turns into profiles/ (round tag as $1, default r02): the bench
+# line (with its own PMC child passes), the rocprofv3 kernel trace of the same command (minus the CPU leg and the one-pair bitstream
+# extra), one SQ-counter pass, and kernel traces of the training step / the CQE forward.
+# usage (from the repo root, through gpurun): bash tools/profile_round.sh r02
+set -o pipefail
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out"
-rm -rf "$R/gpurun_out/prof_r01" "$R/gpurun_out/pmc_fetch" "$R/gpurun_out/pmc_write"
+rm -rf "$R/gpurun_out/prof_$TAG" "$R/gpurun_out/pmc_sq" "$R/gpurun_out/prof_train" "$R/gpurun_out/prof_cqe"
 cd "$R"
-timeout -k 10 400 python bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
+timeout -k 10 700 python bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err || echo "bench failed"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_r01" -o r01 -- python3 "$R/bench.py" --no-cpu-baseline --no-codec > "$R/gpurun_out/prof_bench.log" 2>&1
-PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --train-steps 0 --no-f32-compare --no-graph --no-codec"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -o f -- python3 "$R/bench.py" $PMC_ARGS > "$R/gpurun_out/pmc_fetch.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o w -- python3 "$R/bench.py" $PMC_ARGS > "$R/gpurun_out/pmc_write.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_$TAG" -o $TAG -- python3 "$R/bench.py" --no-cpu-baseline --no-codec --no-pmc > "$R/gpurun_out/prof_bench.log" 2>&1 || echo "trace failed"
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+timeout -k 10 300 rocprofv3 --pmc $SQ --output-format csv -d "$R/gpurun_out/pmc_sq" -o s -- python3 "$R/bench.py" --pmc-child > "$R/gpurun_out/pmc_sq.log" 2>&1 || echo "sq failed"
+timeout -k 10 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/prof_train" -o tr -- python3 "$R/tools/train_prof.py" bf16 > "$R/gpurun_out/prof_train.log" 2>&1 || echo "train trace failed"
+timeout -k 10 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/prof_cqe" -o c -- python3 "$R/tools/cqe_prof.py" bf16 > "$R/gpurun_out/prof_cqe.log" 2>&1 || echo "cqe trace failed"
 cd "$R"
-# keep the merge small: the trace database and the counter CSVs are all refresh_profiles.py reads
-find gpurun_out/prof_r01 gpurun_out/pmc_fetch gpurun_out/pmc_write -type f ! -name '*results.db' ! -name '*counter_collection.csv' -delete
-ls -la gpurun_out/prof_r01 gpurun_out/pmc_fetch gpurun_out/pmc_write
-tail -c 600 gpurun_out/bench_n1.json
+# keep the merge small: the trace databases and the counter CSVs are all refresh_profiles.py reads
+find gpurun_out/prof_$TAG gpurun_out/pmc_sq gpurun_out/prof_train gpurun_out/prof_cqe -type f ! -name '*results.db' ! -name '*counter_collection.csv' -delete
+ls -la gpurun_out/prof_$TAG gpurun_out/pmc_sq
+tail -c 400 gpurun_out/bench_n1.json
