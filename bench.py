@@ -210,6 +210,8 @@ def traffic_for(symbol, pmc, pmc_reason):
         e = pmc[symbol]
         return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py --pmc-child` "
                                                                    f"(eager forward, {e['launches']} launches); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    if pmc is not None:
+        pmc_reason = f"the PMC passes ran but hold no kernel named {symbol!r}"
     stored = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(stored))
@@ -412,7 +414,7 @@ def main():
     a = agg[dom]
     avg_ms = a["ms"] / a["launches"]
     tflops = a["flops"] / a["launches"] / (avg_ms * 1e-3) / 1e12
-    peak = FP8_MFMA_PEAK_TFLOPS if dom.endswith(", true>") else (BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS)
+    peak = FP8_MFMA_PEAK_TFLOPS if (dom.startswith("conv_f16k<") and dom.endswith(", true>")) else (BF16_MFMA_PEAK_TFLOPS if ("bf16" in dom or "f16k" in dom) else F32_MFMA_PEAK_TFLOPS)
     traffic, traffic_source = traffic_for(dom, pmc, pmc_reason)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_source,

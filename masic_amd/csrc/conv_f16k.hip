@@ -1014,10 +1014,10 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
     if (d->prec == MASIC_PREC_FP8) snprintf(buf, n, "conv_f16k<%d, %d, %d, %d, %d, %s, 4, 1, true>", c.KS, c.T, F16K_D, c.KS == 1 ? 6 : 4, c.L, gdn ? "true" : "false");
     else if (c.NP == 2 && c.KS == 2 && !gdn && d->Cout <= 96) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, false, %d, 2, false>", d->Cout <= 64 ? 2 : 3);
-    else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2>", gdn ? "true" : "false");
-    else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
-    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1>", c.T, c.D, gdn ? "true" : "false");
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1>", F16K_D, gdn ? "true" : "false", nm);
+    else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2, false>", gdn ? "true" : "false");
+    else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d, false>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
+    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1, false>", c.T, c.D, gdn ? "true" : "false");
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1, false>", F16K_D, gdn ? "true" : "false", nm);
     return MASIC_OK;
 }
 

@@ -2,7 +2,7 @@
 
 `HSIC._forward_eval` (coremasic/mywork/MASIC.py) issues independent branches of the forward on side streams and
 `masic_amd/graph.py` captures the whole DAG into one HIP graph.  Three stream topologies end `hipStreamEndCapture` on
-this ROCm (7.x / torch 2.10) with a process-killing fault instead of an error (DESIGN.md section 4.4; found the hard
+this ROCm (7.x / torch 2.10) with a process-killing fault instead of an error (DESIGN.md section 4.5; found the hard
 way in round 1):
 
   1. a side stream that forks further streams (a fork whose origin is not the capturing stream),

@@ -1,4 +1,4 @@
-"""The three HIP-graph capture rules of masic_amd/streams.py (DESIGN.md section 4.4) raise RuntimeError BEFORE the offending
+"""The three HIP-graph capture rules of masic_amd/streams.py (DESIGN.md section 4.5) raise RuntimeError BEFORE the offending
 wait is issued -- in round 1 each of these topologies ended hipStreamEndCapture with a process-killing fault.  CPU-runnable:
 ForkJoin takes a backend; the fakes below record what would have been issued."""
 import contextlib
