@@ -770,6 +770,9 @@ struct ConvAArgs {
     unsigned short* y16_pre;      // also store conv + bias before the GDN (F16K), or null
 };
 
+#ifndef CONVA_ABLATE
+#define CONVA_ABLATE 0     // timing experiments only: 1 no GDN math, 2 no convolution, 3 no patch fetch / stash after the first tile, 4 no stores
+#endif
 constexpr int CA_PH = 19, CA_PW = 67, CA_PITCH = 68, CA_NEL = 3 * CA_PH * CA_PW;     // patch of an 8 x 32 tile, stride 2, 5 x 5
 constexpr int CA_PATCH_BYTES = 8192;                                                 // 3 * 19 * 68 * 2 = 7752, padded
 constexpr int CA_NPT = (CA_NEL + 511) / 512;                                          // patch elements per thread
@@ -787,6 +790,10 @@ __global__ void pack_conv_a_kernel(const float* __restrict__ w, uint4* __restric
     wimg[idx] = __builtin_bit_cast(uint4, v);
 }
 
+// X3: three-product GDN contraction; OUT: 0 F16K, 1 F8K (fp8), 2 F16K + the pre-GDN result (training).  Compile-time variants: with
+// the choices as run-time branches both GDN forms were inlined and the kernel spilled 68 VGPRs in its tile loop (129 us per launch
+// at 8x512x512 against 80 for the round-1 kernel).
+template <bool X3, int OUT>
 __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int WIMG = 65536, VEC = WIMG + 20480, PATCH = VEC + 1024;      // LDS map: gamma image | weights | bias, beta^ | 2 patches
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
     int buf = 0;
     for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
         const int next = tile + gridDim.x;
-        if (next < a.ntiles) fetch(next);                        // in flight during this tile's contraction
+        if (next < a.ntiles && CONVA_ABLATE != 3) fetch(next);   // in flight during this tile's contraction
         // ---- convolution: 5 k-steps x 4 channel blocks
         const __bf16* pl = reinterpret_cast<const __bf16*>(lds + PATCH + buf * CA_PATCH_BYTES) + (2 * wave) * CA_PITCH + 2 * j;
         f32x16 acc[4];
@@ -859,7 +866,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
 #pragma unroll
-        for (int sx = 0; sx < 5; ++sx) {
+        for (int sx = 0; sx < (CONVA_ABLATE == 2 ? 0 : 5); ++sx) {
             bf16x8 bfr;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 const float4 bv = *reinterpret_cast<const float4*>(vec + m * 32 + 8 * q + 4 * h);
                 acc[m][4 * q] += bv.x; acc[m][4 * q + 1] += bv.y; acc[m][4 * q + 2] += bv.z; acc[m][4 * q + 3] += bv.w;
             }
-        if (a.y16_pre != nullptr) {
+        if constexpr (OUT == 2) {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
             if (oh < a.Ho && ow < a.Wo) {
@@ -894,13 +901,12 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yp + (size_t)(2 * m) * op16, op16);
             }
         }
-        if (a.gdn_inverse & 2) gdn_in_registers<true>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
-        else gdn_in_registers<false>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
-        {
+        if (CONVA_ABLATE != 1) gdn_in_registers<X3>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
+        if (CONVA_ABLATE != 4) {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
             if (oh < a.Ho && ow < a.Wo) {
-                if (a.y8 != nullptr) {
+                if constexpr (OUT == 1) {
                     unsigned char* yb = a.y8 + (((size_t)b * 4) * oplane + (size_t)oh * a.Wo + ow) * 32 + 16 * h;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) store_f8k_tile(acc[m], yb + (size_t)m * oplane * 32, a.out_inv_scale);
@@ -912,7 +918,7 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 }
             }
         }
-        if (next < a.ntiles) stash(buf ^ 1);
+        if (next < a.ntiles && CONVA_ABLATE != 3) stash(buf ^ 1);
         __syncthreads();
     }
 }
@@ -1279,13 +1285,23 @@ int conv_a_launch(const float* x, const void* w_packed, const float* bias, const
     const int tiles_w = ceil_div(Wo, 32), tiles_per_img = tiles_w * ceil_div(Ho, 8), ntiles = tiles_per_img * B;
     ConvAArgs a{x, (const uint4*)w_packed, bias, (const uint4*)gdn_packed, (unsigned short*)y_f16k, gdn_inverse, Hi, Wi, in_ctot, in_coff,
                 Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale, (unsigned short*)y_pre};
-    static bool attr_set = false;
     const size_t lds_bytes = 65536 + 20480 + 1024 + 2 * CA_PATCH_BYTES;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_a_gdn_f16k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_a_gdn_f16k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, (hipStream_t)stream, a);
+    const dim3 grid(ntiles < 256 ? ntiles : 256);
+#define CONV_A_LAUNCH(X3V, OUTV)                                                                                                   \
+    do {                                                                                                                           \
+        auto kfn = conv_a_gdn_f16k<X3V, OUTV>;                                                                                     \
+        static bool attr_set = false;                                                                                              \
+        if (!attr_set) {                                                                                                           \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+            attr_set = true;                                                                                                       \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), lds_bytes, (hipStream_t)stream, a);                                               \
+    } while (0)
+    const bool x3 = (gdn_inverse & 2) != 0;
+    const int out = y_f8k != nullptr ? 1 : (y_pre != nullptr ? 2 : 0);
+    if (x3) { if (out == 0) CONV_A_LAUNCH(true, 0); else if (out == 1) CONV_A_LAUNCH(true, 1); else CONV_A_LAUNCH(true, 2); }
+    else { if (out == 0) CONV_A_LAUNCH(false, 0); else if (out == 1) CONV_A_LAUNCH(false, 1); else CONV_A_LAUNCH(false, 2); }
+#undef CONV_A_LAUNCH
     return masic_launch_status("conv_a_gdn_fwd");
 }
 }  // namespace
