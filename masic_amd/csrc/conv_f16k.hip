@@ -63,6 +63,10 @@ __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void lgkm_wait(v4u& a, v4u& b, v4u& c, v4u& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
@@ -189,6 +193,8 @@ struct F16kArgs {
     GeomParams q;
     int nphase;
     int xcd_images;               // B % 8 == 0: image b runs on XCD b % 8 (the halos of its tiles meet in one L2)
+    int msplit;                   // workgroups per 128-channel co-block (4 / NM for layers whose grid would not fill the chip, else 1):
+                                  //   blockIdx.y = co-block * msplit + sub-block, a sub-block = NM accumulator tiles of the slab
 };
 
 #ifndef F16K_ABLATE
@@ -352,7 +358,7 @@ template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP, bool F
 __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
     static_assert(!F8 || (NM == 4 && NP == 1 && (T * KS) % 2 == 0 && T <= 4), "fp8 operands: 128-channel blocks, 256-pixel tiles, slab pairs");
-    static_assert(NM + NP == 2 || NM + NP == 4 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 4, 5 and 6 fragments per k-step");
+    static_assert(NM + NP == 2 || NM + NP == 3 || NM + NP == 4 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 4, 5 and 6 fragments per k-step");
     constexpr int WI = T * KS;                   // weight DMA wave-instructions per weight wave per step (4 waves x 1 KiB x WI = slab group)
     constexpr int NWS = D + 1;                   // weight ring slots
     constexpr int WST = T * KS * 4096;           // bytes per step of weights
@@ -406,7 +412,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + ((size_t)b * a.in_c16tot + a.in_c16off) * (size_t)(a.Hi * a.Wi * 16)), 0, a.Cin16 * plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const unsigned char*)a.w + a.phase_off[phase] + (size_t)blockIdx.y * a.stream_bytes[phase]), 0, (int)a.stream_bytes[phase], 0x00020000);
+        (void*)((const unsigned char*)a.w + a.phase_off[phase] + (size_t)(blockIdx.y / a.msplit) * a.stream_bytes[phase]), 0, (int)a.stream_bytes[phase], 0x00020000);
+    const int msub = (int)(blockIdx.y % a.msplit) * NM;       // first 32-channel tile of this workgroup inside the 128-channel slab
+    if ((int)(blockIdx.y / a.msplit) * 128 + msub * 32 >= a.Cout) return;      // a sub-block past the last output channel (Cout = 192: second co-block)
 
     {   // ---- geometry-dependent setup (kept in a scope: nothing of the phase geometry stays live in the K loop)
         const ConvGeom g = make_geom(a.q, phase);
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         } else if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 16) : "memory");
         else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv), "+v"(tv4)::"memory");
-        const unsigned wst = ldsb + al + cslot;
+        const unsigned wst = ldsb + al + cslot + msub * 512;
         constexpr int NQ = F8 ? 2 : 1;                            // ds_read_b128 per fragment
         constexpr int NKS = F8 ? (T * KS) / 2 : T * KS;           // MFMA k-steps per step
         v4u af[2][NM][NQ], bfr[2][NP][NQ];
@@ -582,6 +590,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             else if constexpr (NM == 1 && NP == 4) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], bfr[buf][2][0], bfr[buf][3][0], af[buf][0][0]);
             else if constexpr (NM == 3 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0], af[buf][2][0]);
             else if constexpr (NM == 2 && NP == 2) lgkm_wait<pending>(bfr[buf][0][0], bfr[buf][1][0], af[buf][0][0], af[buf][1][0]);
+            else if constexpr (NM == 2 && NP == 1) lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0], af[buf][1][0]);
             else lgkm_wait<pending>(bfr[buf][0][0], af[buf][0][0]);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
@@ -613,7 +622,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
 
     // ---- epilogue
     const ConvGeom g = make_geom(a.q, phase);
-    const int m0 = blockIdx.y * 128;
+    const int m0 = (blockIdx.y / a.msplit) * 128 + msub * 32;
     const int jr = j >> a.TWlog, jc = j & (a.TW - 1);
     const size_t oplane = (size_t)a.Ho * a.Wo;
     // bias, then (inverse) GDN or the activation.  Cout is a multiple of 32, so a 32-channel block is valid or not as a whole.
@@ -1000,6 +1009,19 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     return c;
 }
 
+// Layers whose grid leaves most of the 256 CUs idle (the 128 -> 192 layer at 64^2 -> 32^2, hyper transforms, context models:
+// 8 ... 128 workgroups): the 128-channel co-block is split over 2 or 4 workgroups of 2 / 1 accumulator tiles each.  The patch and
+// the slab DMA are repeated per workgroup (they come from L2), the MFMA work is not.  MASIC_F16K_MSPLIT=1 disables it (A/B).
+int f16k_msplit(const masic_conv_desc_t& d, const F16kCfg& c, int np, const ConvGeom* g, bool gdn, bool special) {
+    if (d.prec == MASIC_PREC_FP8 || gdn || c.NP != 1 || special || d.Cout < 64) return 1;
+    static const int forced = getenv("MASIC_F16K_MSPLIT") ? atoi(getenv("MASIC_F16K_MSPLIT")) : 0;
+    const int ntiles = ceil_div(g[0].Wp, c.TW) * ceil_div(g[0].Hp, c.TH);
+    const long wgs = (long)ntiles * np * c.ncb * d.B;
+    const int ms = forced ? forced : (wgs <= 64 ? 4 : (wgs <= 160 ? 2 : 1));
+    return (ms == 2 || ms == 4) ? ms : 1;
+}
+int msplit_nm(const masic_conv_desc_t& d, const F16kCfg& c, int np, const ConvGeom* g) { return 4 / f16k_msplit(d, c, np, g, false, false); }
+
 }  // namespace
 
 extern "C" int masic_conv_f16k_supported(const masic_conv_desc_t* d) {
@@ -1022,8 +1044,8 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     else if (c.NP == 2 && c.KS == 2 && !gdn && d->Cout <= 96) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, false, %d, 2, false>", d->Cout <= 64 ? 2 : 3);
     else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2, false>", gdn ? "true" : "false");
     else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d, false>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
-    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, 4, 1, false>", c.T, c.D, gdn ? "true" : "false");
-    else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1, false>", F16K_D, gdn ? "true" : "false", nm);
+    else if (c.KS == 1) snprintf(buf, n, "conv_f16k<1, %d, %d, 6, 1, %s, %d, 1, false>", c.T, c.D, gdn ? "true" : "false", gdn ? 4 : msplit_nm(*d, c, np, g));
+    else snprintf(buf, n, "conv_f16k<2, 2, %d, 4, 2, %s, %d, 1, false>", F16K_D, gdn ? "true" : "false", (gdn || nm == 1) ? nm : msplit_nm(*d, c, np, g));
     return MASIC_OK;
 }
 
@@ -1187,8 +1209,10 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                (unsigned)((0x100000000ull + c.PW - 1) / c.PW), (unsigned)((0x100000000ull + c.PWh - 1) / c.PWh),
                (unsigned)((0x100000000ull + c.NPIXp / 32 - 1) / (c.NPIXp / 32)),
                {c.phase_off[0], c.phase_off[1], c.phase_off[2], c.phase_off[3]},
-               {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np, d->B % 8 == 0};
-    dim3 grid(round_up(ntiles, 8) * np, c.ncb, d->B);
+               {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np, d->B % 8 == 0, 1};
+    const int msplit = f16k_msplit(*d, c, np, g, gdn_packed != nullptr, d2s != 0 || cout_store != 0 || y_f8k != nullptr);
+    a.msplit = msplit;
+    dim3 grid(round_up(ntiles, 8) * np, c.ncb * msplit, d->B);
     hipStream_t st = (hipStream_t)stream;
 #define F16K_LAUNCH_D(KSV, TV, DV, PSPV, LV, GDNV, NMV, NPV)                                                                   \
     do {                                                                                                             \
@@ -1233,13 +1257,18 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         else F16K_LAUNCH(1, 2, 3, 2, false, 4, 2);
     } else if (c.KS == 1 && c.T == 5) {
         if (gdn_packed) F16K_LAUNCH_D(1, 5, 2, 6, 1, true, 4, 1);
+        else if (msplit == 4) F16K_LAUNCH_D(1, 5, 2, 6, 1, false, 1, 1);
+        else if (msplit == 2) F16K_LAUNCH_D(1, 5, 2, 6, 1, false, 2, 1);
         else F16K_LAUNCH_D(1, 5, 2, 6, 1, false, 4, 1);
     } else if (c.KS == 1) {
         if (gdn_packed) F16K_LAUNCH(1, 4, 6, 1, true, 4, 1);
+        else if (msplit == 4) F16K_LAUNCH(1, 4, 6, 1, false, 1, 1);
+        else if (msplit == 2) F16K_LAUNCH(1, 4, 6, 1, false, 2, 1);
         else F16K_LAUNCH(1, 4, 6, 1, false, 4, 1);
     } else {
         if (gdn_packed) F16K_LAUNCH(2, 2, 4, 2, true, 4, 1);
-        else if (d->Cout <= 32) F16K_LAUNCH(2, 2, 4, 2, false, 1, 1);
+        else if (d->Cout <= 32 || msplit == 4) F16K_LAUNCH(2, 2, 4, 2, false, 1, 1);
+        else if (msplit == 2) F16K_LAUNCH(2, 2, 4, 2, false, 2, 1);
         else F16K_LAUNCH(2, 2, 4, 2, false, 4, 1);
     }
 #undef F16K_LAUNCH
