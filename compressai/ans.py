@@ -1,6 +1,6 @@
 """`compressai.ans` (reference: the pybind11 module built from compressai/cpp_exts/rans/rans_interface.cpp:355-381):
-the same three classes over the host-side coder of libmasic_hip.so (masic_amd/csrc/rans.hip).  Streaming decode
-(`set_stream` / `decode_stream`) belongs to the autoregressive decompress of SURVEY.md 8(f)-1 and is not built."""
+the same three classes over the host-side coder of libmasic_hip.so (masic_amd/csrc/rans.hip), including the streaming
+decode (`set_stream` / `decode_stream`, rans_interface.cpp:286-353)."""
 from masic_amd import rans as _rans
 
 
@@ -35,7 +35,9 @@ class RansDecoder:
         return _rans.decode_with_indexes(encoded, indexes, cdfs, cdfs_sizes, offsets).tolist()
 
     def set_stream(self, encoded):
-        raise NotImplementedError("streaming decode is part of HSIC.decompress (SURVEY.md 8(f)-1): next")
+        self._stream = _rans.StreamDecoder(encoded)
 
-    def decode_stream(self, *args, **kwargs):
-        raise NotImplementedError("streaming decode is part of HSIC.decompress (SURVEY.md 8(f)-1): next")
+    def decode_stream(self, indexes, cdfs, cdfs_sizes, offsets):
+        if getattr(self, "_stream", None) is None:
+            raise RuntimeError("RansDecoder.decode_stream: call set_stream first")
+        return self._stream.decode(indexes, cdfs, cdfs_sizes, offsets).tolist()

@@ -282,21 +282,78 @@ class _GaussianBase(EntropyModel):
     def _standardized_cumulative(self, inputs):
         return 0.5 * torch.erfc(float(-(2 ** -0.5)) * inputs)
 
+    @staticmethod
+    def _standardized_quantile(quantile):
+        import scipy.stats
+        return scipy.stats.norm.ppf(quantile)
+
     def update_scale_table(self, scale_table, force=False):
-        raise NotImplementedError(_NEXT)
+        """reference :494-501"""
+        if self._offset.numel() > 0 and not force:
+            return
+        self.scale_table = self._prepare_scale_table(scale_table).to(self.scale_table.device)
+        self.update()
 
     def update(self):
-        raise NotImplementedError(_NEXT)
+        """Quantised CDF tables of the zero-mean Gaussians of `scale_table` (reference :503-525), evaluated with float32 torch ops on
+        the host for the same reason as EntropyBottleneck.update: byte-compatible streams need the reference's CPU arithmetic."""
+        table = self.scale_table.detach().cpu()
+        multiplier = -self._standardized_quantile(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = torch.max(pmf_length).item()
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        samples_scale = table.unsqueeze(1).float()
+        upper = self._standardized_cumulative((0.5 - samples) / samples_scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / samples_scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        dev = self.scale_table.device
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._offset = (-pmf_center).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+
+    def build_indexes(self, scales):
+        """index of the first scale_table entry >= LowerBound(scale) (reference :555-561); integer bookkeeping on the tensor's device"""
+        scales = self.lower_bound_scale(scales)
+        indexes = scales.new_full(scales.size(), len(self.scale_table) - 1).int()
+        for s in self.scale_table[:-1]:
+            indexes -= (scales <= s).int()
+        return indexes
 
 
 class GaussianConditional(_GaussianBase):
-    """Single-Gaussian conditional (reference :433-562). Import surface only: MASIC uses the mixture."""
+    """Single-Gaussian conditional (reference :433-562); not used by MASIC (it uses the mixture), provided for the API surface.
+    forward = the K = 1 case of the mixture kernels: quantise about the means, likelihood of |y^ - mu| under N(0, LowerBound(sigma))."""
 
     def __init__(self, scale_table, *args, **kwargs):
         super().__init__(scale_table, *args, **kwargs)
 
+    def _quantize_about(self, inputs, means):
+        inputs = inputs.contiguous()
+        if self.training:
+            return _hip.quantize(inputs, "noise", noise=self._get_noise_cached(inputs))
+        if means is None:
+            return _hip.quantize(inputs, "dequantize")
+        means = means.expand_as(inputs).contiguous()
+        centred = _hip.elementwise(_hip.EW_AXPY, inputs, means, s0=1.0, s1=-1.0)     # x - mu
+        return _hip.elementwise(_hip.EW_ADD, _hip.quantize(centred, "dequantize"), means)
+
+    def _likelihood(self, inputs, scales, means=None):
+        mu = torch.zeros_like(inputs) if means is None else means.expand_as(inputs).contiguous()
+        _, lik = _hip.gmm_likelihood(inputs.contiguous(), scales.contiguous(), mu, torch.ones_like(inputs), 1, training=True,
+                                     noise=torch.zeros_like(inputs), scale_bound=self._scale_bound_value, lik_bound=0.0)
+        return lik
+
     def forward(self, inputs, scales, means=None):
-        raise NotImplementedError("GaussianConditional is not on the MASIC path; use GaussianMixtureConditional_gf")
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (inputs, scales, means)):
+            raise NotImplementedError("GaussianConditional has no backward on the HIP path (MASIC trains the mixture, GaussianMixtureConditional_gf)")
+        outputs = self._quantize_about(inputs, means)
+        mu = torch.zeros_like(outputs) if means is None else means.expand_as(outputs).contiguous()
+        lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        _, lik = _hip.gmm_likelihood(outputs, scales.contiguous(), mu, torch.ones_like(outputs), 1, training=True, noise=torch.zeros_like(outputs),
+                                     scale_bound=self._scale_bound_value, lik_bound=lb)
+        return outputs, lik
 
 
 class GaussianMixtureConditional(_GaussianBase):

@@ -33,7 +33,10 @@ class GDN(nn.Module):
 
 
 class GDN1(GDN):
-    """Simplified GDN (|x| instead of x^2; reference gdn.py:95-121). Not used by MASIC: no HIP kernel."""
+    """Simplified GDN: y_i = x_i / (beta_i + sum_j gamma_ij |x_j|) (reference gdn.py:95-121).  Not used by MASIC; inference-only
+    float32 kernel (masic_gdn1_fwd) for the API surface."""
 
     def forward(self, x):
-        raise NotImplementedError("GDN1 is outside the MASIC hot path (SURVEY.md section 2 #3); no MI355X kernel is built for it")
+        if torch.is_grad_enabled() and (x.requires_grad or self.gamma.requires_grad):
+            raise NotImplementedError("GDN1 has no backward on the HIP path (MASIC uses GDN); call it under torch.no_grad()")
+        return _hip.gdn1(x.contiguous(), self.beta.detach(), self.gamma.detach().contiguous(), inverse=self.inverse, beta_min=self.beta_min)

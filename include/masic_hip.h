@@ -227,6 +227,9 @@ int masic_gdn_fwd(const float* x, const float* beta, const float* gamma, float* 
  * accumulate, ~2^-16 relative) at 16/3 of the f32 matrix rate -- HBM-bound; MASIC_PREC_F32: exact float32 MFMA */
 int masic_gdn_fwd_ex(const float* x, const float* beta, const float* gamma, float* y,
                      int B, int C, int H, int W, int inverse, double beta_min, int prec, void* stream);
+/* Simplified GDN ("GDN1", compressai/layers/gdn.py:95-121): y_i = x_i / (beta^_i + sum_j gamma^_ij |x_j|) (inverse: multiply); float32, any C */
+int masic_gdn1_fwd(const float* x, const float* beta, const float* gamma, float* y,
+                   int B, int C, int H, int W, int inverse, double beta_min, void* stream);
 /* Same, C = 128 only, result written as F16K bf16 [B][8][H*W][16] for masic_conv_f16k_fwd (bf16x3 contraction). */
 int masic_gdn_fwd_f16k(const float* x, const float* beta, const float* gamma, void* y_f16k,
                        int B, int C, int H, int W, int inverse, double beta_min, void* stream);
@@ -421,6 +424,10 @@ int masic_gmm_cdf_rows(const float* sigma, const float* mu, const float* logits,
 int masic_rans_encode_freqs(const int32_t* start_freq, size_t n, uint8_t* out, size_t out_cap, size_t* out_len);
 int masic_rans_decoder_open(const uint8_t* in, size_t in_len, void** handle);
 int masic_rans_decoder_decode_rows(void* handle, const uint16_t* starts, int nrows, int L, int32_t* symbols);
+/* the next n symbols with tables picked by indexes (arguments as masic_rans_decode_with_indexes), keeping the coder state between
+ * calls: reference RansDecoder::set_stream / decode_stream (rans_interface.cpp:286-353) */
+int masic_rans_decoder_decode_indexes(void* handle, const int32_t* indexes, int n, const int32_t* cdfs, int cdf_stride,
+                                      const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols);
 void masic_rans_decoder_close(void* handle);
 
 #ifdef __cplusplus

@@ -60,6 +60,8 @@ SIGNATURES = {
     "masic_rans_decoder_open": (c_int, [_P, c_size_t, _P]),
     "masic_rans_decoder_decode_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "masic_rans_decoder_close": (None, [_P]),
+    "masic_rans_decoder_decode_indexes": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P]),
+    "masic_gdn1_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_conv5s1_pair_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P]),
     "masic_conv_a_packed_bytes": (c_size_t, []),
     "masic_conv_a_pack_weight": (c_int, [_P, _P, _P]),

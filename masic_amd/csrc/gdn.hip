@@ -242,7 +242,7 @@ __global__ void gdn_pack_f16k_kernel(const float* __restrict__ beta, const float
 __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, const float* __restrict__ beta,
                                                   const float* __restrict__ gamma, float* __restrict__ y,
                                                   int C, int HW, int inverse,
-                                                  float beta_bound, float gamma_bound, float pedestal) {
+                                                  float beta_bound, float gamma_bound, float pedestal, int simplified) {
     extern __shared__ float sq[];   // [C][64]
     const int b = blockIdx.y;
     const int p = blockIdx.x * 64 + threadIdx.x;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, c
     float* yb = y + (size_t)b * C * HW + p;
     for (int c = 0; c < C; ++c) {
         const float v = live ? xb[(size_t)c * HW] : 0.0f;
-        sq[c * 64 + threadIdx.x] = __fmul_rn(v, v);
+        sq[c * 64 + threadIdx.x] = simplified ? fabsf(v) : __fmul_rn(v, v);
     }
     // each thread only reads back its own column: no barrier needed
     for (int i = 0; i < C; ++i) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void gdn_generic(const float* __restrict__ x, c
         n += s;
         if (live) {
             const float xv = xb[(size_t)i * HW];
-            const float r = sqrtf(n);
+            const float r = simplified ? n : sqrtf(n);
             yb[(size_t)i * HW] = inverse ? xv * r : xv * (1.0f / r);
         }
     }
@@ -305,9 +305,25 @@ extern "C" int masic_gdn_fwd_ex(const float* x, const float* beta, const float* 
                            beta_bound, gamma_bound, pedestal);
     } else {
         hipLaunchKernelGGL(gdn_generic, dim3(ceil_div(HW, 64), B), dim3(64), (size_t)C * 64 * sizeof(float), st,
-                           x, beta, gamma, y, C, HW, inverse, beta_bound, gamma_bound, pedestal);
+                           x, beta, gamma, y, C, HW, inverse, beta_bound, gamma_bound, pedestal, 0);
     }
     return masic_launch_status("gdn_fwd");
+}
+
+extern "C" int masic_gdn1_fwd(const float* x, const float* beta, const float* gamma, float* y,
+                              int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    MASIC_REQUIRE(x && beta && gamma && y, MASIC_ERR_ARG, "gdn1_fwd: null pointer");
+    MASIC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (size_t)C * 64 * sizeof(float) <= 160 * 1024, MASIC_ERR_SHAPE, "gdn1_fwd: bad dimension (C <= 640)");
+    const double ped = 0x1p-36;
+    const int HW = H * W;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gdn_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gdn_generic, dim3(ceil_div(HW, 64), B), dim3(64), (size_t)C * 64 * sizeof(float), (hipStream_t)stream,
+                       x, beta, gamma, y, C, HW, inverse, (float)__builtin_sqrt(beta_min + ped), (float)__builtin_sqrt(ped), (float)ped, 1);
+    return masic_launch_status("gdn1_fwd");
 }
 
 // GDN of a 128-channel float32 NCHW tensor with the result written as F16K bf16 [B][8][H*W][16] -- the input layout of

@@ -168,18 +168,11 @@ extern "C" int masic_rans_encode_with_indexes(const int32_t* symbols, const int3
     return MASIC_OK;
 }
 
-extern "C" int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32_t* indexes, int n, const int32_t* cdfs,
-                                              int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols) {
-    MASIC_REQUIRE(in && indexes && cdfs && cdf_sizes && offsets && symbols && n >= 0, MASIC_ERR_ARG, "rans_decode: null pointer");
-    MASIC_REQUIRE(in_len >= 8 && in_len % 4 == 0, MASIC_ERR_SHAPE, "rans_decode: stream of %zu bytes", in_len);
-    int rc = check_tables(cdfs, cdf_stride, cdf_sizes, ncdfs);
-    if (rc != MASIC_OK) return rc;
-    std::vector<uint32_t> words(in_len / 4);
-    memcpy(words.data(), in, in_len);
-    const uint32_t* p = words.data();
-    const uint32_t* end = p + words.size();
-    uint64_t x = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
-    p += 2;
+namespace {
+// symbols i = 0 .. n-1 with tables picked by indexes[i], continuing from the coder state (x, p): shared by the one-shot and the
+// streaming decoder (reference rans_interface.cpp:214-283 and :286-353 -- the same loop over a stream kept between calls)
+int decode_indexed(uint64_t& x, const uint32_t*& p, const uint32_t* end, const int32_t* indexes, int n, const int32_t* cdfs, int cdf_stride,
+                   const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
         const int idx = indexes[i];
@@ -220,6 +213,22 @@ extern "C" int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, 
         symbols[i] = value + offsets[idx];
     }
     return MASIC_OK;
+}
+}  // namespace
+
+extern "C" int masic_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const int32_t* indexes, int n, const int32_t* cdfs,
+                                              int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols) {
+    MASIC_REQUIRE(in && indexes && cdfs && cdf_sizes && offsets && symbols && n >= 0, MASIC_ERR_ARG, "rans_decode: null pointer");
+    MASIC_REQUIRE(in_len >= 8 && in_len % 4 == 0, MASIC_ERR_SHAPE, "rans_decode: stream of %zu bytes", in_len);
+    int rc = check_tables(cdfs, cdf_stride, cdf_sizes, ncdfs);
+    if (rc != MASIC_OK) return rc;
+    std::vector<uint32_t> words(in_len / 4);
+    memcpy(words.data(), in, in_len);
+    const uint32_t* p = words.data();
+    const uint32_t* end = p + words.size();
+    uint64_t x = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+    p += 2;
+    return decode_indexed(x, p, end, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, ncdfs, symbols);
 }
 
 // ---------------------------------------------------------------------------- adaptive tables
@@ -293,6 +302,21 @@ extern "C" int masic_rans_decoder_decode_rows(void* handle, const uint16_t* star
         symbols[r] = s;
     }
     return MASIC_OK;
+}
+
+// streaming form of masic_rans_decode_with_indexes on a decoder opened with masic_rans_decoder_open: decodes the next n symbols and
+// keeps the coder state for the next call (reference RansDecoder::set_stream / decode_stream, rans_interface.cpp:286-353)
+extern "C" int masic_rans_decoder_decode_indexes(void* handle, const int32_t* indexes, int n, const int32_t* cdfs, int cdf_stride,
+                                                 const int32_t* cdf_sizes, const int32_t* offsets, int ncdfs, int32_t* symbols) {
+    MASIC_REQUIRE(handle && indexes && cdfs && cdf_sizes && offsets && symbols && n >= 0, MASIC_ERR_ARG, "rans_decoder_decode_indexes: null pointer");
+    int rc = check_tables(cdfs, cdf_stride, cdf_sizes, ncdfs);
+    if (rc != MASIC_OK) return rc;
+    AdaptiveDecoder* d = (AdaptiveDecoder*)handle;
+    const uint32_t* p = d->words.data() + d->pos;
+    const uint32_t* end = d->words.data() + d->words.size();
+    rc = decode_indexed(d->x, p, end, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, ncdfs, symbols);
+    d->pos = (size_t)(p - d->words.data());
+    return rc;
 }
 
 extern "C" void masic_rans_decoder_close(void* handle) { delete (AdaptiveDecoder*)handle; }

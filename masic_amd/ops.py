@@ -175,6 +175,17 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6, prec=_lib.PREC_F32):
     return y
 
 
+def gdn1(x, beta, gamma, inverse=False, beta_min=1e-6):
+    """Simplified GDN (|x| in place of x^2, no square root; compressai/layers/gdn.py:95-121), float32."""
+    _dev(x, "gdn1 input"); _dev(beta, "beta"); _dev(gamma, "gamma")
+    B, C, H, W = x.shape
+    if beta.numel() != C or tuple(gamma.shape) != (C, C):
+        raise RuntimeError("masic_amd.gdn1: parameter shapes do not match the input channels")
+    y = torch.empty_like(x)
+    check(lib.masic_gdn1_fwd(_p(x), _p(beta), _p(gamma), _p(y), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn1_fwd")
+    return y
+
+
 def gdn_f16k(x, beta, gamma, inverse=False, beta_min=1e-6):
     """GDN of a 128-channel float32 NCHW tensor -> F16K bf16 buffer (input of conv2d_f16k)."""
     _dev(x, "gdn input"); _dev(beta, "beta"); _dev(gamma, "gamma")

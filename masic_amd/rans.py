@@ -61,3 +61,29 @@ def decode_with_indexes(encoded, indexes, cdfs, cdf_sizes, offsets):
     check(lib.masic_rans_decode_with_indexes(_ptr(buf), buf.size, _ptr(idx), idx.size, _ptr(table), table.shape[1], _ptr(sizes), _ptr(offs),
                                              table.shape[0], _ptr(out)), "rans_decode_with_indexes")
     return out
+
+
+class StreamDecoder:
+    """Incremental decode_with_indexes over one stream (reference RansDecoder.set_stream / decode_stream, rans_interface.cpp:286-353)."""
+
+    def __init__(self, encoded):
+        import ctypes
+        self._buf = np.frombuffer(bytes(encoded), dtype=np.uint8)
+        self._h = ctypes.c_void_p()
+        check(lib.masic_rans_decoder_open(_ptr(self._buf), self._buf.size, ctypes.byref(self._h)), "rans_decoder_open")
+
+    def decode(self, indexes, cdfs, cdf_sizes, offsets):
+        idx = _i32(indexes).reshape(-1)
+        table, sizes, offs = _tables(cdfs, cdf_sizes, offsets)
+        out = np.empty(idx.size, dtype=np.int32)
+        check(lib.masic_rans_decoder_decode_indexes(self._h, _ptr(idx), idx.size, _ptr(table), table.shape[1], _ptr(sizes), _ptr(offs), table.shape[0],
+                                                    _ptr(out)), "rans_decoder_decode_indexes")
+        return out
+
+    def close(self):
+        if self._h:
+            lib.masic_rans_decoder_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

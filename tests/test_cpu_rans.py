@@ -151,3 +151,38 @@ def test_wavefront_order_is_causal_for_the_type_a_mask():
                         a, b = i + di, j + dj
                         if 0 <= a < h and 0 <= b < w:
                             assert when[a * w + b] < when[i * w + j]
+
+
+def test_streaming_decoder_matches_reference_streams():
+    """compressai.ans.RansDecoder.set_stream / decode_stream (reference rans_interface.cpp:286-353): the reference's own streams decoded in
+    uneven pieces, with the coder state kept between calls, give the symbols of the one-shot decode."""
+    from compressai.ans import RansDecoder
+    tab, sizes, offs = G["tables"], G["sizes"], G["offsets"]
+    for case in ("short", "long", "escapes"):
+        sym, idx, ref = G["sym_" + case], G["idx_" + case], G["enc_" + case].tobytes()
+        dec = RansDecoder()
+        with pytest.raises(RuntimeError):
+            RansDecoder().decode_stream(idx[:1].tolist(), tab, sizes, offs)
+        dec.set_stream(ref)
+        got, pos = [], 0
+        for n in (1, 3, 0, 17, 10 ** 9):
+            piece = idx[pos:pos + n]
+            got += dec.decode_stream(piece.tolist(), tab, sizes, offs)
+            pos += len(piece)
+        assert got == sym.tolist(), case
+
+
+def test_gaussian_conditional_tables_vs_reference():
+    """GaussianConditional.update / update_scale_table (reference entropy_models.py:494-525): the quantised CDF tables of a scale table
+    against the reference's (tests/golden/misc_api.npz); host code, no GPU needed."""
+    from compressai.entropy_models import GaussianConditional
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "misc_api.npz"))
+    gc = GaussianConditional([float(v) for v in fx["gc/scale_table"]])
+    gc.update()
+    assert gc._quantized_cdf.numpy().tolist() == fx["gc/quantized_cdf"].tolist()
+    assert gc._offset.numpy().tolist() == fx["gc/offset"].tolist() and gc._cdf_length.numpy().tolist() == fx["gc/cdf_length"].tolist()
+    gc2 = GaussianConditional(None)
+    gc2.update_scale_table([float(v) for v in fx["gc/scale_table"]])
+    assert gc2._quantized_cdf.numpy().tolist() == fx["gc/quantized_cdf"].tolist()
+    gc2.update_scale_table([1.0, 2.0])                       # already initialised and not forced: unchanged (reference :497-499)
+    assert gc2._quantized_cdf.shape == gc._quantized_cdf.shape

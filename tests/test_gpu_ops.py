@@ -545,3 +545,33 @@ def test_pair_prep_vs_restatement(H, W, start, crop, xy):
     assert np.array_equal(patch.cpu().numpy(), want_patch)
     with pytest.raises(RuntimeError):
         ops.pair_prep(torch.from_numpy(img).to(DEV), (H - 10, 0), crop)     # crop outside the picture
+
+
+def test_api_surface_gaussian_conditional_and_gdn1_vs_reference():
+    """Classes of the compressai surface that MASIC itself does not call: GaussianConditional.forward / build_indexes (reference
+    entropy_models.py:527-561) and GDN1 (layers/gdn.py:95-121) against the reference's outputs (tests/golden/misc_api.npz)."""
+    from compressai.entropy_models import GaussianConditional
+    from compressai.layers import GDN1
+    fx = load_npz("misc_api.npz")
+    gc = GaussianConditional([float(v) for v in fx["gc/scale_table"]]).to(DEV).eval()
+    x, sc, mu = (torch.from_numpy(fx["gc/" + k]).to(DEV) for k in ("x", "scales", "means"))
+    with torch.no_grad():
+        y0, l0 = gc(x, sc)
+        y1, l1 = gc(x, sc, mu)
+        idx = gc.build_indexes(sc)
+    assert torch.equal(y0.cpu(), torch.from_numpy(fx["gc/y_nomeans"]))
+    assert_close(y1, torch.from_numpy(fx["gc/y_means"]), "GaussianConditional: dequantised about the means", 1e-6)
+    for got, key in ((l0, "gc/lik_nomeans"), (l1, "gc/lik_means")):
+        ref = torch.from_numpy(fx[key])
+        assert float(((got.cpu() - ref).abs() / (ref.abs() + 1e-9)).max()) <= 1e-3 and float((got.cpu() - ref).abs().max()) <= 1e-6, key
+    assert idx.cpu().numpy().tolist() == fx["gc/indexes"].tolist()
+    gc.train()
+    with pytest.raises(NotImplementedError):
+        gc(x.clone().requires_grad_(True), sc)
+    for tag, inverse in (("gdn1/", False), ("gdn1_inv/", True)):
+        m = GDN1(6, inverse=inverse).to(DEV)
+        with torch.no_grad():
+            m.beta.copy_(torch.from_numpy(fx[tag + "beta"]))
+            m.gamma.copy_(torch.from_numpy(fx[tag + "gamma"]))
+            out = m(torch.from_numpy(fx[tag + "x"]).to(DEV))
+        assert_close(out, torch.from_numpy(fx[tag + "y"]), "GDN1 " + tag, 1e-5)
