@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import hsic_oracle as O
-from tests.util import assert_close
+from tests.util import assert_close, load_npz
 
 pytestmark = pytest.mark.gpu
 
