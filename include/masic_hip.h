@@ -192,6 +192,13 @@ int masic_conv_f16k_gdn_dual_fwd(const void* x_f16k, const void* w_packed, const
                                  void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream);
 int masic_conv_a_gdn_dual_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                               void* y_pre_f16k, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
+/* weight gradient of Conv2d(Cin -> Cout, k3, s1, p1) with both operands in F16K (Cin, Cout multiples of 32): the 3x3 layers of
+ * Independent_EN in the CQE training step (newtrain_cqe_real.py:128-174).  Pixel-major records become MFMA operands through the
+ * hardware transpose read ds_read_b64_tr_b16 (masic_amd/csrc/wgrad_f16k.hip).  dw: float32 [Cout][Cin][3][3]; workspace:
+ * masic_conv3x3_wgrad_f16k_workspace_bytes bytes (zeroed by the call). */
+size_t masic_conv3x3_wgrad_f16k_workspace_bytes(int Cin, int Cout);
+int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                             int B, int Cin, int Cout, int H, int W, void* stream);
 /* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
  * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */

@@ -1,0 +1,275 @@
+// wgrad_f16k.hip -- weight gradient of the 3x3 stride-1 convolutions of Independent_EN on F16K operands (gfx950 / MI355X).
+//
+// Reference: what torch autograd computes (convolution_backward) for the 36 `conv3x3` layers of the CQE network
+// (coremasic/mywork/MASIC.py:149-164, :1436-1501; compressai/layers/layers.py:81-83, :160-190) in the training step of
+// newtrain_cqe_real.py:128-174:
+//     dW[co][ci][kh][kw] = sum_{b,r,c} dy[b][co][r][c] * x[b][ci][r + kh - 1][c + kw - 1]
+// a GEMM per tap whose K dimension is the PIXEL index.  Round 1 ran it on the tap-generic float32-tile kernel
+// (conv_wgrad.hip: conv_wgrad_f32<1, 3, true>): 1.8-2.8 ms per layer at 8 x 96 x 512 x 512, 37 % of the CQE training step.
+//
+// Here both operands are read in the layout the forward / input-gradient kernels already use, F16K = [B][C/16][H*W][16] bf16
+// (half the bytes of the float32 NCHW tensors, no conversion pass), and the pixel-major records are turned into MFMA operands
+// (8 consecutive k = pixels of one channel per lane) by the hardware transpose read `ds_read_b64_tr_b16`: a 16-lane group reads
+// 4 records (pixels) x 16 channels and every lane receives its channel's 4 pixels.
+//
+// Workgroup = NQ x 3 waves: wave (qb, kh) owns the 32 input channels of block qb, kernel row kh, all MA 32-channel output
+// blocks and the three taps of its row: MA x 3 accumulators of 32 x 32 (dW_t[co][ci]); per k-step of 16 pixels it reads MA
+// A fragments (dy) and 3 B fragments (x at column shifts -1, 0, +1: the same records 32 bytes apart) for MA x 3 MFMAs.
+// Pixel tiles of 4 rows x 32 columns (+ halo) are staged by `buffer_load ... lds` DMA, three buffers deep with a counted vmcnt
+// (every wave issues the same number of DMA instructions per tile, unused slots go to a sink: the tile after next stays in flight
+// across the barrier; padding pixels and ragged edges read as zeros through the buffer range check); the planes of consecutive 16-channel blocks sit 128 bytes
+// (mod 256) apart so that the two 16-lane groups of a half wave never share a bank.  Workgroups take a strided share of the
+// tiles and add their partial dW into a [tap][co][ci] workspace with float atomics (ci contiguous: full 128-byte segments);
+// a last pass transposes it into the weight layout.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int TR = 4, TC = 32;                       // tile: output rows x columns
+constexpr int GP = TR * TC * 32 + 128;               // bytes per 16-channel plane of the dy tile (+128: bank offset between planes)
+constexpr int XW = TC + 2, XR = TR + 2;              // patch columns / rows
+constexpr int XROW = XW * 32;                        // 1088 bytes per patch row
+constexpr int XP = XR * XROW;                        // 6528 bytes per 16-channel plane of the x patch (= 128 mod 256)
+
+struct Wg3Args {
+    const unsigned short* g16;    // dy  F16K [B][CA16][H*W][16]
+    const unsigned short* x16;    // x   F16K [B][CQ16][H*W][16]
+    float* ws;                    // [9][CA][CQ] float32, zeroed by the caller
+    int B, H, W, CA16, CQ16, CA, CQ;
+    int a0, q0;                   // first output / input channel of this launch's channel group
+    int tiles_w, tiles_h, ntiles;
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ void tr_read(v2u& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ void depend(v2u& a, v2u& b) { asm volatile("" : "+v"(a), "+v"(b)); }   // uses of a, b stay behind the preceding wait
+
+__device__ __forceinline__ bf16x8 frag(const v2u& lo, const v2u& hi) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+
+template <int MA, int NQ>
+__global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
+    constexpr int NW = NQ * 3;
+    constexpr int GBYTES = 2 * MA * GP, XBYTES = 2 * NQ * XP, BUF = GBYTES + XBYTES;
+    constexpr int NBUF = 3;
+    constexpr int NI_G = 2 * MA * TR, NI_X = 2 * NQ * XR * 2, NI = NI_G + NI_X, NPW = (NI + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = wave / 3, kh = wave - 3 * qb;
+    const int HW = a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g16, 0, a.B * a.CA16 * HW * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, 0, a.B * a.CQ16 * HW * 32, 0x00020000);
+
+    // ---- this wave's DMA instructions (tile independent part): instruction i = wave + j * NW
+    //   i < NI_G: dy plane (block, row): 32 pixels x 32 bytes;  else x plane (block, patch row, part): part 0 = patch columns 0..31,
+    //   part 1 = columns 32, 33 (lanes 0..3 only)
+    int d_lds[NPW], d_blk[NPW], d_row[NPW], d_col[NPW];
+    bool d_isx[NPW], d_live[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int i = wave + j * NW;
+        d_live[j] = i < NI;
+        d_isx[j] = i >= NI_G;
+        if (!d_isx[j]) {
+            d_blk[j] = i / TR;
+            d_row[j] = i - d_blk[j] * TR;
+            d_col[j] = lane >> 1;
+            d_lds[j] = d_blk[j] * GP + d_row[j] * (TC * 32);
+        } else {
+            const int k = i - NI_G, part = k & 1, br = k >> 1;
+            d_blk[j] = br / XR;
+            d_row[j] = br - d_blk[j] * XR - 1;                       // image row relative to the tile's first row
+            d_col[j] = part * 32 + (lane >> 1) - 1;                  // image column relative to the tile's first column
+            d_lds[j] = GBYTES + d_blk[j] * XP + (d_row[j] + 1) * XROW + part * 1024;
+            if (part == 1 && lane >= 4) d_live[j] = false;
+        }
+    }
+    // every wave issues exactly NPW DMA instructions per call (dead slots and calls past the last tile read out of range into
+    // the sink), so `s_waitcnt vmcnt(NPW)` always means "everything but the most recent call has landed"
+    auto issue = [&](int tile, int buf) {
+        const bool real = tile < a.ntiles;
+        const int tt = real ? tile : 0;
+        const int b = tt / (a.tiles_w * a.tiles_h), t = tt - b * (a.tiles_w * a.tiles_h);
+        const int r0 = (t / a.tiles_w) * TR, c0 = (t % a.tiles_w) * TC;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int i = wave + j * NW;
+            const int r = r0 + d_row[j], c = c0 + d_col[j];
+            const bool ok = real && r >= 0 && r < a.H && c >= 0 && c < a.W;
+            const int voff = ok ? (r * a.W + c) * 32 + (lane & 1) * 16 : 0x7ffffff0;
+            if (!real || i >= NI) {
+                dma16(rg, lds + NBUF * BUF, 0x7ffffff0, 0);
+            } else if (d_isx[j]) {
+                if (d_live[j]) dma16(rx, lds + buf * BUF + d_lds[j], voff, ((b * a.CQ16 + (a.q0 >> 4) + d_blk[j]) * HW) * 32);
+            } else {
+                dma16(rg, lds + buf * BUF + d_lds[j], voff, ((b * a.CA16 + (a.a0 >> 4) + d_blk[j]) * HW) * 32);
+            }
+        }
+    };
+
+    f32x16 acc[MA][3];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.0f;
+
+    // lane part of the transposed-read addresses: 16-lane group g4 = (channel half, k half); lane 4q + p of a group supplies
+    // row (pixel) q, columns (channels) 4p .. 4p+3 of its 4 x 16 block
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned la = ldsb + (g4 & 1) * GP + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;                                          // + ma * 2 * GP
+    const unsigned lb = ldsb + GBYTES + (2 * qb + (g4 & 1)) * XP + kh * XROW + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;        // + kw * 32
+
+    int tile = blockIdx.x, buf = 0;
+    issue(tile, 0);
+    issue(tile + gridDim.x, 1);
+    for (; tile < a.ntiles; tile += gridDim.x, buf = buf == NBUF - 1 ? 0 : buf + 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");   // this tile's records have landed (the next tile's may still fly) ...
+        __builtin_amdgcn_s_barrier();                                // ... for every wave, and everyone is done reading the buffer of the tile before
+        issue(tile + 2 * gridDim.x, buf >= 1 ? buf - 1 : NBUF - 1);  // two tiles ahead, into that free buffer
+        const unsigned ba = la + buf * BUF, bb = lb + buf * BUF;
+        v2u af[2][MA][2], bfr[2][3][2];
+        auto request = [&](auto kc, auto pc) {
+            constexpr int ks = decltype(kc)::value, pb = decltype(pc)::value;
+            constexpr int rr = ks >> 1, ch = ks & 1;                 // k-step = 16 pixels: row rr of the tile, column half ch
+            sfor<0, MA>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                tr_read<m * 2 * GP + (rr * TC + ch * 16) * 32>(af[pb][m][0], ba);
+                tr_read<m * 2 * GP + (rr * TC + ch * 16) * 32 + 128>(af[pb][m][1], ba);
+            });
+            sfor<0, 3>([&](auto tc) {
+                constexpr int kw = decltype(tc)::value;
+                tr_read<rr * XROW + (ch * 16 + kw) * 32>(bfr[pb][kw][0], bb);
+                tr_read<rr * XROW + (ch * 16 + kw) * 32 + 128>(bfr[pb][kw][1], bb);
+            });
+        };
+        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        sfor<0, TR * 2>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value, pb = ks & 1;
+            if constexpr (ks + 1 < TR * 2) request(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (ks + 1) & 1>{});
+            constexpr int pending = ks + 1 < TR * 2 ? 2 * (MA + 3) : 0;     // LDS returns in order: the requests for ks+1 may stay out
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
+            sfor<0, MA>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                depend(af[pb][m][0], af[pb][m][1]);
+            });
+            sfor<0, 3>([&](auto tc) {
+                constexpr int kw = decltype(tc)::value;
+                depend(bfr[pb][kw][0], bfr[pb][kw][1]);
+            });
+            sfor<0, 3>([&](auto tc) {
+                constexpr int kw = decltype(tc)::value;
+                const bf16x8 bq = frag(bfr[pb][kw][0], bfr[pb][kw][1]);
+                sfor<0, MA>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    acc[m][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), bq, acc[m][kw], 0, 0, 0);
+                });
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- reduce into ws[tap][co][ci]: accumulator row (co) = 8 (e >> 2) + 4 h + (e & 3), column (ci) = lane & 31
+    const int j = lane & 31, h = lane >> 5;
+    const int ci = a.q0 + qb * 32 + j;
+    if (ci < a.CQ) {
+#pragma unroll
+        for (int m = 0; m < MA; ++m)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float* wp = a.ws + ((size_t)(kh * 3 + kw) * a.CA + a.a0 + m * 32 + 4 * h) * a.CQ + ci;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = a.a0 + m * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+                    if (co < a.CA) atomicAdd(wp + (size_t)((e & 3) + 8 * (e >> 2)) * a.CQ, acc[m][kw][e]);
+                }
+            }
+    }
+}
+
+// ws [9][CA][CQ] -> dw [CA][CQ][9]
+__global__ __launch_bounds__(256) void wgrad3_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int AQ) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)9 * AQ; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i / AQ);
+        const size_t aq = i - (size_t)t * AQ;
+        dw[aq * 9 + t] = ws[i];
+    }
+}
+
+template <int MA, int NQ>
+void launch(const Wg3Args& a, int grid, hipStream_t st) {
+    auto kfn = wgrad3x3_f16k<MA, NQ>;
+    static bool attr_set = false;
+    constexpr size_t lds = 3 * (size_t)(2 * MA * GP + 2 * NQ * XP) + 1024;
+    static_assert(lds <= 160 * 1024, "three tile buffers must fit the LDS");
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NQ * 3 * 64), lds, st, a);
+}
+
+}  // namespace
+
+extern "C" size_t masic_conv3x3_wgrad_f16k_workspace_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * sizeof(float); }
+
+// dW [Cout][Cin][3][3] (float32) of Conv2d(Cin -> Cout, k3, s1, p1) from x and dy in F16K (Cin, Cout multiples of 32).
+extern "C" int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                                        int B, int Cin, int Cout, int H, int W, void* stream) {
+    MASIC_REQUIRE(x_f16k && dy_f16k && dw && workspace, MASIC_ERR_ARG, "conv3x3_wgrad_f16k: null pointer");
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED,
+                  "conv3x3_wgrad_f16k: needs Cin, Cout multiples of 32");
+    MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv3x3_wgrad_f16k: tensor too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+        masic_set_error("conv3x3_wgrad_f16k: workspace memset failed");
+        return MASIC_ERR_LAUNCH;
+    }
+    Wg3Args a{(const unsigned short*)dy_f16k, (const unsigned short*)x_f16k, (float*)workspace, B, H, W, Cout / 16, Cin / 16, Cout, Cin, 0, 0,
+              ceil_div(W, TC), ceil_div(H, TR), 0};
+    a.ntiles = a.tiles_w * a.tiles_h * B;
+    // channel groups of up to 96 output x 64 input channels (6 waves: at most two per SIMD, so the 9 accumulator tiles of a wave
+    // fit its register budget); each group: one workgroup per CU taking a strided share of the pixel tiles
+    for (int a0 = 0; a0 < Cout; a0 += 96)
+        for (int q0 = 0; q0 < Cin; q0 += 64) {
+            a.a0 = a0; a.q0 = q0;
+            const int ma = (Cout - a0 >= 96 ? 96 : Cout - a0) / 32, nq = (Cin - q0 >= 64 ? 64 : Cin - q0) / 32;
+            const int grid = a.ntiles < 256 ? a.ntiles : 256;
+            switch (ma * 4 + nq) {
+                case 1 * 4 + 1: launch<1, 1>(a, grid, st); break;
+                case 1 * 4 + 2: launch<1, 2>(a, grid, st); break;
+                case 2 * 4 + 1: launch<2, 1>(a, grid, st); break;
+                case 2 * 4 + 2: launch<2, 2>(a, grid, st); break;
+                case 3 * 4 + 1: launch<3, 1>(a, grid, st); break;
+                default: launch<3, 2>(a, grid, st); break;
+            }
+        }
+    const int AQ = Cin * Cout;
+    int tb = (9 * AQ + 255) / 256;
+    if (tb > 2048) tb = 2048;
+    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (const float*)workspace, dw, AQ);
+    return masic_launch_status("conv3x3_wgrad_f16k");
+}

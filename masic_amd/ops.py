@@ -980,3 +980,13 @@ def conv_a_gdn_dual(x, packed, bias, gdn, in_coff=0, products=3):
     check(lib.masic_conv_a_gdn_dual_fwd(_p(x), _p(packed), _p(bias), _p(gdn[0]), _gdn_flags(gdn[1], products), _p(pre), _p(y), B, H, W, ctot, in_coff, _stream()),
           "conv_a_gdn_dual_fwd")
     return pre, y, Ho, Wo
+
+
+def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
+    """dW [Cout, Cin, 3, 3] (float32) of Conv2d(k3, s1, p1) from x and dy in F16K (bf16 operands, float32 accumulate)."""
+    if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:
+        raise RuntimeError("masic_amd.conv3x3_wgrad_f16k: F16K buffer sizes do not match (B, C, H, W)")
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x16.device)
+    ws = torch.empty(lib.masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout) // 4, dtype=torch.float32, device=x16.device)
+    check(lib.masic_conv3x3_wgrad_f16k(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, _stream()), "conv3x3_wgrad_f16k")
+    return dw

@@ -312,3 +312,16 @@ def test_independent_en_f16k_path_vs_oracle_and_nchw_path():
         e = assert_close(out[k], ref[k], "cqe f16k vs oracle:" + k, 2e-2)
         e2 = assert_close(out[k], old[k], "cqe f16k vs NCHW bf16 path:" + k, 2e-2)
         print(f"Independent_EN F16K path, {k}: {e:.2e} from the oracle, {e2:.2e} from the NCHW bf16-operand path")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 32, 32, 16, 64), (1, 64, 96, 24, 40), (2, 96, 64, 9, 70), (1, 96, 96, 64, 64), (1, 128, 32, 8, 32)])
+def test_conv3x3_wgrad_f16k_vs_torch(B, Cin, Cout, H, W):
+    """Weight gradient of the 3x3 stride-1 layers from F16K operands (transposed LDS reads; ragged tiles, every channel-group
+    combination) against torch's convolution weight gradient on the bf16-rounded operands."""
+    from masic_amd import ops
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(_bf(x), (Cout, Cin, 3, 3), _bf(dy), padding=1)
+    got = ops.conv3x3_wgrad_f16k(ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV)), B, Cin, Cout, H, W)
+    assert_close(got, ref, f"conv3x3_wgrad_f16k {Cin}->{Cout}", 1e-5)
