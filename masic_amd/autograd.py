@@ -62,8 +62,11 @@ class ConvFn(Function):
         return gx, gw, gb, None, None
 
 
-def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True):
-    """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW."""
+_WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
+
+
+def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None):
+    """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW (x16: x in F16K if the caller has it)."""
     g = _c(g)
     if act != ops.ACT_NONE:
         g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=act)
@@ -72,6 +75,12 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
     gx = gw = gb = None
     from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
+    g16 = [None]
+
+    def g_f16k():                     # dy in F16K, converted once for the input gradient and the weight gradient
+        if g16[0] is None:
+            g16[0] = ops.nchw_to_f16k(g)
+        return g16[0]
     if need_gx:
         d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
         if (d.Ho, d.Wo) != (Hi, Wi):
@@ -79,18 +88,23 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
         if _gemm_1x1(mod):
             # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
             wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
-            gx = ops.gemm_f16k(ops.nchw_to_f16k(g), wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
+            gx = ops.gemm_f16k(g_f16k(), wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
         elif _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
             # bf16 mode: the DMA-staged F16K kernel of the inference path (conv_f16k.hip) -- g converted once to the channel-blocked
             # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
             d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)
             if ops.conv_f16k_supported(d16):
-                gx = ops.conv2d_f16k(ops.nchw_to_f16k(g), ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
+                gx = ops.conv2d_f16k(g_f16k(), ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
         if gx is None:
             gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
     if need_gw:
-        d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
-        gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
+        if (_WGRAD3_F16K and _mnn._PRECISION != PREC_F32 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
+                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin):
+            # 3x3 stride-1 layers (Independent_EN): both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
+            gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g_f16k(), B, Cin, Cout, Hi, Wi)
+        else:
+            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
+            gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
     if need_gb:
         gb = ops.channel_sum(g)
     return gx, gw, gb
