@@ -1008,6 +1008,8 @@ class Enhancement_Block(nn.Module):
         self.RB3 = ResidualBlock(shape, shape)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and _ag.enhancement_block_supported(self, x) and (x.requires_grad or self.RB1.conv1.weight.requires_grad):
+            return _ag.enhancement_block(self, x)   # bf16 mode training: one node, forward and backward on F16K buffers
         t = self.RB2(self.RB1(x))
         return self.RB3(t, extra_identity=x)        # (RB3(t)) + x, the outer add fused into RB3's last conv
 

@@ -204,6 +204,16 @@ int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw,
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */
 int masic_conv_f16k_res_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
                             void* y_f16k, const masic_conv_desc_t* d, void* stream);
+/* the same with the pieces the CQE training step needs (masic_amd/autograd.py: EnhancementBlockFn), everything F16K:
+ *   y = act(conv(x) + bias) * act'(mask) + res1 + res2;  y_pre (optional) = the value before the residual adds.
+ * Forward: mask NULL, y_pre = the LeakyReLU output (its sign is the mask of the backward).  Input gradient (d->transposed on the same
+ * weight): mask = the producer's activation output, mask_slope 0.01 (LeakyReLU) / 0 (ReLU), res1 / res2 = gradients of the identity paths. */
+int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                               const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream);
+/* F16K elementwise / reduction helpers of that backward: out = g * act'(y); out[c] = sum over (b, pixel) of x (a bias gradient) */
+int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream);
+size_t masic_f16k_channel_sum_workspace_bytes(int B, int C);
+int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream);
 /* a layer with few output channels (Independent_EN.conv2: 96 -> 3 + the picture as residual, MASIC.py:1492-1496) on the same kernels:
  * `d` describes the convolution with its weight zero-padded to Cout = 32; y_nchw / res32 are float32 [B][cout_store][Ho][Wo]. */
 int masic_conv_f16k_few_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* res32, float* y_nchw,

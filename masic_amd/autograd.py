@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import PREC_F32
+from ._lib import PREC_BF16, PREC_F32
 
 PEDESTAL = 2.0 ** -36
 
@@ -312,6 +312,76 @@ class AddFn(Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+class EnhancementBlockFn(Function):
+    """Enhancement_Block -- three residual blocks and the skip over all of them (reference MASIC.py:149-164) -- as ONE node of the CQE
+    training step in bf16 mode, forward AND backward on F16K buffers (conv_f16k.hip, wgrad_f16k.hip, f16k_ops.hip):
+
+      forward   x -> F16K once; per block  t = L(c1(x)),  u = L(c2(t)) (stored by the same launch as `y_pre`),  o = u + x (+ x0 on
+                the last block); out -> float32 NCHW once.  Saved: x0, t_i, u_i, o_1, o_2 in bf16 (18 B / element against 48 B of
+                the node-per-layer float32 graph).
+      backward  per block, last to first:  g_u = g_o * L'(u);  dW2 = wgrad(t, g_u);  g_t = dgrad_c2(g_u) * L'(t) (mask in the
+                epilogue);  dW1 = wgrad(x_in, g_t);  g_x = dgrad_c1(g_t) + g_o (+ g_out on the first block: the outer skip) -- the
+                adds are the residual operands of the same epilogue.  Gradients travel between layers in bf16 F16K (float32
+                accumulate inside every kernel), as the forward activations of this mode do.
+    """
+
+    @staticmethod
+    def forward(ctx, x, eb, *params):
+        x = _c(x)
+        B, C, H, W = x.shape
+        x0 = ops.nchw_to_f16k(x)
+        saved, cur = [x0], x0
+        for i, rb in enumerate((eb.RB1, eb.RB2, eb.RB3)):
+            t = rb.conv1.run_f16k_res(cur, B, H, W, act=ops.ACT_LEAKY)
+            u = ops.f16k_empty(B, C, H, W, x.device)
+            cur = rb.conv2.run_f16k_res(t, B, H, W, act=ops.ACT_LEAKY, res1=cur, res2=x0 if i == 2 else None, res_ctot=C, y_pre=u)
+            saved += [t, u] if i == 2 else [t, u, cur]
+        ctx.eb, ctx.shape = eb, (B, C, H, W)
+        ctx.save_for_backward(*params, *saved)
+        return ops.f16k_to_nchw_dev(cur, B, C, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        params, (x0, t1, u1, o1, t2, u2, o2, t3, u3) = ctx.saved_tensors[:12], ctx.saved_tensors[12:]
+        g_out = ops.nchw_to_f16k(_c(g))
+        blocks = ((ctx.eb.RB1, x0, t1, u1), (ctx.eb.RB2, o1, t2, u2), (ctx.eb.RB3, o2, t3, u3))
+        d16 = ops.make_conv_desc(B, C, H, W, C, 3, 3, 1, 1, transposed=True, in_ctot=C, out_ctot=C, prec=PREC_BF16)
+        grads = [None] * 12
+        go = g_out
+        for i in (2, 1, 0):
+            rb, x_in, t, u = blocks[i]
+            w1, w2 = params[4 * i], params[4 * i + 2]
+            gu = ops.f16k_act_bwd(go, u, 0.01)
+            grads[4 * i + 2] = ops.conv3x3_wgrad_f16k(t, gu, B, C, C, H, W)
+            grads[4 * i + 3] = ops.f16k_channel_sum(gu, B, C, H * W)
+            gt = ops.conv2d_f16k_res(gu, ops.pack_conv_f16k_weight(w2.detach(), d16), None, d16, res_ctot=C, mask=t, mask_slope=0.01)
+            del gu
+            grads[4 * i] = ops.conv3x3_wgrad_f16k(x_in, gt, B, C, C, H, W)
+            grads[4 * i + 1] = ops.f16k_channel_sum(gt, B, C, H * W)
+            go = ops.conv2d_f16k_res(gt, ops.pack_conv_f16k_weight(w1.detach(), d16), None, d16, res1=go, res2=g_out if i == 0 else None, res_ctot=C)
+            del gt
+        gx = ops.f16k_to_nchw_dev(go, B, C, H, W) if ctx.needs_input_grad[0] else None
+        return (gx, None) + tuple(grads)
+
+
+def enhancement_block_supported(eb, x):
+    """bf16 mode, 3x3 stride-1 blocks of C % 32 channels without a channel-changing skip, F16K kernels available for the shape."""
+    from . import nn as _mnn
+    if _mnn._PRECISION != PREC_BF16 or _mnn._FP8 or x.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    convs = [c for rb in (eb.RB1, eb.RB2, eb.RB3) for c in (rb.conv1, rb.conv2)]
+    return (C % 32 == 0 and all(rb.skip is None for rb in (eb.RB1, eb.RB2, eb.RB3))
+            and all(c.bias is not None and c.in_channels == C and c.out_channels == C and c._geometry() == (3, 3, 1, 1) for c in convs)
+            and eb.f16k_supported(B, H, W))
+
+
+def enhancement_block(eb, x):
+    params = [p for rb in (eb.RB1, eb.RB2, eb.RB3) for c in (rb.conv1, rb.conv2) for p in (c.weight, c.bias)]
+    return EnhancementBlockFn.apply(x, eb, *params)
 
 
 def cat(*ts):

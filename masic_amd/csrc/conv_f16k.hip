@@ -124,6 +124,18 @@ __device__ __forceinline__ void add_f16k_residual(f32x16& t, const unsigned shor
         t[4 * q + 3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
     }
 }
+// t *= act'(mask): the backward of ReLU / LeakyReLU(0.01) as an epilogue of the input-gradient convolution -- mask = the forward
+// activation's OUTPUT in F16K (its sign is the pre-activation's), addressed like a residual tensor
+__device__ __forceinline__ void mul_f16k_actmask(f32x16& t, const unsigned short* mask, unsigned rec_stride, float slope) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint2 r = *reinterpret_cast<const uint2*>(mask + (size_t)(q >> 1) * rec_stride + 8 * (q & 1));
+        t[4 * q + 0] *= __builtin_bit_cast(float, r.x << 16) > 0.0f ? 1.0f : slope;
+        t[4 * q + 1] *= __builtin_bit_cast(float, r.x & 0xffff0000u) > 0.0f ? 1.0f : slope;
+        t[4 * q + 2] *= __builtin_bit_cast(float, r.y << 16) > 0.0f ? 1.0f : slope;
+        t[4 * q + 3] *= __builtin_bit_cast(float, r.y & 0xffff0000u) > 0.0f ? 1.0f : slope;
+    }
+}
 __device__ __forceinline__ void store_f16k_tile(const f32x16& t, unsigned short* rec, unsigned rec_stride) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -172,7 +184,10 @@ struct F16kArgs {
     const unsigned short* res2;   //   (ResidualBlock / Enhancement_Block identities, compressai/layers/layers.py:189, MASIC.py:163)
     int res_ctot;
     unsigned short* y16_pre;      // fused GDN + F16K output: also store the convolution's result BEFORE the GDN (same view), or null --
-                                  //   what the GDN backward of a training step needs (masic_amd/autograd.py: AnalysisFn / SynthesisFn)
+                                  //   what the GDN backward of a training step needs (masic_amd/autograd.py: AnalysisFn / SynthesisFn);
+                                  //   residual form: the activation's output BEFORE the residual adds (view of res_ctot channels)
+    const unsigned short* mask16; // F16K output only: multiply by act'(mask) before the residual adds (mask: F16K of res_ctot channels;
+    float mask_slope;             //   slope for mask <= 0: 0.01 LeakyReLU, 0 ReLU) -- input gradients of the training step
     const float* res32;           // float32 NCHW output only: residual [B][cout_store][Ho][Wo] added after the activation, or null
     int cout_store;               // float32 NCHW output: channels actually stored (< Cout when the weight was zero-padded to a multiple of 32)
     const float* wscale;          // fp8 operands: per-output-channel dequantisation factor (weight scale x input scale), else null
@@ -743,12 +758,14 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 const int c16 = (a.out_coff + m0) >> 4;
                 unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * oplane + opix) * 16 + 8 * h;
                 const unsigned op16 = (unsigned)oplane * 16;
-                if (a.res1 != nullptr) {
+                if (a.res1 != nullptr || a.mask16 != nullptr || (!GDN && a.y16_pre != nullptr)) {
                     const size_t ro = (((size_t)b * (a.res_ctot >> 4) + (m0 >> 4)) * oplane + opix) * 16 + 4 * h;
 #pragma unroll
                     for (int m = 0; m < NM; ++m)
                         if (m0 + m * 32 < a.Cout) {
-                            add_f16k_residual(acc[n][m], a.res1 + ro + (size_t)(2 * m) * op16, op16);
+                            if (a.mask16 != nullptr) mul_f16k_actmask(acc[n][m], a.mask16 + ro + (size_t)(2 * m) * op16, op16, a.mask_slope);
+                            if (!GDN && a.y16_pre != nullptr) store_f16k_tile(acc[n][m], a.y16_pre + ro + 4 * h + (size_t)(2 * m) * op16, op16);
+                            if (a.res1 != nullptr) add_f16k_residual(acc[n][m], a.res1 + ro + (size_t)(2 * m) * op16, op16);
                             if (a.res2 != nullptr) add_f16k_residual(acc[n][m], a.res2 + ro + (size_t)(2 * m) * op16, op16);
                         }
                 }
@@ -1080,7 +1097,22 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale = nullptr, void* y_f8k = nullptr, float out_inv_scale = 0.0f,
                 const void* res1 = nullptr, const void* res2 = nullptr, int res_ctot = 0, const float* res32 = nullptr, int cout_store = 0,
-                void* y_pre = nullptr);
+                void* y_pre = nullptr, const void* mask16 = nullptr, float mask_slope = 0.0f);
+}
+
+// Extended residual form for the training step of Independent_EN (masic_amd/autograd.py: EnhancementBlockFn), everything F16K:
+//   y = act(conv(x) + bias) * act'(mask) + res1 + res2,   y_pre (optional) = the value before the residual adds.
+// Forward: mask NULL, y_pre = the LeakyReLU output the backward needs for its mask.  Backward (input gradient = the transposed
+// convolution on the same weight): mask = the forward activation's output of the PRODUCER layer, mask_slope = 0.01 / 0 (LeakyReLU /
+// ReLU), res1 / res2 = the gradients arriving over the identity paths.  mask, res1, res2, y_pre: res_ctot channels.
+extern "C" int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                                          const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream) {
+    MASIC_REQUIRE(d != nullptr && y_f16k != nullptr, MASIC_ERR_ARG, "conv_f16k_res_ex_fwd: null pointer");
+    MASIC_REQUIRE(res1 != nullptr || res2 == nullptr, MASIC_ERR_ARG, "conv_f16k_res_ex_fwd: res2 without res1");
+    MASIC_REQUIRE((res1 == nullptr && mask == nullptr && y_pre_f16k == nullptr) || (res_ctot % 16 == 0 && res_ctot >= d->Cout), MASIC_ERR_SHAPE,
+                  "conv_f16k_res_ex_fwd: residual / mask / pre tensors need >= Cout channels, a multiple of 16");
+    return f16k_launch(x_f16k, w_packed, bias, nullptr, nullptr, 0, 0, nullptr, y_f16k, d, stream, nullptr, nullptr, 0.0f, res1, res2, res_ctot, nullptr, 0,
+                       y_pre_f16k, mask, mask_slope);
 }
 
 // masic_conv_f16k_gdn_fwd with F16K output that ALSO stores the convolution's result before the GDN (y_pre_f16k, same layout as
@@ -1178,7 +1210,7 @@ namespace {
 int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                 const void* gdn_packed, int gdn_inverse, int d2s, float* y_nchw, void* y_f16k,
                 const masic_conv_desc_t* d, void* stream, const float* wscale, void* y_f8k, float out_inv_scale,
-                const void* res1, const void* res2, int res_ctot, const float* res32, int cout_store, void* y_pre) {
+                const void* res1, const void* res2, int res_ctot, const float* res32, int cout_store, void* y_pre, const void* mask16, float mask_slope) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     const bool f8 = d->prec == MASIC_PREC_FP8;
@@ -1201,7 +1233,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, (unsigned short*)y_pre, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
+               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, (unsigned short*)y_pre, (const unsigned short*)mask16, mask_slope, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : (cout_store > 0 ? cout_store : d->out_ctot), d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,

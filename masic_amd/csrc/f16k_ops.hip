@@ -110,7 +110,75 @@ __global__ __launch_bounds__(256) void f16k_to_nchw_kernel(const unsigned short*
         if (c8 * 8 + i < C) yb[(size_t)(c8 * 8 + i) * HW] = v[i];
 }
 
+// g' = g * act'(y) on F16K buffers (y = the forward activation's output: its sign is the pre-activation's)
+__global__ __launch_bounds__(256) void f16k_act_bwd_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y, uint4* __restrict__ out, size_t n16, float slope) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 a = g[i], m = y[i];
+        const unsigned av[4] = {a.x, a.y, a.z, a.w}, mv[4] = {m.x, m.y, m.z, m.w};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float lo = bf_lo(av[k]) * (bf_lo(mv[k]) > 0.0f ? 1.0f : slope);
+            const float hi = bf_hi(av[k]) * (bf_hi(mv[k]) > 0.0f ? 1.0f : slope);
+            o[k] = pack2(lo, hi);
+        }
+        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// per-channel sums of an F16K tensor: block (pixel chunk, 16-channel block, image) -> float32 partials [B * chunks][C], then a reduce
+__global__ __launch_bounds__(256) void f16k_channel_sum_stage1(const uint4* __restrict__ x, float* __restrict__ partial, int C16, int HW, int chunks) {
+    const int chunk = blockIdx.x, cb = blockIdx.y, b = blockIdx.z;
+    const int per = (HW + chunks - 1) / chunks;
+    const int lo = chunk * per, hi = lo + per < HW ? lo + per : HW;
+    const uint4* p = x + ((size_t)b * C16 + cb) * HW * 2;          // 2 uint4 per record
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int half = threadIdx.x & 1;                                // which 8 channels of the record
+    for (int px = lo + (threadIdx.x >> 1); px < hi; px += 128) {
+        const uint4 q = p[2 * (size_t)px + half];
+        acc[0] += bf_lo(q.x); acc[1] += bf_hi(q.x); acc[2] += bf_lo(q.y); acc[3] += bf_hi(q.y);
+        acc[4] += bf_lo(q.z); acc[5] += bf_hi(q.z); acc[6] += bf_lo(q.w); acc[7] += bf_hi(q.w);
+    }
+    __shared__ float red[256][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 16) {                                          // channel c of the block: half c >> 3, slot c & 7
+        const int c = threadIdx.x;
+        float s = 0.0f;
+        for (int t = (c >> 3); t < 256; t += 2) s += red[t][c & 7];
+        partial[((size_t)(b * chunks + chunk)) * (C16 * 16) + cb * 16 + c] = s;
+    }
+}
+__global__ __launch_bounds__(64) void f16k_channel_sum_stage2(const float* __restrict__ partial, float* __restrict__ out, int C, int n) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)partial[(size_t)i * C + c];
+    out[c] = (float)s;
+}
+
 }  // namespace
+
+// out = g * act'(y), all F16K of n bf16 elements (n % 8 == 0); slope: 0.01 LeakyReLU, 0 ReLU
+extern "C" int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream) {
+    MASIC_REQUIRE(g && y && out && n % 8 == 0, MASIC_ERR_ARG, "f16k_act_bwd: null pointer or n %% 8 != 0");
+    const size_t n16 = n / 8;
+    int nb = (int)((n16 + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    if (n16) hipLaunchKernelGGL(f16k_act_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (const uint4*)y, (uint4*)out, n16, slope);
+    return masic_launch_status("f16k_act_bwd");
+}
+
+constexpr int F16K_CS_CHUNKS = 32;
+extern "C" size_t masic_f16k_channel_sum_workspace_bytes(int B, int C) { return (size_t)B * F16K_CS_CHUNKS * round_up(C, 16) * sizeof(float); }
+// out[c] = sum over (b, pixel) of an F16K tensor [B][C/16][HW][16] (the bias gradient of a layer whose dy is kept in F16K)
+extern "C" int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream) {
+    MASIC_REQUIRE(x && out && workspace && B > 0 && C > 0 && C % 16 == 0 && HW > 0, MASIC_ERR_ARG, "f16k_channel_sum: bad argument");
+    hipLaunchKernelGGL(f16k_channel_sum_stage1, dim3(F16K_CS_CHUNKS, C / 16, B), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (float*)workspace, C / 16, HW, F16K_CS_CHUNKS);
+    hipLaunchKernelGGL(f16k_channel_sum_stage2, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, out, C, B * F16K_CS_CHUNKS);
+    return masic_launch_status("f16k_channel_sum");
+}
 
 // dst[:, dst_coff : dst_coff + C] = (minv ? warp(src, minv) : src) * (gate ? gate[:, gate_c] : 1); src: F16K of exactly C channels,
 // C % 8 == 0 and dst_coff % 8 == 0; minv: the [B,3,3] normalised sampling matrices of masic_warp_matrix / masic_amd.homography.

@@ -248,12 +248,13 @@ class _PackedWeightMixin:
                                           (packed_gdn_f16k(gdn), gdn.inverse), products=products)
         return pre, y, desc.Ho, desc.Wo
 
-    def run_f16k_res(self, x16, B, Hi, Wi, act=ops.ACT_NONE, res1=None, res2=None, res_ctot=0, out16=None, out_ctot=None, out_coff=0):
-        """Inference-only: F16K -> F16K (optionally a channel view of `out16`) with F16K residual tensors added after the activation."""
+    def run_f16k_res(self, x16, B, Hi, Wi, act=ops.ACT_NONE, res1=None, res2=None, res_ctot=0, out16=None, out_ctot=None, out_coff=0, y_pre=None):
+        """No autograd: F16K -> F16K (optionally a channel view of `out16`) with F16K residual tensors added after the activation;
+        `y_pre` (F16K, res_ctot channels) receives the activation's output before the adds (what a backward needs for its mask)."""
         oc = (self.out_channels + 15) // 16 * 16 if out_ctot is None else out_ctot
         desc = self._desc_f16k(B, Hi, Wi, out_ctot=oc, out_coff=out_coff, act=act)
         return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc, y16=out16,
-                                   res1=res1, res2=res2, res_ctot=res_ctot)
+                                   res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
 
     def few_supported(self, B, Hi, Wi):
         kh, kw, s_, p_ = self._geometry()

@@ -915,8 +915,10 @@ def f16k_to_nchw_dev(x16, B, C, H, W, src_ctot=None, src_coff=0):
     return y
 
 
-def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res_ctot=0):
-    """F16K in -> F16K out (channel view desc.out_ctot / out_coff of `y16`, or a fresh buffer) + residual F16K tensors."""
+def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res_ctot=0, mask=None, mask_slope=0.0, y_pre=None):
+    """F16K in -> F16K out (channel view desc.out_ctot / out_coff of `y16`, or a fresh buffer) + residual F16K tensors.
+    Training-step pieces (masic_conv_f16k_res_ex_fwd): `mask` multiplies by act'(mask) before the adds (input gradients), `y_pre`
+    receives the value before the adds; both are F16K tensors of res_ctot channels like the residuals."""
     if x16.dtype != torch.int16 or x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
         raise RuntimeError("masic_amd.conv2d_f16k_res: input buffer does not match the descriptor")
     n_out = desc.B * desc.out_ctot * desc.Ho * desc.Wo
@@ -924,9 +926,9 @@ def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res
         y16 = torch.empty(n_out, dtype=torch.int16, device=x16.device)
     elif y16.dtype != torch.int16 or y16.numel() != n_out:
         raise RuntimeError("masic_amd.conv2d_f16k_res: output buffer does not match the descriptor")
-    for r in (res1, res2):
+    for r in (res1, res2, mask, y_pre):
         if r is not None and (r.dtype != torch.int16 or r.numel() != desc.B * res_ctot * desc.Ho * desc.Wo):
-            raise RuntimeError("masic_amd.conv2d_f16k_res: residual buffer does not match (B, res_ctot, Ho, Wo)")
+            raise RuntimeError("masic_amd.conv2d_f16k_res: residual / mask / pre buffer does not match (B, res_ctot, Ho, Wo)")
     timed = None
     if _timer is not None:
         buf = ctypes.create_string_buffer(96)
@@ -935,13 +937,36 @@ def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res
         if _timer.only is None or variant == _timer.only:
             timed = (variant, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             timed[1].record()
-    check(lib.masic_conv_f16k_res_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(y16), ctypes.byref(desc), _stream()),
-          "conv_f16k_res_fwd")
+    if mask is None and y_pre is None:
+        check(lib.masic_conv_f16k_res_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(y16), ctypes.byref(desc), _stream()),
+              "conv_f16k_res_fwd")
+    else:
+        check(lib.masic_conv_f16k_res_ex_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(mask), float(mask_slope), _p(y_pre),
+                                             _p(y16), ctypes.byref(desc), _stream()), "conv_f16k_res_ex_fwd")
     if timed is not None:
         timed[2].record()
         flops, nbytes = conv_algorithmic_work(desc)
         _timer.records.append((timed[0], 1, flops, nbytes, timed[1], timed[2]))
     return y16
+
+
+def f16k_act_bwd(g16, y16, slope):
+    """g * act'(y) on F16K buffers (slope 0.01: LeakyReLU, 0: ReLU); y is the activation's OUTPUT."""
+    if g16.dtype != torch.int16 or y16.dtype != torch.int16 or g16.numel() != y16.numel() or g16.numel() % 8:
+        raise RuntimeError("masic_amd.f16k_act_bwd: F16K buffers of equal size expected")
+    out = torch.empty_like(g16)
+    check(lib.masic_f16k_act_bwd(_p(g16), _p(y16), _p(out), g16.numel(), float(slope), _stream()), "f16k_act_bwd")
+    return out
+
+
+def f16k_channel_sum(x16, B, C, HW):
+    """float32 [C] sums over (image, pixel) of an F16K tensor (a bias gradient)."""
+    if x16.dtype != torch.int16 or C % 16 or x16.numel() != B * C * HW:
+        raise RuntimeError("masic_amd.f16k_channel_sum: buffer does not match (B, C, HW), C % 16 == 0")
+    out = torch.empty(C, dtype=torch.float32, device=x16.device)
+    ws = torch.empty(lib.masic_f16k_channel_sum_workspace_bytes(B, C) // 4, dtype=torch.float32, device=x16.device)
+    check(lib.masic_f16k_channel_sum(_p(x16), _p(out), _p(ws), B, C, HW, _stream()), "f16k_channel_sum")
+    return out
 
 
 def conv2d_f16k_few(x16, packed, bias32, desc, C, res32=None):

@@ -325,3 +325,65 @@ def test_conv3x3_wgrad_f16k_vs_torch(B, Cin, Cout, H, W):
     ref = torch.nn.grad.conv2d_weight(_bf(x), (Cout, Cin, 3, 3), _bf(dy), padding=1)
     got = ops.conv3x3_wgrad_f16k(ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV)), B, Cin, Cout, H, W)
     assert_close(got, ref, f"conv3x3_wgrad_f16k {Cin}->{Cout}", 1e-5)
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 64, 96), (96, 40, 72)])
+def test_enhancement_block_fused_training_node_vs_float32_graph(C, H, W, monkeypatch):
+    """bf16 mode trains Enhancement_Block (reference MASIC.py:149-164) as ONE node, forward and backward on F16K buffers
+    (masic_amd/autograd.py: EnhancementBlockFn).  Against the float32 node-per-layer graph of the same module (itself pinned to the
+    reference by the goldens above), on random inputs and a random output gradient -- a hard case: sums of random signs, and bf16
+    rounding flips LeakyReLU masks near zero -- the output stays within 0.5 % relative L2, and the input gradient and each of the 12
+    parameter gradients are (a) aligned with the float32 ones (cosine >= 0.995) and (b) no worse than 1.5 x the error the
+    node-per-layer graph has with the same bf16 operands (measured: both 4-8 % relative L2, the operand precision's own floor)."""
+    from coremasic.mywork.MASIC import Enhancement_Block
+    from masic_amd import autograd as A, nn as mnn
+    torch.manual_seed(C)
+    eb = Enhancement_Block(C).to(DEV).train()
+    x = torch.randn(2, C, H, W, device=DEV).requires_grad_(True)
+    gy = torch.randn(2, C, H, W, device=DEV)
+
+    def run():
+        eb.zero_grad()
+        x.grad = None
+        y = eb(x)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in eb.parameters()]
+    assert not A.enhancement_block_supported(eb, x)                   # float32 mode: the node-per-layer graph
+    r32 = run()
+    mnn.set_precision("bf16")
+    try:
+        assert A.enhancement_block_supported(eb, x)
+        fused = run()
+        monkeypatch.setattr(A, "enhancement_block_supported", lambda *a: False)
+        unfused = run()
+    finally:
+        mnn.set_precision("f32")
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    def cos(a, b):
+        return float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm()))
+    assert len(fused) == 14
+    ef, eu = [rel(a, b) for a, b in zip(fused, r32)], [rel(a, b) for a, b in zip(unfused, r32)]
+    cs = [cos(a, b) for a, b in zip(fused, r32)]
+    print(f"Enhancement_Block({C}) fused bf16 node vs float32 graph: out {ef[0]:.2e}, dx {ef[1]:.2e} (node-per-layer bf16 {eu[1]:.2e}), "
+          f"parameter gradients worst {max(ef[2:]):.2e} (node-per-layer bf16 {max(eu[2:]):.2e}), lowest cosine {min(cs):.5f}")
+    assert ef[0] <= 5e-3 and min(cs) >= 0.995, (ef[0], min(cs))
+    for k in range(1, 14):
+        assert ef[k] <= 1.5 * eu[k] + 1e-3, (k, ef[k], eu[k])
+
+
+def test_f16k_act_bwd_and_channel_sum_vs_torch():
+    from masic_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 48, 9, 24
+    a = torch.randn(B, C, H, W, generator=g).to(DEV)
+    y = torch.randn(B, C, H, W, generator=g).to(DEV)
+    a16, y16 = ops.nchw_to_f16k(a), ops.nchw_to_f16k(y)
+    ab, yb = a.bfloat16().float(), y.bfloat16().float()
+    out = ops.f16k_to_nchw_dev(ops.f16k_act_bwd(a16, y16, 0.01), B, C, H, W)
+    want = (ab * torch.where(yb > 0, 1.0, 0.01)).bfloat16().float()
+    assert torch.equal(out, want)
+    s = ops.f16k_channel_sum(a16, B, C, H * W)
+    assert torch.allclose(s, ab.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=1e-4)
