@@ -1086,9 +1086,11 @@ class Independent_EN(nn.Module):
         out1_warp, out2_warp = warp(out1, m_fwd), warp(out2, m_back)
         out1 = self.EBl2(_ag.cat(gate(out1, w_L, 1), gate(out2_warp, w_L, 0)))                  # :1481
         out2 = self.EBr2(_ag.cat(gate(out2, w_R, 1), gate(out1_warp, w_R, 0)))                  # :1482
-        out1 = self.EBl3(_ag.cat(out1, x1c))
-        out2 = self.EBr3(_ag.cat(out2, x2c))
-        return {"x1_hat": self.conv2.run(out1, res1=x1_hat), "x2_hat": self.conv2.run(out2, res1=x2_hat)}
+        def last(eb, feats, x_hat):                 # conv2(EB3(feats)) + x_hat   (:1485-1488)
+            if _ag.enhancement_block_supported(eb, feats, tail=self.conv2):
+                return _ag.enhancement_block(eb, feats, tail=self.conv2, res=x_hat)
+            return self.conv2.run(eb(feats), res1=x_hat)
+        return {"x1_hat": last(self.EBl3, _ag.cat(out1, x1c), x1_hat), "x2_hat": last(self.EBr3, _ag.cat(out2, x2c), x2_hat)}
 
     def _forward_f16k(self, x1_hat, x2_hat, h_matrix):
         """Inference with bf16 operands: the 32 / 64 / 96-channel full-resolution activations stay in F16K bf16 between the 36

@@ -318,6 +318,7 @@ class EnhancementBlockFn(Function):
     """Enhancement_Block -- three residual blocks and the skip over all of them (reference MASIC.py:149-164) -- as ONE node of the CQE
     training step in bf16 mode, forward AND backward on F16K buffers (conv_f16k.hip, wgrad_f16k.hip, f16k_ops.hip):
 
+      (with `tail`: Independent_EN.conv2 + the residual image, reference :1487-1488, run on the block's F16K output in the same node)
       forward   x -> F16K once; per block  t = L(c1(x)),  u = L(c2(t)) (stored by the same launch as `y_pre`),  o = u + x (+ x0 on
                 the last block); out -> float32 NCHW once.  Saved: x0, t_i, u_i, o_1, o_2 in bf16 (18 B / element against 48 B of
                 the node-per-layer float32 graph).
@@ -328,7 +329,7 @@ class EnhancementBlockFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, eb, *params):
+    def forward(ctx, x, eb, tail, res, *params):
         x = _c(x)
         B, C, H, W = x.shape
         x0 = ops.nchw_to_f16k(x)
@@ -337,16 +338,38 @@ class EnhancementBlockFn(Function):
             t = rb.conv1.run_f16k_res(cur, B, H, W, act=ops.ACT_LEAKY)
             u = ops.f16k_empty(B, C, H, W, x.device)
             cur = rb.conv2.run_f16k_res(t, B, H, W, act=ops.ACT_LEAKY, res1=cur, res2=x0 if i == 2 else None, res_ctot=C, y_pre=u)
-            saved += [t, u] if i == 2 else [t, u, cur]
-        ctx.eb, ctx.shape = eb, (B, C, H, W)
+            saved += [t, u] if i == 2 and tail is None else [t, u, cur]
+        ctx.eb, ctx.tail, ctx.shape = eb, tail, (B, C, H, W)
         ctx.save_for_backward(*params, *saved)
-        return ops.f16k_to_nchw_dev(cur, B, C, H, W)
+        if tail is None:
+            return ops.f16k_to_nchw_dev(cur, B, C, H, W)
+        return tail.run_f16k_few(cur, B, H, W, res32=None if res is None else _c(res))      # the block's output never leaves F16K
 
     @staticmethod
     def backward(ctx, g):
         B, C, H, W = ctx.shape
-        params, (x0, t1, u1, o1, t2, u2, o2, t3, u3) = ctx.saved_tensors[:12], ctx.saved_tensors[12:]
-        g_out = ops.nchw_to_f16k(_c(g))
+        tail = ctx.tail
+        params, acts = ctx.saved_tensors[:12], ctx.saved_tensors[12 + (0 if tail is None else 2):]
+        x0, t1, u1, o1, t2, u2, o2, t3, u3 = acts[:9]
+        g = _c(g)
+        g_res = g_tw = g_tb = None
+        if tail is None:
+            g_out = ops.nchw_to_f16k(g)
+        else:
+            # y = conv(o3) + res with few output channels: dy zero-padded to 32 channels (two F16K records) -- the weight-gradient
+            # kernel's tile, and a channel count every conv_f16k configuration takes for the input gradient (the transposed convolution
+            # on the zero-padded weight)
+            Ct = tail.out_channels
+            w_t = ctx.saved_tensors[12]
+            g_res = g if ctx.needs_input_grad[3] else None
+            dy32 = torch.zeros(B * 32 * H * W, dtype=torch.int16, device=g.device)
+            ops.nchw_to_f16k_view(g, dy32, 32, 0)
+            wpad = torch.zeros((32, C, 3, 3), dtype=torch.float32, device=g.device)
+            wpad[:Ct] = w_t.detach()
+            dt = ops.make_conv_desc(B, 32, H, W, C, 3, 3, 1, 1, transposed=True, in_ctot=32, out_ctot=C, prec=PREC_BF16)
+            g_out = ops.conv2d_f16k_res(dy32, ops.pack_conv_f16k_weight(wpad, dt), None, dt)
+            g_tw = ops.conv3x3_wgrad_f16k(acts[9], dy32, B, C, 32, H, W)[:Ct].contiguous()
+            g_tb = ops.channel_sum(g)
         blocks = ((ctx.eb.RB1, x0, t1, u1), (ctx.eb.RB2, o1, t2, u2), (ctx.eb.RB3, o2, t3, u3))
         d16 = ops.make_conv_desc(B, C, H, W, C, 3, 3, 1, 1, transposed=True, in_ctot=C, out_ctot=C, prec=PREC_BF16)
         grads = [None] * 12
@@ -364,24 +387,31 @@ class EnhancementBlockFn(Function):
             go = ops.conv2d_f16k_res(gt, ops.pack_conv_f16k_weight(w1.detach(), d16), None, d16, res1=go, res2=g_out if i == 0 else None, res_ctot=C)
             del gt
         gx = ops.f16k_to_nchw_dev(go, B, C, H, W) if ctx.needs_input_grad[0] else None
-        return (gx, None) + tuple(grads)
+        return (gx, None, None, g_res) + tuple(grads) + (() if tail is None else (g_tw, g_tb))
 
 
-def enhancement_block_supported(eb, x):
-    """bf16 mode, 3x3 stride-1 blocks of C % 32 channels without a channel-changing skip, F16K kernels available for the shape."""
+def enhancement_block_supported(eb, x, tail=None):
+    """bf16 mode, 3x3 stride-1 blocks of C % 32 channels without a channel-changing skip, F16K kernels available for the shape
+    (`tail`: a 3x3 stride-1 Conv2d to <= 16 channels run on the block's F16K output inside the same node)."""
     from . import nn as _mnn
     if _mnn._PRECISION != PREC_BF16 or _mnn._FP8 or x.dim() != 4:
         return False
     B, C, H, W = x.shape
     convs = [c for rb in (eb.RB1, eb.RB2, eb.RB3) for c in (rb.conv1, rb.conv2)]
+    if tail is not None and not (tail.bias is not None and tail.in_channels == C and tail.out_channels <= 16 and tail._geometry() == (3, 3, 1, 1)
+                                 and not tail.transposed_conv and tail.few_supported(B, H, W)):
+        return False
     return (C % 32 == 0 and all(rb.skip is None for rb in (eb.RB1, eb.RB2, eb.RB3))
             and all(c.bias is not None and c.in_channels == C and c.out_channels == C and c._geometry() == (3, 3, 1, 1) for c in convs)
             and eb.f16k_supported(B, H, W))
 
 
-def enhancement_block(eb, x):
+def enhancement_block(eb, x, tail=None, res=None):
+    """Enhancement_Block(x), or tail(Enhancement_Block(x)) + res, as one node (see EnhancementBlockFn)."""
     params = [p for rb in (eb.RB1, eb.RB2, eb.RB3) for c in (rb.conv1, rb.conv2) for p in (c.weight, c.bias)]
-    return EnhancementBlockFn.apply(x, eb, *params)
+    if tail is not None:
+        params += [tail.weight, tail.bias]
+    return EnhancementBlockFn.apply(x, eb, tail, res, *params)
 
 
 def cat(*ts):

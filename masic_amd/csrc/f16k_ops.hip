@@ -150,12 +150,19 @@ __global__ __launch_bounds__(256) void f16k_channel_sum_stage1(const uint4* __re
         partial[((size_t)(b * chunks + chunk)) * (C16 * 16) + cb * 16 + c] = s;
     }
 }
-__global__ __launch_bounds__(64) void f16k_channel_sum_stage2(const float* __restrict__ partial, float* __restrict__ out, int C, int n) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+// one block per 16 channels: 256 threads = 16 channels x 16 row lanes, then a tree over the row lanes (double: order-independent result)
+__global__ __launch_bounds__(256) void f16k_channel_sum_stage2(const float* __restrict__ partial, float* __restrict__ out, int C, int n) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane_r = threadIdx.x >> 4;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)partial[(size_t)i * C + c];
-    out[c] = (float)s;
+    for (int i = lane_r; i < n; i += 16) s += (double)partial[(size_t)i * C + c];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k >= 16; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) out[c] = (float)red[threadIdx.x];
 }
 
 }  // namespace
@@ -176,7 +183,7 @@ extern "C" size_t masic_f16k_channel_sum_workspace_bytes(int B, int C) { return 
 extern "C" int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream) {
     MASIC_REQUIRE(x && out && workspace && B > 0 && C > 0 && C % 16 == 0 && HW > 0, MASIC_ERR_ARG, "f16k_channel_sum: bad argument");
     hipLaunchKernelGGL(f16k_channel_sum_stage1, dim3(F16K_CS_CHUNKS, C / 16, B), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (float*)workspace, C / 16, HW, F16K_CS_CHUNKS);
-    hipLaunchKernelGGL(f16k_channel_sum_stage2, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, out, C, B * F16K_CS_CHUNKS);
+    hipLaunchKernelGGL(f16k_channel_sum_stage2, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, C, B * F16K_CS_CHUNKS);
     return masic_launch_status("f16k_channel_sum");
 }
 

@@ -374,6 +374,49 @@ def test_enhancement_block_fused_training_node_vs_float32_graph(C, H, W, monkeyp
         assert ef[k] <= 1.5 * eu[k] + 1e-3, (k, ef[k], eu[k])
 
 
+def test_enhancement_block_with_output_layer_in_one_node(monkeypatch):
+    """conv2(Enhancement_Block(x)) + image (reference MASIC.py:1485-1488) as one bf16 node: same gates as above against the float32
+    graph, gradients of x, the residual image, the 12 block parameters and the output layer's weight and bias."""
+    from coremasic.mywork.MASIC import Enhancement_Block, conv3x3
+    from masic_amd import autograd as A, nn as mnn
+    torch.manual_seed(11)
+    C, H, W = 96, 40, 72
+    eb, tail = Enhancement_Block(C).to(DEV).train(), conv3x3(C, 3).to(DEV).train()
+    x = torch.randn(2, C, H, W, device=DEV).requires_grad_(True)
+    img = torch.rand(2, 3, H, W, device=DEV).requires_grad_(True)
+    gy = torch.randn(2, 3, H, W, device=DEV)
+    ps = list(eb.parameters()) + list(tail.parameters())
+
+    def run(fused):
+        for p in ps + [x, img]:
+            p.grad = None
+        y = A.enhancement_block(eb, x, tail=tail, res=img) if fused else tail.run(eb(x), res1=img)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone(), img.grad.clone()] + [p.grad.clone() for p in ps]
+    r32 = run(False)
+    mnn.set_precision("bf16")
+    try:
+        assert A.enhancement_block_supported(eb, x, tail=tail)
+        fused = run(True)
+        monkeypatch.setattr(A, "enhancement_block_supported", lambda *a, **k: False)
+        unfused = run(False)
+    finally:
+        mnn.set_precision("f32")
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    def cos(a, b):
+        return float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm()))
+    ef, eu = [rel(a, b) for a, b in zip(fused, r32)], [rel(a, b) for a, b in zip(unfused, r32)]
+    cs = [cos(a, b) for a, b in zip(fused, r32)]
+    print(f"conv2(Enhancement_Block(96)) + image, fused bf16 node vs float32 graph: out {ef[0]:.2e}, gradients worst {max(ef[1:]):.2e} "
+          f"(node-per-layer bf16 {max(eu[1:]):.2e}), lowest cosine {min(cs):.5f}")
+    assert len(fused) == 17 and torch.equal(fused[2], gy) and ef[0] <= 5e-3 and min(cs) >= 0.995, (ef[0], min(cs))
+    for k in range(1, 17):
+        assert ef[k] <= 1.5 * eu[k] + 1e-3, (k, ef[k], eu[k])
+
+
 def test_f16k_act_bwd_and_channel_sum_vs_torch():
     from masic_amd import ops
     g = torch.Generator().manual_seed(5)
