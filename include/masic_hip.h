@@ -214,6 +214,9 @@ int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const f
 int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream);
 size_t masic_f16k_channel_sum_workspace_bytes(int B, int C);
 int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream);
+/* diagnostics: 16 uint64 on the device, filled by every following conv_f16k launch with {core-clock, 100 MHz} stamp pairs at kernel
+ * entry, K-loop entry, K-loop exit and kernel exit of its first and of its last workgroup; NULL switches it off (tools/f16k_stamps.py) */
+void masic_conv_f16k_set_stamps(void* device_buffer);
 /* a layer with few output channels (Independent_EN.conv2: 96 -> 3 + the picture as residual, MASIC.py:1492-1496) on the same kernels:
  * `d` describes the convolution with its weight zero-padded to Cout = 32; y_nchw / res32 are float32 [B][cout_store][Ho][Wo]. */
 int masic_conv_f16k_few_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* res32, float* y_nchw,

@@ -186,6 +186,7 @@ struct F16kArgs {
     unsigned short* y16_pre;      // fused GDN + F16K output: also store the convolution's result BEFORE the GDN (same view), or null --
                                   //   what the GDN backward of a training step needs (masic_amd/autograd.py: AnalysisFn / SynthesisFn);
                                   //   residual form: the activation's output BEFORE the residual adds (view of res_ctot channels)
+    unsigned long long* stamps;   // diagnostics (masic_conv_f16k_set_stamps): {s_memtime, s_memrealtime} at 4 points of the first and last workgroup
     const unsigned short* mask16; // F16K output only: multiply by act'(mask) before the residual adds (mask: F16K of res_ctot channels;
     float mask_slope;             //   slope for mask <= 0: 0.01 LeakyReLU, 0 ReLU) -- input gradients of the training step
     const float* res32;           // float32 NCHW output only: residual [B][cout_store][Ho][Wo] added after the activation, or null
@@ -212,6 +213,9 @@ struct F16kArgs {
                                   //   blockIdx.y = co-block * msplit + sub-block, a sub-block = NM accumulator tiles of the slab
 };
 
+#ifndef F16K_DMA_SPREAD
+#define F16K_DMA_SPREAD 1  // 0: the K loop's DMA pieces issued en bloc at the top of every step (A/B timing, tools/ablate_f16k.sh)
+#endif
 #ifndef F16K_ABLATE
 #define F16K_ABLATE 0     // timing experiments only (tools/ablate_f16k.sh): 1 no DMA in the K loop, 2 no barriers, 3 no fragment reads, 4 a quarter of the MFMAs
 #endif
@@ -413,6 +417,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     }
     if (tile >= a.ntiles) return;
     if (F16K_ABLATE == 6) return;                 // launch cost only
+    // diagnostics: core-clock and 100 MHz constant-clock stamps of wave 0 of the first and of the last workgroup
+    unsigned long long* const stamp = (a.stamps != nullptr && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x))
+                                          ? a.stamps + (blockIdx.x == 0 ? 0 : 8) : nullptr;
+    if (stamp) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[1] = __builtin_amdgcn_s_memrealtime(); }
     const int tw_i = tile % a.tiles_w, th_i = tile / a.tiles_w;
     const int r0 = th_i * a.TH, c0 = tw_i * a.TW;
     const int nchunks = a.Cin16 / KS;
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     __syncthreads();
 
     if (F16K_ABLATE == 7) return;                 // launch + prologue (setup, first DMA, wait)
+    if (stamp) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
     int cslot = 0, pslot = (D % NWS) * WST;                   // byte offsets of the consumer / producer ring slots
     int cb = PATCH0, pb = PATCH0 + (L % NB) * a.PB;           // byte offsets of the patch buffer of chunk c / of chunk c+L
     int xsoff = L * (KS * plane_bytes);                       // patch producer: byte offset of chunk c+L in the input
@@ -527,19 +536,27 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
     // One step: slice S of the patch DMA (or none), T taps x KS k-steps of 2x2 MFMAs, counted wait, barrier.
     auto step = [&](auto slice, int t, bool last) {
         constexpr int S = decltype(slice)::value;
-        if (F16K_ABLATE == 1) {
-        } else if (wrole) {                                   // weight slab group of step g+D
+        // The step's DMA pieces -- weight waves: the slab group of step g+D; patch waves: slice S of chunk c+L -- are issued one or
+        // two at a time AFTER the MFMAs of each k-step, in the shadow of the matrix pipe, instead of en bloc at the top of the step
+        // (60-185 cycles apiece there, MI355X_MICROARCH.md).  Worth ~2 % (in-kernel stamps, tools/f16k_stamps.py: 47.0 -> 46.1 core
+        // clocks per MFMA per SIMD in the K loop of the 128 -> 128 stride-2 layers): the K loop is not DMA-issue-bound -- see
+        // DESIGN.md section 10 for what bounds it.  F16K_DMA_SPREAD=0 keeps the en-bloc issue (A/B timing).
+        auto dma_pieces = [&](int first, int last) {
+            if (F16K_ABLATE == 1) return;
+            if (wrole) {
 #pragma unroll
-            for (int k = 0; k < WI; ++k) dma_buf16(rw, lds + pslot + k * 4096 + wq * 1024, wvoff, wsoff + k * 4096);
-            wsoff += WST;
-            pslot = pslot + WST == NWS * WST ? 0 : pslot + WST;
-        } else if (S >= 0) {                                  // patch slice S of chunk c+L
+                for (int k = first; k < last; ++k)
+                    if (k < WI) dma_buf16(rw, lds + pslot + k * 4096 + wq * 1024, wvoff, wsoff + k * 4096);
+            } else if (S >= 0) {
 #pragma unroll
-            for (int u = 0; u < PSP; ++u) {
-                constexpr int k = (S >= 0 ? S : 0) * PSP;
-                dma_buf16(rx, lds + (pdst[k + u] >= 0 ? pb + pdst[k + u] : dummy_off), goff[k + u], xsoff);
+                for (int u = first; u < last; ++u) {
+                    constexpr int k = (S >= 0 ? S : 0) * PSP;
+                    if (u < PSP) dma_buf16(rx, lds + (pdst[k + u] >= 0 ? pb + pdst[k + u] : dummy_off), goff[k + u], xsoff);
+                }
             }
-        }
+        };
+        constexpr int NPIECES = WI > PSP ? WI : PSP;
+        if (!F16K_DMA_SPREAD) dma_pieces(0, NPIECES);
         // LDS reads of the K loop go through inline asm with hand-counted lgkmcnt: for a compiler-visible ds_read hipcc puts
         // `s_waitcnt vmcnt(0)` in front (the DMA in flight might alias it), which would drain the prefetch queue every step.
         // The fragments of k-step i+1 are requested before the MFMAs of k-step i are issued.
@@ -616,7 +633,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 });
             });
             }
+            if constexpr (F16K_DMA_SPREAD != 0) {
+                constexpr int per = (NPIECES + NKS - 1) / NKS;
+                __builtin_amdgcn_sched_barrier(0);
+                dma_pieces(i * per, (i + 1) * per);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
+        if (wrole && F16K_ABLATE != 1) {
+            wsoff += WST;
+            pslot = pslot + WST == NWS * WST ? 0 : pslot + WST;
+        }
         cslot = cslot + WST == NWS * WST ? 0 : cslot + WST;
         // weight waves: the slab group of the next step has landed, the D-1 groups after it stay in flight.
         // patch waves: at the end of a chunk the next chunk's patch has landed, the L-1 chunks after it stay in flight.
@@ -634,6 +661,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
         xsoff += KS * plane_bytes;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp) { stamp[4] = __builtin_amdgcn_s_memtime(); stamp[5] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- epilogue
     const ConvGeom g = make_geom(a.q, phase);
@@ -775,6 +803,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             }
         }
     }
+    if (stamp) { stamp[6] = __builtin_amdgcn_s_memtime(); stamp[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // ------------------------------------------------------------------------------------------ first analysis layer
@@ -959,6 +988,8 @@ struct F16kCfg {
 };
 
 constexpr int F16K_D = 3;
+
+unsigned long long* g_f16k_stamps = nullptr;
 
 F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
     F16kCfg c{};
@@ -1233,7 +1264,7 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;
     const int tiles_w = ceil_div(g[0].Wp, c.TW), ntiles = tiles_w * ceil_div(g[0].Hp, c.TH);
     F16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, gate, y_nchw, (unsigned short*)y_f16k,
-               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, (unsigned short*)y_pre, (const unsigned short*)mask16, mask_slope, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
+               (const uint4*)gdn_packed, (const unsigned short*)res1, (const unsigned short*)res2, res_ctot, (unsigned short*)y_pre, g_f16k_stamps, (const unsigned short*)mask16, mask_slope, res32, cout_store > 0 ? cout_store : d->Cout, wscale, (unsigned char*)y_f8k, out_inv_scale, gdn_inverse, d2s & 0xff, d->in_ctot / cblk, d->in_coff / cblk, c.Cin16,
                d->Hi, d->Wi, d->Cout, d->Ho, d->Wo, d2s ? ((d2s >> 8) & 0xfff) : (cout_store > 0 ? cout_store : d->out_ctot), d2s ? (d2s >> 20) : d->out_coff,
                d->gate_ctot, d->gate_c, d->act,
                c.TW, c.TWlog, c.SR, c.TH, tiles_w, ntiles,
@@ -1666,3 +1697,8 @@ extern "C" int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const
     hipLaunchKernelGGL((gemm_f16k<4, true>), grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
     return masic_launch_status("gemm_f8k_fwd");
 }
+
+// Diagnostics: a device buffer of 16 uint64 that every following conv_f16k launch fills with {s_memtime (core clock), s_memrealtime
+// (100 MHz)} pairs at kernel entry, K-loop entry, K-loop exit and kernel exit of its first [0..7] and last [8..15] workgroup;
+// NULL switches it off.  tools/f16k_stamps.py reads the phases and the shader clock the chip held from them.
+extern "C" void masic_conv_f16k_set_stamps(void* device_buffer) { g_f16k_stamps = (unsigned long long*)device_buffer; }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float se
 // the same loop on pseudo-random operands that change with every instruction (8 A and 8 B fragments cycled): the multiplier array
 // toggles as it does on real activations, which is what the power limit sees
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop_random(float* out, int iters, unsigned seed) {
+__global__ __launch_bounds__(256) void mfma_loop_random(float* out, int iters, unsigned seed, unsigned long long* stamps) {
     bf16x8 a[8], b[8];
     unsigned h = seed ^ (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
 #pragma unroll
@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void mfma_loop_random(float* out, int iters, u
     for (int k = 0; k < NACC; ++k)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.0f;
+    const bool st = stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (st) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); }
     for (int it = 0; it < iters; it += 8) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void mfma_loop_random(float* out, int iters, u
     float s = 0.0f;
     for (int k = 0; k < NACC; ++k)
         for (int i = 0; i < 16; ++i) s += acc[k][i];
+    if (st) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[3] = __builtin_amdgcn_s_memrealtime(); }
     if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -61,7 +64,8 @@ static void run_random(int wgs_per_cu, int ncu, int iters, float* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = wgs_per_cu * ncu;
-    hipLaunchKernelGGL(mfma_loop_random<NACC>, dim3(grid), dim3(256), 0, 0, out, iters / 10, 7u);
+    unsigned long long* stamps; hipMalloc(&stamps, 32);
+    hipLaunchKernelGGL(mfma_loop_random<NACC>, dim3(grid), dim3(256), 0, 0, out, iters / 10, 7u, stamps);
     hipDeviceSynchronize();
     float best = 1e30f, sum = 0.0f;
     const int reps = 20;                      // back to back, as the layers of a forward are
@@ -69,7 +73,7 @@ static void run_random(int wgs_per_cu, int ncu, int iters, float* out) {
     for (int r = 0; r <= reps; ++r) hipEventCreate(&ev[r]);
     hipEventRecord(ev[0], 0);
     for (int r = 0; r < reps; ++r) {
-        hipLaunchKernelGGL(mfma_loop_random<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + r);
+        hipLaunchKernelGGL(mfma_loop_random<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + r, stamps);
         hipEventRecord(ev[r + 1], 0);
     }
     hipEventSynchronize(ev[reps]);
@@ -77,8 +81,13 @@ static void run_random(int wgs_per_cu, int ncu, int iters, float* out) {
         float ms; hipEventElapsedTime(&ms, ev[r], ev[r + 1]);
         best = ms < best ? ms : best; sum += ms;
     }
+    unsigned long long hs[4];
+    hipMemcpy(hs, stamps, 32, hipMemcpyDeviceToHost);
+    const double mhz = (double)(hs[2] - hs[0]) / (double)(hs[3] - hs[1]) * 100.0;      // s_memtime: core clock; s_memrealtime: 100 MHz
+    const double clk_per_mfma = (double)(hs[2] - hs[0]) / ((double)iters * NACC * wgs_per_cu);
     const double flops = (double)grid * 4 * iters * NACC * 2.0 * 32 * 32 * 16;
-    printf("{\"operands\": \"random, changing every instruction\", \"accumulators\": %d, \"waves_per_simd\": %d, \"iters\": %d, \"ms_best\": %.3f, "
+    printf("{\"shader_clock_mhz_in_loop\": %.0f, \"core_clk_per_mfma_per_simd\": %.1f, ", mhz, clk_per_mfma);
+    printf("\"operands\": \"random, changing every instruction\", \"accumulators\": %d, \"waves_per_simd\": %d, \"iters\": %d, \"ms_best\": %.3f, "
            "\"ms_avg\": %.3f, \"tflops_best\": %.1f, \"tflops_avg\": %.1f}\n", NACC, wgs_per_cu, iters, best, sum / reps, flops / best / 1e9,
            flops / (sum / reps) / 1e9);
 }
