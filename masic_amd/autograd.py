@@ -66,48 +66,55 @@ _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weig
 
 
 def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None):
-    """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW (x16: x in F16K if the caller has it)."""
+    """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW (x16: x in F16K if the caller has it).
+    (Issuing dW / db on a side stream next to dx was measured: 24.9 -> 25.2 ms per HSIC training step, i.e. nothing -- not kept.)"""
     g = _c(g)
     if act != ops.ACT_NONE:
         g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=act)
     kh, kw, s, p = mod._geometry()
     B, Cin, Hi, Wi = x.shape
     Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
-    gx = gw = gb = None
     from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
-    g16 = [None]
-
-    def g_f16k():                     # dy in F16K, converted once for the input gradient and the weight gradient
-        if g16[0] is None:
-            g16[0] = ops.nchw_to_f16k(g)
-        return g16[0]
+    bf16 = _mnn._PRECISION != PREC_F32
+    d = d16 = None
+    dx_gemm = dx_f16k = False
     if need_gx:
         d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
         if (d.Ho, d.Wo) != (Hi, Wi):
             raise RuntimeError("masic_amd: input-gradient geometry mismatch (odd spatial size?)")
-        if _gemm_1x1(mod):
-            # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
-            wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
-            gx = ops.gemm_f16k(g_f16k(), wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
-        elif _DGRAD_F16K and _mnn._PRECISION != PREC_F32 and Cout % 16 == 0 and kh * kw > 1:
+        dx_gemm = _gemm_1x1(mod)
+        if not dx_gemm and _DGRAD_F16K and bf16 and Cout % 16 == 0 and kh * kw > 1:
             # bf16 mode: the DMA-staged F16K kernel of the inference path (conv_f16k.hip) -- g converted once to the channel-blocked
             # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
             d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)
-            if ops.conv_f16k_supported(d16):
-                gx = ops.conv2d_f16k(g_f16k(), ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
-        if gx is None:
-            gx = ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
-    if need_gw:
-        if (_WGRAD3_F16K and _mnn._PRECISION != PREC_F32 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
-                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin):
-            # 3x3 stride-1 layers (Independent_EN): both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
-            gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g_f16k(), B, Cin, Cout, Hi, Wi)
-        else:
-            d = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
-            gw = ops.conv2d_wgrad(x, g, d, tuple(weight.shape))
-    if need_gb:
-        gb = ops.channel_sum(g)
-    return gx, gw, gb
+            dx_f16k = ops.conv_f16k_supported(d16)
+    # 3x3 stride-1 layers (Independent_EN, hyper transforms): dW from both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
+    dw_f16k = (need_gw and _WGRAD3_F16K and bf16 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
+               and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
+    g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k) else None      # dy in F16K, converted once for both gradients
+
+    def input_gradient():
+        if dx_gemm:
+            # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
+            wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
+            return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
+        if dx_f16k:
+            return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
+        return ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
+
+    def parameter_gradients():
+        gw = gb = None
+        if dw_f16k:
+            gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
+        elif need_gw:
+            dw = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
+            gw = ops.conv2d_wgrad(x, g, dw, tuple(weight.shape))
+        if need_gb:
+            gb = ops.channel_sum(g)
+        return gw, gb
+
+    gx = input_gradient() if need_gx else None
+    return (gx,) + parameter_gradients()
 
 
 def conv(mod, x, act=ops.ACT_NONE):
