@@ -310,6 +310,12 @@ int masic_softmax_k_fwd(const float* x, float* y, int B, int M, int K, int HW, v
  */
 int masic_warp_matrix(const float* M, float* minv_norm, int B, int Hs, int Ws, int Hd, int Wd,
                       int invert_first, void* stream);
+/* grid_sample convention of every warp of the library (forward, backward, masic_f16k_gate): 1 = align_corners=True -- kornia 0.5.0's
+ * warp_perspective default, what the reference's pinned dependency runs (readme.md:12) and this library's default; 0 =
+ * align_corners=False (kornia <= 0.4.1).  kornia is not vendored in the reference and no reference test pins a result at this
+ * boundary, so the convention stays selectable.  Process-wide; set once before the first forward. */
+void masic_set_warp_align_corners(int align_corners);
+int masic_get_warp_align_corners(void);
 int masic_warp_perspective_fwd(const float* src, const float* minv_norm, float* dst,
                                int B, int C, int Hs, int Ws, int Hd, int Wd,
                                int out_ctot, int out_coff, void* stream);

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void eb_auxloss_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------- warp backward (w.r.t. the source)
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ g_dst, const float* __restrict__ minv,
-                                                       float* __restrict__ g_src, int C, int Hs, int Ws, int Hd, int Wd) {
+                                                       float* __restrict__ g_src, int C, int Hs, int Ws, int Hd, int Wd, int align_corners) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= Hd * Wd) return;
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
     const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
     const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
-    const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(Ws - 1), 2.0f));
-    const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(Hs - 1), 2.0f));
+    const float fx = masic_grid_unnormalize(nx, Ws, align_corners);
+    const float fy = masic_grid_unnormalize(ny, Hs, align_corners);
     if (!(fx == fx) || !(fy == fy)) return;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float wx = fx - x0f, wy = fy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
@@ -533,6 +533,6 @@ extern "C" int masic_warp_perspective_bwd(const float* g_dst, const float* minv_
                                           int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream) {
     MASIC_REQUIRE(g_dst && minv_norm && g_src, MASIC_ERR_ARG, "warp_perspective_bwd: null pointer");
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(Hd * Wd, 256), B), dim3(256), 0, (hipStream_t)stream, g_dst, minv_norm,
-                       g_src, C, Hs, Ws, Hd, Wd);
+                       g_src, C, Hs, Ws, Hd, Wd, masic_warp_align_corners_value());
     return masic_launch_status("warp_perspective_bwd");
 }

@@ -40,3 +40,14 @@ __device__ __forceinline__ float apply_inop(float v, int op) {
     if (op == MASIC_INOP_ROUND) return rintf(v);
     return v;
 }
+
+// F.grid_sample's map of a normalised coordinate n in [-1, 1] to a pixel coordinate of an axis of `size` samples.
+//   align_corners = true  (kornia 0.5.0's warp_perspective default, what MASIC runs):  (n + 1) * ((size - 1) / 2)
+//   align_corners = false (kornia <= 0.4.1's default):                                 ((n + 1) * size - 1) / 2
+// kornia is absent from this environment and the reference pins no result at this boundary ("parity
+// unpinned"), so the convention is a run-time setting of the library, masic_set_warp_align_corners (default 1).
+__device__ __forceinline__ float masic_grid_unnormalize(float n, int size, int align_corners) {
+    return align_corners ? __fmul_rn(__fadd_rn(n, 1.0f), __fdiv_rn((float)(size - 1), 2.0f))
+                         : __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(n, 1.0f), (float)size), 1.0f), 2.0f);
+}
+int masic_warp_align_corners_value();      // warp.hip

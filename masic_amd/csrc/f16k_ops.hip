@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // one thread per (pixel, 8-channel half record)
 __global__ __launch_bounds__(256) void f16k_gate_kernel(const unsigned short* __restrict__ src, const float* __restrict__ gate,
                                                         const float* __restrict__ minv, unsigned short* __restrict__ dst,
-                                                        int C, int H, int W, int dst_ctot, int dst_coff, int gate_ctot, int gate_c) {
+                                                        int C, int H, int W, int dst_ctot, int dst_coff, int gate_ctot, int gate_c, int align_corners) {
     const int b = blockIdx.z, c8 = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int HW = H * W;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void f16k_gate_kernel(const unsigned short* __
         const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
         const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
         const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
-        const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(W - 1), 2.0f));
-        const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(H - 1), 2.0f));
+        const float fx = masic_grid_unnormalize(nx, W, align_corners);
+        const float fy = masic_grid_unnormalize(ny, H, align_corners);
         const float x0f = floorf(fx), y0f = floorf(fy);
         const float wx = __fsub_rn(fx, x0f), wy = __fsub_rn(fy, y0f);
         const float ex = __fsub_rn(1.0f, wx), ey = __fsub_rn(1.0f, wy);
@@ -196,7 +196,7 @@ extern "C" int masic_f16k_gate(const void* src, const float* gate, const float* 
                   MASIC_ERR_SHAPE, "f16k_gate: channel views (C %% 16, dst_coff %% 8, inside dst_ctot)");
     MASIC_REQUIRE(gate == nullptr || (gate_c >= 0 && gate_c < gate_ctot), MASIC_ERR_SHAPE, "f16k_gate: gate channel out of range");
     hipLaunchKernelGGL(f16k_gate_kernel, dim3(ceil_div(H * W, 256), C / 8, B), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)src, gate, minv, (unsigned short*)dst, C, H, W, dst_ctot, dst_coff, gate_ctot, gate_c);
+                       (const unsigned short*)src, gate, minv, (unsigned short*)dst, C, H, W, dst_ctot, dst_coff, gate_ctot, gate_c, masic_warp_align_corners_value());
     return masic_launch_status("f16k_gate");
 }
 

@@ -12,6 +12,7 @@
 // HBM-bound gather: one thread per destination pixel computes the source location once and
 // samples every channel (4 taps each); destination stores are coalesced along W.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -53,7 +54,7 @@ __global__ void warp_matrix_kernel(const float* __restrict__ M, float* __restric
 
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, const float* __restrict__ minv,
                                                    float* __restrict__ dst, int C, int Hs, int Ws, int Hd, int Wd,
-                                                   int out_ctot, int out_coff) {
+                                                   int out_ctot, int out_coff, int align_corners) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= Hd * Wd) return;
@@ -67,9 +68,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
     const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
     const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
     const float nx = __fmul_rn(X, scale), ny = __fmul_rn(Y, scale);
-    // F.grid_sample(align_corners=True): pixel = (n + 1) * ((size - 1) / 2)
-    const float fx = __fmul_rn(__fadd_rn(nx, 1.0f), __fdiv_rn((float)(Ws - 1), 2.0f));
-    const float fy = __fmul_rn(__fadd_rn(ny, 1.0f), __fdiv_rn((float)(Hs - 1), 2.0f));
+    const float fx = masic_grid_unnormalize(nx, Ws, align_corners);
+    const float fy = masic_grid_unnormalize(ny, Hs, align_corners);
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float wx = __fsub_rn(fx, x0f), wy = __fsub_rn(fy, y0f);
     const float ex = __fsub_rn(1.0f, wx), ey = __fsub_rn(1.0f, wy);
@@ -201,6 +201,13 @@ extern "C" int masic_warp_perspective_fwd(const float* src, const float* minv_no
     MASIC_REQUIRE(src != nullptr || C == 1, MASIC_ERR_ARG, "warp_perspective_fwd: ones-source needs C == 1");
     MASIC_REQUIRE(out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "warp_perspective_fwd: output view out of range");
     hipLaunchKernelGGL(warp_kernel, dim3(ceil_div(Hd * Wd, 256), B), dim3(256), 0, (hipStream_t)stream, src, minv_norm,
-                       dst, C, Hs, Ws, Hd, Wd, out_ctot, out_coff);
+                       dst, C, Hs, Ws, Hd, Wd, out_ctot, out_coff, masic_warp_align_corners_value());
     return masic_launch_status("warp_perspective_fwd");
 }
+
+static std::atomic<int> g_warp_align_corners{1};
+int masic_warp_align_corners_value() { return g_warp_align_corners.load(std::memory_order_relaxed); }
+// grid_sample convention of every warp of the library (forward, backward, the F16K gated warp): 1 = align_corners=True (kornia 0.5.0,
+// the default), 0 = align_corners=False (kornia <= 0.4.1).  Process-wide; set it once before the first forward.
+extern "C" void masic_set_warp_align_corners(int align_corners) { g_warp_align_corners.store(align_corners ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int masic_get_warp_align_corners(void) { return masic_warp_align_corners_value(); }

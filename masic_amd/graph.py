@@ -11,6 +11,7 @@ buffers and replaying.
 """
 import torch
 
+from . import ops
 from .homography import warp_matrices_host
 
 
@@ -69,14 +70,15 @@ class GraphedHSIC:
         self._packs = _mnn.cached_packs(net)
         self._sources = _mnn.pack_sources(net)
         self._signature = _mnn.pack_signature(self._sources)
-        self._precision = _mnn.get_precision()
+        self._precision = (_mnn.get_precision(), ops.get_warp_align_corners())     # settings baked into the captured launches
 
     def _check_fresh(self):
         from . import nn as _mnn
-        if _mnn.pack_signature(self._sources) == self._signature and _mnn.get_precision() == self._precision and not self.net.training:
+        if (_mnn.pack_signature(self._sources) == self._signature and (_mnn.get_precision(), ops.get_warp_align_corners()) == self._precision
+                and not self.net.training):
             return
         if self.on_stale == "raise":
-            raise RuntimeError("GraphedHSIC: the model's parameters / buffers, its mode or the operand precision changed since the "
+            raise RuntimeError("GraphedHSIC: the model's parameters / buffers, its mode, the operand precision or the warp convention changed since the "
                                "capture; build a new GraphedHSIC (or pass on_stale='recapture')")
         self._capture()
 

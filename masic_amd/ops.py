@@ -335,6 +335,17 @@ def homography_from_corners(corners, delta, ori_hw, patch_hw):
     return out
 
 
+def set_warp_align_corners(flag):
+    """grid_sample convention of every warp of the library: True = kornia 0.5.0's default (the reference's pinned version, and the
+    default here), False = kornia <= 0.4.1's.  Process-wide (include/masic_hip.h: masic_set_warp_align_corners); captured HIP graphs
+    notice the change (masic_amd/graph.py)."""
+    lib.masic_set_warp_align_corners(1 if flag else 0)
+
+
+def get_warp_align_corners():
+    return bool(lib.masic_get_warp_align_corners())
+
+
 def warp_perspective(src, minv_norm, dsize, ones_like=None, out=None, out_coff=0):
     """src None: warp an all-ones [B,1,H,W] image whose size is given by ones_like=(B,H,W)."""
     _dev(minv_norm, "warp matrix")

@@ -239,14 +239,16 @@ def warp_grid(Minv_norm, h_out, w_out):
     return torch.stack((X * scale, Y * scale), dim=-1)
 
 
-def warp_perspective(src, M, dsize):
+def warp_perspective(src, M, dsize, align_corners=True):
     """kornia 0.5.0 `warp_perspective(src, M, dsize)` with its defaults (bilinear, zeros,
     align_corners=None -> True). Reference call sites: MASIC.py:638,644,781,821,833.
-    PARITY UNPINNED: kornia is not available; restated from its published source."""
+    PARITY UNPINNED: kornia is not available; restated from its published source.
+    `align_corners=False` is kornia <= 0.4.1's default (same (W - 1) normalisation of the homography, grid_sample without
+    corner alignment): the alternative SURVEY.md section 8c asks to keep selectable."""
     H, W = src.shape[-2:]
     h_out, w_out = dsize
     grid = warp_grid(warp_matrix(M, (H, W), (h_out, w_out)), h_out, w_out)
-    return F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=align_corners)
 
 
 def mask(im1, H):

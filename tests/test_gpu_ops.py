@@ -219,6 +219,42 @@ def test_warp_and_masks(H, W):
     assert int(((mr_ref > 0) & (mr_ref < 1)).sum()) > 0     # non-binarised border is exercised
 
 
+def test_warp_align_corners_false_convention():
+    """The warp's grid_sample convention is a setting (kornia, absent here, changed its default between 0.4.1 and
+    the reference's pinned 0.5.0 and nothing in the reference pins a result): with align_corners=False the forward, the backward
+    and the F16K gated warp follow the oracle run with the same setting, and the default is restored afterwards."""
+    ops = _ops()
+    from masic_amd import synth
+    from masic_amd.homography import warp_matrices
+    H, W = 48, 80
+    x, _, hm = synth.synth_inputs(2, H, W, seed=6)
+    m, _ = warp_matrices(hm.to(DEV), (H, W), (H, W), want_inverse=True)
+    assert ops.get_warp_align_corners()
+    ref_true = O.warp_perspective(x, hm, (H, W))
+    xr = x.clone().requires_grad_(True)
+    ref_false = O.warp_perspective(xr, hm, (H, W), align_corners=False)
+    g = _rand(2, 3, H, W, seed=61)
+    ref_false.backward(g)
+    assert float((ref_false.detach() - ref_true).abs().max()) > 1e-3          # the two conventions differ on this input
+    ops.set_warp_align_corners(False)
+    try:
+        assert not ops.get_warp_align_corners()
+        assert_close(ops.warp_perspective(x.to(DEV), m, (H, W)), ref_false.detach(), "warp, align_corners=False")
+        assert_close(ops.warp_perspective_bwd(g.to(DEV), m, tuple(x.shape)), xr.grad, "warp backward, align_corners=False", rtol=1e-4)
+        # F16K gated warp (Independent_EN's bf16 path): the same sampling on bf16 records
+        C = 16
+        f = _rand(2, C, H, W, seed=62)
+        f16 = ops.nchw_to_f16k(f.to(DEV))
+        dst = ops.f16k_empty(2, C, H, W, DEV)
+        ops.f16k_gate(f16, 2, C, H, W, dst, C, 0, minv=m)
+        want = O.warp_perspective(f.bfloat16().float(), hm, (H, W), align_corners=False)
+        got = ops.f16k_to_nchw_dev(dst, 2, C, H, W)
+        assert float((got.cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())      # bf16 store of the result
+    finally:
+        ops.set_warp_align_corners(True)
+    assert_close(ops.warp_perspective(x.to(DEV), m, (H, W)), ref_true, "warp, default convention restored")
+
+
 def test_reductions_and_small_helpers():
     ops = _ops()
     lik = torch.rand(3, 50, 17, 11) * 0.9 + 1e-6
