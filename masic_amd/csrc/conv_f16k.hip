@@ -374,7 +374,7 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
 // consumes two consecutive slabs of the step, one per lane half: with KS = 2 the two channel blocks of a tap, with KS = 1
 // two consecutive taps.  DMA, LDS images, ring and geometry are the bf16 kernel's (a record is 32 bytes in both layouts).
 template <int KS, int T, int D, int PSP, int L, bool GDN, int NM, int NP, bool F8 = false>
-__global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
+__global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs a) {     // D == 1: the two-workgroups-per-CU ("lite") configurations
     static_assert(!GDN || NM == 4, "the fused GDN needs all 128 channels");
     static_assert(!F8 || (NM == 4 && NP == 1 && (T * KS) % 2 == 0 && T <= 4), "fp8 operands: 128-channel blocks, 256-pixel tiles, slab pairs");
     static_assert(NM + NP == 2 || NM + NP == 3 || NM + NP == 4 || NM + NP == 5 || NM + NP == 6, "fragment-wait helpers exist for 2, 4, 5 and 6 fragments per k-step");
@@ -556,7 +556,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
             }
         };
         constexpr int NPIECES = WI > PSP ? WI : PSP;
-        if (!F16K_DMA_SPREAD) dma_pieces(0, NPIECES);
+        // D == 1: the slab group of the NEXT step is awaited at the end of this one, so it goes out first (its latency budget is the
+        // step; the CU's other workgroup covers what is left of it)
+        constexpr bool SPREAD = F16K_DMA_SPREAD != 0 && D > 1;
+        if (!SPREAD) dma_pieces(0, NPIECES);
         // LDS reads of the K loop go through inline asm with hand-counted lgkmcnt: for a compiler-visible ds_read hipcc puts
         // `s_waitcnt vmcnt(0)` in front (the DMA in flight might alias it), which would drain the prefetch queue every step.
         // The fragments of k-step i+1 are requested before the MFMAs of k-step i are issued.
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16k(const F16kArgs a) {
                 });
             });
             }
-            if constexpr (F16K_DMA_SPREAD != 0) {
+            if constexpr (SPREAD) {
                 constexpr int per = (NPIECES + NKS - 1) / NKS;
                 __builtin_amdgcn_sched_barrier(0);
                 dma_pieces(i * per, (i + 1) * per);
@@ -1024,6 +1027,16 @@ F16kCfg choose_f16k(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         // patch look-ahead and a 3-slot ring.  MASIC_F16K_KS2=0 keeps 16-channel chunks (A/B timing).
         static const bool ks2 = !(getenv("MASIC_F16K_KS2") && getenv("MASIC_F16K_KS2")[0] == '0');
         if (ks2 && c.NP == 2 && d.Cin % 32 == 0) { c.KS = 2; c.D = 2; c.L = 1; NPI = 10; }
+        // 64 / 96 output channels (no GDN: that needs 128) (the 3x3 layers of Independent_EN and their input gradients): the K loop is short (K = 9 x
+        // 32 ... 96) and the per-workgroup prologue + epilogue were 35 % of a workgroup's life (in-kernel stamps: 4.9 + 17.5 + 5.6 us
+        // on the 96 -> 96 layer).  "Lite" configuration: 256-pixel tiles, 2-slot weight ring, 2 patch buffers = 77 KiB of LDS and
+        // <= 128 VGPRs, so that TWO workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
+        // MASIC_F16K_LITE=0 keeps the 512-pixel single-workgroup form (A/B timing).
+        static const bool lite = !(getenv("MASIC_F16K_LITE") && getenv("MASIC_F16K_LITE")[0] == '0');
+        static const int lite_min = getenv("MASIC_F16K_LITE_MIN") ? atoi(getenv("MASIC_F16K_LITE_MIN")) : 33;     // smallest Cout that takes it
+        if (lite && c.NP > 1 && d.Cout >= lite_min && d.Cout <= 96 && d.Cin % 32 == 0 && ceil_div(min_taps, 2) >= 2) {
+            c.NP = 1; c.KS = 2; c.T = 2; c.D = 1; c.L = 1; NPI = 6;
+        }
     }
     if (ceil_div(max_taps, c.T) * (c.T == 5 ? 8 : c.T) > MAXTAPS || ceil_div(min_taps, c.T) < 2) return c;
     c.Cin16 = d.Cin / cblk;                                   // channel blocks (records) per pixel
@@ -1089,6 +1102,7 @@ extern "C" int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, 
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     const int nm = (d->Cout <= 32 && !gdn) ? 1 : 4;
     if (d->prec == MASIC_PREC_FP8) snprintf(buf, n, "conv_f16k<%d, %d, %d, %d, %d, %s, 4, 1, true>", c.KS, c.T, F16K_D, c.KS == 1 ? 6 : 4, c.L, gdn ? "true" : "false");
+    else if (c.D == 1) snprintf(buf, n, "conv_f16k<2, 2, 1, 3, 1, false, %d, 1, false>", d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 3));
     else if (c.NP == 2 && c.KS == 2 && !gdn && d->Cout <= 96) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, false, %d, 2, false>", d->Cout <= 64 ? 2 : 3);
     else if (c.NP == 2 && c.KS == 2) snprintf(buf, n, "conv_f16k<2, 2, 2, 5, 1, %s, 4, 2, false>", gdn ? "true" : "false");
     else if (c.NP > 1) snprintf(buf, n, "conv_f16k<1, 2, %d, %d, 2, %s, %d, %d, false>", F16K_D, c.NP == 4 ? 5 : 3, gdn ? "true" : "false", nm, c.NP);
@@ -1328,6 +1342,11 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
         else if (msplit == 4) F16K_LAUNCH(1, 4, 6, 1, false, 1, 1);
         else if (msplit == 2) F16K_LAUNCH(1, 4, 6, 1, false, 2, 1);
         else F16K_LAUNCH(1, 4, 6, 1, false, 4, 1);
+    } else if (c.D == 1) {
+        MASIC_REQUIRE(gdn_packed == nullptr && d->Cout <= 96, MASIC_ERR_UNSUPPORTED, "conv_f16k: lite configuration with GDN / > 96 channels");
+        if (d->Cout <= 32) F16K_LAUNCH_D(2, 2, 1, 3, 1, false, 1, 1);
+        else if (d->Cout <= 64) F16K_LAUNCH_D(2, 2, 1, 3, 1, false, 2, 1);
+        else F16K_LAUNCH_D(2, 2, 1, 3, 1, false, 3, 1);
     } else {
         if (gdn_packed) F16K_LAUNCH(2, 2, 4, 2, true, 4, 1);
         else if (d->Cout <= 32 || msplit == 4) F16K_LAUNCH(2, 2, 4, 2, false, 1, 1);
