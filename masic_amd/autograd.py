@@ -380,6 +380,12 @@ class EnhancementBlockFn(Function):
         blocks = ((ctx.eb.RB1, x0, t1, u1), (ctx.eb.RB2, o1, t2, u2), (ctx.eb.RB3, o2, t3, u3))
         d16 = ops.make_conv_desc(B, C, H, W, C, 3, 3, 1, 1, transposed=True, in_ctot=C, out_ctot=C, prec=PREC_BF16)
         grads = [None] * 12
+        resident = ctx.eb.RB1.conv1.resident_supported(B, H, W)
+
+        def dgrad(g16, w, **kw):            # the transposed convolution on the same weight, epilogue operands as conv2d_f16k_res
+            if resident:
+                return ops.conv3x3_resident(g16, ops.pack_conv3x3_resident_weight(w.detach(), transposed=True), None, B, C, H, W, res_ctot=C, **kw)
+            return ops.conv2d_f16k_res(g16, ops.pack_conv_f16k_weight(w.detach(), d16), None, d16, res_ctot=C, **kw)
         go = g_out
         for i in (2, 1, 0):
             rb, x_in, t, u = blocks[i]
@@ -387,11 +393,11 @@ class EnhancementBlockFn(Function):
             gu = ops.f16k_act_bwd(go, u, 0.01)
             grads[4 * i + 2] = ops.conv3x3_wgrad_f16k(t, gu, B, C, C, H, W)
             grads[4 * i + 3] = ops.f16k_channel_sum(gu, B, C, H * W)
-            gt = ops.conv2d_f16k_res(gu, ops.pack_conv_f16k_weight(w2.detach(), d16), None, d16, res_ctot=C, mask=t, mask_slope=0.01)
+            gt = dgrad(gu, w2, mask=t, mask_slope=0.01)
             del gu
             grads[4 * i] = ops.conv3x3_wgrad_f16k(x_in, gt, B, C, C, H, W)
             grads[4 * i + 1] = ops.f16k_channel_sum(gt, B, C, H * W)
-            go = ops.conv2d_f16k_res(gt, ops.pack_conv_f16k_weight(w1.detach(), d16), None, d16, res1=go, res2=g_out if i == 0 else None, res_ctot=C)
+            go = dgrad(gt, w1, res1=go, res2=g_out if i == 0 else None)
             del gt
         gx = ops.f16k_to_nchw_dev(go, B, C, H, W) if ctx.needs_input_grad[0] else None
         return (gx, None, None, g_res) + tuple(grads) + (() if tail is None else (g_tw, g_tb))

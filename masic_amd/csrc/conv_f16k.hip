@@ -1721,3 +1721,270 @@ extern "C" int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const
 // (100 MHz)} pairs at kernel entry, K-loop entry, K-loop exit and kernel exit of its first [0..7] and last [8..15] workgroup;
 // NULL switches it off.  tools/f16k_stamps.py reads the phases and the shader clock the chip held from them.
 extern "C" void masic_conv_f16k_set_stamps(void* device_buffer) { g_f16k_stamps = (unsigned long long*)device_buffer; }
+
+// ------------------------------------------------------------------------------------------ 3x3 layers with resident weights
+// Conv2d(C -> C, k3, s1, p1) (or its input gradient) on F16K for C = 32: the 32-channel stage of Independent_EN (reference
+// MASIC.py:149-164, 1470-1471 -- 12 of its 36 convolutions, and as many input gradients in training).  K = 288 is 18 MFMA k-steps: on
+// conv_f16k such a layer is three quarters per-workgroup prologue / epilogue (171 us per launch at 8 x 512^2 against an HBM floor of
+// ~45).  Here the whole weight tensor (18 KiB of bf16 fragments) stays in LDS for the life of a PERSISTENT workgroup that walks
+// over 16 x 32-pixel tiles of one XCD's share of the images:
+//   * waves 8-11 are loaders: per tile they issue the 39 `buffer_load ... lds` pieces of the (18 x 34 pixel x 32 channel) patch two
+//     tiles ahead into a ring of three buffers (10 pieces each: a single wave needs 60-185 cycles per piece, 121 -> see DESIGN.md us
+//     per launch with one loader) and wait -- with a counted vmcnt, nothing else is on their counter -- for the patch of the
+//     NEXT tile; padding pixels are out-of-range buffer offsets (zero fill);
+//   * waves 0-7 own two image rows of the tile each: 18 k-steps x (1 weight + 2 patch fragments by ds_read_b128, 2 MFMAs), then
+//     the F16K epilogue of conv_f16k (bias, activation, act'(mask), pre-residual copy, residual adds, 16-byte stores);
+//   * ONE barrier per tile hands the landed patch to the compute waves and the drained buffer back to the loader.
+// HBM-bound by design: 39 KiB in + 32 KiB out (+ residuals) per tile against 36 MFMAs per wave.
+struct C3Args {
+    const unsigned short* x; const unsigned short* w; const float* bias;
+    const unsigned short* res1; const unsigned short* res2; const unsigned short* mask16; unsigned short* y_pre; unsigned short* y16;
+    int B, H, W, in_ctot16, in_c16off, out_ctot, out_coff, res_ctot, act;
+    float mask_slope;
+    int tiles_w, tiles_per_image, ntiles;
+};
+
+namespace {
+
+// s_barrier that the compiler does not move LDS accesses across (the intrinsic alone is "no memory"); no hardware wait is added:
+// what crosses it here was waited for explicitly (the loader's vmcnt) or consumed by MFMAs (the compute waves' fragment reads)
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int C>
+__global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) {
+    constexpr int KB = C / 16;                         // 16-channel blocks = 32-byte records per pixel
+    constexpr int TH = 16, TW = 32, PWd = TW + 2, NPIX = (TH + 2) * PWd;
+    constexpr int PREC = KB * 2 * NPIX;                // 16-byte records of a patch: [kb][k-half][pixel]
+    constexpr int NI = (PREC + 63) / 64;               // DMA wave-instructions per patch
+    constexpr int PBYTES = NI * 1024;
+    constexpr int SLAB = 2 * C * 16;                   // one (tap, kb) weight slab: [k-half][co]
+    constexpr int WBYTES = 9 * KB * SLAB;
+    constexpr int NWI = WBYTES / 1024;
+    constexpr int NBUF = 3;
+    constexpr int NLW = 4;                             // loader waves (8 .. 11): one wave issues a 1-KiB piece every 60-185 cycles
+    constexpr int NIW = (NI + NLW - 1) / NLW;          // pieces per loader wave and patch (the last wave pads with sink pieces)
+    constexpr int NWW = (NWI + NLW - 1) / NLW;         // weight pieces per loader wave
+    constexpr int SINK = WBYTES + NBUF * PBYTES;       // 1 KiB that padding pieces write zeros to
+    static_assert(C == 32, "accumulator / wave mapping below is the 32-channel one");
+    static_assert(NIW + NWW <= 60 && WBYTES % 1024 == 0, "vmcnt is 6 bits; whole DMA pieces");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // [weights][NBUF patches][sink]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // tiles of XCD k (workgroup ids go round-robin over the 8 XCDs) are one contiguous eighth of the tile list -- whole images when
+    // B % 8 == 0 -- so the halos neighbouring tiles share are re-read from that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int per = (a.ntiles + 7) >> 3;
+    const int t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
+    const int t_first = xcd * per + slot;
+    const int n_my = t_first < t_end ? (t_end - t_first + nslot - 1) / nslot : 0;
+    if (n_my == 0) return;
+    const int HW = a.H * a.W;
+    const int plane_bytes = HW * 32;
+
+    if (wave >= 8) {
+        // ---- loaders: wave 8 + lw takes pieces lw, lw + 4, ... of every patch
+        const int lw = wave - 8;
+        int packed[NIW];                               // plane << 16 | patch row << 8 | patch column of this lane's record in piece I
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int q = (k * NLW + lw) * 64 + lane;
+            const int plane = q / NPIX, p = q - plane * NPIX;
+            const int pr = p / PWd, pc = p - pr * PWd;
+            packed[k] = q < PREC ? (plane << 16 | pr << 8 | pc) : -1;
+        }
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, WBYTES, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NWW; ++k) {
+            const int piece = k * NLW + lw;
+            dma_buf16(rw, lds + (piece < NWI ? piece * 1024 : SINK), piece < NWI ? lane * 16 : 0x7ffffff0, piece < NWI ? piece * 1024 : 0);
+        }
+        auto issue = [&](int i) {
+            const int tile = t_first + i * nslot;
+            const int b = tile / a.tiles_per_image, rem = tile - b * a.tiles_per_image;
+            const int th_i = rem / a.tiles_w, tw_i = rem - th_i * a.tiles_w;
+            const int ih0 = th_i * TH - 1, iw0 = tw_i * TW - 1;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.x + ((size_t)b * a.in_ctot16 + a.in_c16off) * (size_t)HW * 16), 0, KB * plane_bytes, 0x00020000);
+            unsigned char* dst = lds + WBYTES + (i % NBUF) * PBYTES;
+#pragma unroll
+            for (int k = 0; k < NIW; ++k) {
+                const int pk = packed[k], piece = k * NLW + lw;
+                const int ih = ih0 + ((pk >> 8) & 0xff), iw = iw0 + (pk & 0xff);
+                const bool ok = pk >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                const int plane = pk >> 16;
+                const int voff = ok ? (plane >> 1) * plane_bytes + (ih * a.W + iw) * 32 + (plane & 1) * 16 : 0x7ffffff0;
+                dma_buf16(rx, piece < NI ? dst + piece * 1024 : lds + SINK, voff, 0);
+            }
+        };
+        issue(0);
+        if (n_my > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");       // weights + tile 0 have landed, tile 1 may be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        wg_barrier();
+        for (int i = 0; i < n_my; ++i) {
+            // the buffer of tile i + 2 is the one tile i - 1 was read from: every compute wave left it before the last barrier
+            if (i + 2 < n_my) {
+                issue(i + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");   // tile i + 1 has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wg_barrier();
+        }
+        return;
+    }
+
+    // ---- compute waves: wave w owns rows 2w, 2w + 1 of the tile (two 32-pixel x 32-channel accumulator tiles)
+    const unsigned char* wa = lds + (h * C + j) * 16;                                   // lane part of the weight fragments
+    const int pbl = WBYTES + (h * NPIX + 2 * wave * PWd + j) * 16;                      // lane part of the patch fragments
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = a.bias != nullptr ? a.bias[4 * h + (e & 3) + 8 * (e >> 2)] : 0.0f;
+    wg_barrier();                                                       // weights + tile 0 are in LDS
+    for (int i = 0; i < n_my; ++i) {
+        const unsigned char* pb = lds + pbl + (i % NBUF) * PBYTES;
+        const int tile = t_first + i * nslot;
+        const int b = tile / a.tiles_per_image, rem = tile - b * a.tiles_per_image;
+        const int th_i = rem / a.tiles_w, tw_i = rem - th_i * a.tiles_w;
+        const unsigned op16 = (unsigned)HW * 16;
+        const size_t opix0 = (size_t)(th_i * TH + 2 * wave) * a.W + tw_i * TW + j;
+        const size_t ro0 = ((size_t)b * (a.res_ctot >> 4) * HW + opix0) * 16 + 4 * h;      // row n: + n * W * 16
+        // residual / mask operands of the epilogue are requested BEFORE the MFMAs (their HBM latency runs under the tile's work):
+        // lane (j, h) needs 4 consecutive bf16 at element 8(q & 1) + 4h of record q >> 1, q = 0..3 (add_f16k_residual)
+        uint2 rv1[2][4], rv2[2][4], mv[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t o = ro0 + (size_t)n * a.W * 16 + (size_t)(q >> 1) * op16 + 8 * (q & 1);
+                if (a.res1 != nullptr) rv1[n][q] = *reinterpret_cast<const uint2*>(a.res1 + o);
+                if (a.res2 != nullptr) rv2[n][q] = *reinterpret_cast<const uint2*>(a.res2 + o);
+                if (a.mask16 != nullptr) mv[n][q] = *reinterpret_cast<const uint2*>(a.mask16 + o);
+            }
+        f32x16 acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int ty = t / 3, tx = t - 3 * ty;
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(wa + (t * KB + kb) * SLAB);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const bf16x8 bw = *reinterpret_cast<const bf16x8*>(pb + (kb * 2 * NPIX + (ty + n) * PWd + tx) * 16);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue (the F16K store path of conv_f16k for one 32-channel tile)
+        auto add4 = [](f32x16& tt, int q, const uint2 r) {
+            tt[4 * q + 0] += __builtin_bit_cast(float, r.x << 16);
+            tt[4 * q + 1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
+            tt[4 * q + 2] += __builtin_bit_cast(float, r.y << 16);
+            tt[4 * q + 3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
+        };
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const size_t opix = opix0 + (size_t)n * a.W;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = apply_act(acc[n][e] + bv[e], a.act);
+            if (a.mask16 != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[n][4 * q + 0] *= __builtin_bit_cast(float, mv[n][q].x << 16) > 0.0f ? 1.0f : a.mask_slope;
+                    acc[n][4 * q + 1] *= __builtin_bit_cast(float, mv[n][q].x & 0xffff0000u) > 0.0f ? 1.0f : a.mask_slope;
+                    acc[n][4 * q + 2] *= __builtin_bit_cast(float, mv[n][q].y << 16) > 0.0f ? 1.0f : a.mask_slope;
+                    acc[n][4 * q + 3] *= __builtin_bit_cast(float, mv[n][q].y & 0xffff0000u) > 0.0f ? 1.0f : a.mask_slope;
+                }
+            }
+            if (a.y_pre != nullptr) store_f16k_tile(acc[n], a.y_pre + ro0 + (size_t)n * a.W * 16 + 4 * h, op16);
+            if (a.res1 != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) add4(acc[n], q, rv1[n][q]);
+            }
+            if (a.res2 != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) add4(acc[n], q, rv2[n][q]);
+            }
+            store_f16k_tile(acc[n], a.y16 + (((size_t)b * (a.out_ctot >> 4) + (a.out_coff >> 4)) * HW + opix) * 16 + 8 * h, op16);
+        }
+        wg_barrier();          // tile i + 1 has landed (loader); this tile's buffer may be refilled
+    }
+}
+
+// weights of Conv2d(C -> C, 3x3) [C][C][3][3] float32 -> bf16 fragment slabs [tap][kb][k-half][co][8 k];  transposed: the slabs of the
+// layer's INPUT gradient (the stride-1 transposed convolution on the same tensor: taps mirrored, channel roles swapped)
+__global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int C, int transposed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                 // one 16-byte record: (tap, kb, hh, co)
+    const int KB = C / 16;
+    if (idx >= 9 * KB * 2 * C) return;
+    const int co = idx % C, hh = (idx / C) & 1, kb = (idx / (2 * C)) % KB, t = idx / (2 * C * KB);
+    unsigned v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float f[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ci = kb * 16 + hh * 8 + 2 * p + q;
+            f[q] = transposed ? w[((size_t)ci * C + co) * 9 + (8 - t)] : w[((size_t)co * C + ci) * 9 + t];
+        }
+        v[p] = pack2bf(f[0], f[1]);
+    }
+    reinterpret_cast<uint4*>(out)[idx] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace
+
+extern "C" size_t masic_conv3x3_resident_packed_bytes(int C) { return C == 32 ? (size_t)9 * (C / 16) * 2 * C * 16 : 0; }
+
+extern "C" int masic_conv3x3_resident_supported(int B, int C, int H, int W) {
+    return B > 0 && C == 32 && H % 16 == 0 && W % 32 == 0 && H <= 255 * 16 && (long)H * W * 32 * (C / 16) < (1l << 31);
+}
+
+extern "C" int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int C, int transposed, void* stream) {
+    MASIC_REQUIRE(w && w_packed && C == 32, MASIC_ERR_UNSUPPORTED, "conv3x3_resident_pack_weight: C = 32 only");
+    hipLaunchKernelGGL(pack_c3_weights_kernel, dim3(ceil_div(9 * (C / 16) * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)w_packed, C, transposed);
+    return masic_launch_status("conv3x3_resident_pack_weight");
+}
+
+// y = act(conv3x3(x) + bias) * act'(mask) + res1 + res2 on F16K buffers, y_pre = the value before the adds (see
+// masic_conv_f16k_res_ex_fwd: same meaning of every operand); x: channels [in_coff, in_coff + C) of an in_ctot-channel buffer,
+// y: channels [out_coff, out_coff + C) of an out_ctot-channel buffer, residual / mask / pre tensors: res_ctot channels.
+extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                                          const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int C, int H, int W, int in_ctot,
+                                          int in_coff, int out_ctot, int out_coff, int act, void* stream) {
+    MASIC_REQUIRE(x_f16k && w_packed && y_f16k, MASIC_ERR_ARG, "conv3x3_resident_fwd: null pointer");
+    MASIC_REQUIRE(masic_conv3x3_resident_supported(B, C, H, W), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: needs C = 32, H %% 16 == 0, W %% 32 == 0");
+    MASIC_REQUIRE(in_ctot % 16 == 0 && in_coff % 16 == 0 && in_coff >= 0 && in_coff + C <= in_ctot && out_ctot % 16 == 0 && out_coff % 16 == 0 &&
+                      out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "conv3x3_resident_fwd: channel views");
+    MASIC_REQUIRE(res1 != nullptr || res2 == nullptr, MASIC_ERR_ARG, "conv3x3_resident_fwd: res2 without res1");
+    MASIC_REQUIRE((res1 == nullptr && mask == nullptr && y_pre_f16k == nullptr) || (res_ctot % 16 == 0 && res_ctot >= C), MASIC_ERR_SHAPE,
+                  "conv3x3_resident_fwd: residual / mask / pre tensors need >= C channels, a multiple of 16");
+    MASIC_REQUIRE(act == MASIC_ACT_NONE || act == MASIC_ACT_RELU || act == MASIC_ACT_LEAKY, MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: activation");
+    const int tiles_w = W / 32, tiles_h = H / 16;
+    C3Args a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (const unsigned short*)res1, (const unsigned short*)res2,
+             (const unsigned short*)mask, (unsigned short*)y_pre_f16k, (unsigned short*)y_f16k, B, H, W, in_ctot / 16, in_coff / 16, out_ctot, out_coff,
+             res_ctot, act, mask_slope, tiles_w, tiles_w * tiles_h, B * tiles_w * tiles_h};
+    constexpr int LDS_BYTES = 9 * 2 * 2 * 32 * 16 + 3 * ((2 * 2 * 18 * 34 + 63) / 64) * 1024 + 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int grid = 256;                                                  // one persistent workgroup per CU
+    if (a.ntiles < grid) grid = round_up(a.ntiles, 8);
+    hipLaunchKernelGGL(conv3x3_resident_f16k<32>, dim3(grid), dim3(768), LDS_BYTES, (hipStream_t)stream, a);
+    return masic_launch_status("conv3x3_resident_fwd");
+}

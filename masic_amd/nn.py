@@ -18,6 +18,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_FP8
 
 _PRECISION = {"f32": PREC_F32, "bf16": PREC_BF16, "fp8": PREC_BF16}[os.environ.get("MASIC_PRECISION", "f32")]
 _FP8 = os.environ.get("MASIC_PRECISION", "f32") == "fp8"
+_C3_RESIDENT = os.environ.get("MASIC_C3_RESIDENT", "1") != "0"
 
 
 def set_precision(name):
@@ -252,9 +253,21 @@ class _PackedWeightMixin:
         """No autograd: F16K -> F16K (optionally a channel view of `out16`) with F16K residual tensors added after the activation;
         `y_pre` (F16K, res_ctot channels) receives the activation's output before the adds (what a backward needs for its mask)."""
         oc = (self.out_channels + 15) // 16 * 16 if out_ctot is None else out_ctot
+        bias = None if self.bias is None else self.bias.detach()
+        if self.resident_supported(B, Hi, Wi) and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY):
+            # 32 -> 32 3x3 layers: weights resident in LDS, persistent workgroups (conv_f16k.hip: conv3x3_resident_f16k)
+            w = self.weight
+            wp = _cached(self, "_packed_c3_cache", (w._version, w.data_ptr(), str(w.device)), (), lambda: ops.pack_conv3x3_resident_weight(w.detach()))
+            return ops.conv3x3_resident(x16, wp, bias, B, self.in_channels, Hi, Wi, act=act, y16=out16, out_ctot=oc, out_coff=out_coff,
+                                        res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
         desc = self._desc_f16k(B, Hi, Wi, out_ctot=oc, out_coff=out_coff, act=act)
-        return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc, y16=out16,
+        return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), bias, desc, y16=out16,
                                    res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
+
+    def resident_supported(self, B, Hi, Wi):
+        """Conv2d(32 -> 32, k3, s1, p1) at H % 16 == 0, W % 32 == 0: the resident-weight kernel (MASIC_C3_RESIDENT=0: conv_f16k, A/B timing)."""
+        return (_C3_RESIDENT and not self.transposed_conv and not self.masked_conv and self.in_channels == self.out_channels
+                and self._geometry() == (3, 3, 1, 1) and ops.conv3x3_resident_supported(B, self.in_channels, Hi, Wi))
 
     def few_supported(self, B, Hi, Wi):
         kh, kw, s_, p_ = self._geometry()
