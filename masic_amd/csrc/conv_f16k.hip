@@ -1757,20 +1757,22 @@ __device__ __forceinline__ void wg_barrier() {
 template <int C>
 __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) {
     constexpr int KB = C / 16;                         // 16-channel blocks = 32-byte records per pixel
-    constexpr int TH = 16, TW = 32, PWd = TW + 2, NPIX = (TH + 2) * PWd;
+    constexpr int NM = C / 32;                         // 32-channel accumulator tiles per pixel; a wave owns one of them for two image rows
+    constexpr int TH = 16 / NM, TW = 32, PWd = TW + 2, NPIX = (TH + 2) * PWd;
     constexpr int PREC = KB * 2 * NPIX;                // 16-byte records of a patch: [kb][k-half][pixel]
     constexpr int NI = (PREC + 63) / 64;               // DMA wave-instructions per patch
     constexpr int PBYTES = NI * 1024;
     constexpr int SLAB = 2 * C * 16;                   // one (tap, kb) weight slab: [k-half][co]
     constexpr int WBYTES = 9 * KB * SLAB;
     constexpr int NWI = WBYTES / 1024;
-    constexpr int NBUF = 3;
+    constexpr int NBUF = C == 32 ? 3 : 2;              // patch ring (64 channels: 72 KiB of weights leave room for two 43-KiB patches)
+    constexpr int PD = NBUF - 1;                       // tiles of look-ahead
     constexpr int NLW = 4;                             // loader waves (8 .. 11): one wave issues a 1-KiB piece every 60-185 cycles
     constexpr int NIW = (NI + NLW - 1) / NLW;          // pieces per loader wave and patch (the last wave pads with sink pieces)
     constexpr int NWW = (NWI + NLW - 1) / NLW;         // weight pieces per loader wave
     constexpr int SINK = WBYTES + NBUF * PBYTES;       // 1 KiB that padding pieces write zeros to
-    static_assert(C == 32, "accumulator / wave mapping below is the 32-channel one");
-    static_assert(NIW + NWW <= 60 && WBYTES % 1024 == 0, "vmcnt is 6 bits; whole DMA pieces");
+    static_assert(C == 32 || C == 64, "8 compute waves = (16 / NM row pairs) x NM channel tiles");
+    static_assert(PD * NIW + NWW <= 60 && WBYTES % 1024 == 0 && SINK + 1024 <= 160 * 1024, "vmcnt is 6 bits; whole DMA pieces; LDS");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // [weights][NBUF patches][sink]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1823,7 +1825,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
             }
         };
         issue(0);
-        if (n_my > 1) {
+        if (PD == 2 && n_my > 1) {
             issue(1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");       // weights + tile 0 have landed, tile 1 may be in flight
         } else {
@@ -1831,10 +1833,10 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
         }
         wg_barrier();
         for (int i = 0; i < n_my; ++i) {
-            // the buffer of tile i + 2 is the one tile i - 1 was read from: every compute wave left it before the last barrier
-            if (i + 2 < n_my) {
-                issue(i + 2);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");   // tile i + 1 has landed
+            // the buffer of tile i + PD is the one tile i - 1 was read from: every compute wave left it before the last barrier
+            if (i + PD < n_my) {
+                issue(i + PD);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NIW) : "memory");   // tile i + 1 has landed
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1843,12 +1845,13 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
         return;
     }
 
-    // ---- compute waves: wave w owns rows 2w, 2w + 1 of the tile (two 32-pixel x 32-channel accumulator tiles)
-    const unsigned char* wa = lds + (h * C + j) * 16;                                   // lane part of the weight fragments
-    const int pbl = WBYTES + (h * NPIX + 2 * wave * PWd + j) * 16;                      // lane part of the patch fragments
+    // ---- compute waves: wave w owns channel tile w % NM for rows 2 (w / NM), 2 (w / NM) + 1 of the tile (two 32 x 32 accumulator tiles)
+    const int mt = wave % NM, row0 = 2 * (wave / NM);
+    const unsigned char* wa = lds + (h * C + mt * 32 + j) * 16;                         // lane part of the weight fragments
+    const int pbl = WBYTES + (h * NPIX + row0 * PWd + j) * 16;                          // lane part of the patch fragments
     float bv[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = a.bias != nullptr ? a.bias[4 * h + (e & 3) + 8 * (e >> 2)] : 0.0f;
+    for (int e = 0; e < 16; ++e) bv[e] = a.bias != nullptr ? a.bias[mt * 32 + 4 * h + (e & 3) + 8 * (e >> 2)] : 0.0f;
     wg_barrier();                                                       // weights + tile 0 are in LDS
     for (int i = 0; i < n_my; ++i) {
         const unsigned char* pb = lds + pbl + (i % NBUF) * PBYTES;
@@ -1856,8 +1859,8 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
         const int b = tile / a.tiles_per_image, rem = tile - b * a.tiles_per_image;
         const int th_i = rem / a.tiles_w, tw_i = rem - th_i * a.tiles_w;
         const unsigned op16 = (unsigned)HW * 16;
-        const size_t opix0 = (size_t)(th_i * TH + 2 * wave) * a.W + tw_i * TW + j;
-        const size_t ro0 = ((size_t)b * (a.res_ctot >> 4) * HW + opix0) * 16 + 4 * h;      // row n: + n * W * 16
+        const size_t opix0 = (size_t)(th_i * TH + row0) * a.W + tw_i * TW + j;
+        const size_t ro0 = (((size_t)b * (a.res_ctot >> 4) + 2 * mt) * HW + opix0) * 16 + 4 * h;      // row n: + n * W * 16
         // residual / mask operands of the epilogue are requested BEFORE the MFMAs (their HBM latency runs under the tile's work):
         // lane (j, h) needs 4 consecutive bf16 at element 8(q & 1) + 4h of record q >> 1, q = 0..3 (add_f16k_residual)
         uint2 rv1[2][4], rv2[2][4], mv[2][4];
@@ -1918,7 +1921,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) add4(acc[n], q, rv2[n][q]);
             }
-            store_f16k_tile(acc[n], a.y16 + (((size_t)b * (a.out_ctot >> 4) + (a.out_coff >> 4)) * HW + opix) * 16 + 8 * h, op16);
+            store_f16k_tile(acc[n], a.y16 + (((size_t)b * (a.out_ctot >> 4) + (a.out_coff >> 4) + 2 * mt) * HW + opix) * 16 + 8 * h, op16);
         }
         wg_barrier();          // tile i + 1 has landed (loader); this tile's buffer may be refilled
     }
@@ -1947,14 +1950,14 @@ __global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __res
 
 }  // namespace
 
-extern "C" size_t masic_conv3x3_resident_packed_bytes(int C) { return C == 32 ? (size_t)9 * (C / 16) * 2 * C * 16 : 0; }
+extern "C" size_t masic_conv3x3_resident_packed_bytes(int C) { return (C == 32 || C == 64) ? (size_t)9 * (C / 16) * 2 * C * 16 : 0; }
 
 extern "C" int masic_conv3x3_resident_supported(int B, int C, int H, int W) {
-    return B > 0 && C == 32 && H % 16 == 0 && W % 32 == 0 && H <= 255 * 16 && (long)H * W * 32 * (C / 16) < (1l << 31);
+    return B > 0 && (C == 32 || C == 64) && H % (512 / C) == 0 && W % 32 == 0 && (long)H * W * 32 * (C / 16) < (1l << 31);
 }
 
 extern "C" int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int C, int transposed, void* stream) {
-    MASIC_REQUIRE(w && w_packed && C == 32, MASIC_ERR_UNSUPPORTED, "conv3x3_resident_pack_weight: C = 32 only");
+    MASIC_REQUIRE(w && w_packed && (C == 32 || C == 64), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_pack_weight: C = 32 or 64");
     hipLaunchKernelGGL(pack_c3_weights_kernel, dim3(ceil_div(9 * (C / 16) * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)w_packed, C, transposed);
     return masic_launch_status("conv3x3_resident_pack_weight");
 }
@@ -1966,25 +1969,29 @@ extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_pack
                                           const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int C, int H, int W, int in_ctot,
                                           int in_coff, int out_ctot, int out_coff, int act, void* stream) {
     MASIC_REQUIRE(x_f16k && w_packed && y_f16k, MASIC_ERR_ARG, "conv3x3_resident_fwd: null pointer");
-    MASIC_REQUIRE(masic_conv3x3_resident_supported(B, C, H, W), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: needs C = 32, H %% 16 == 0, W %% 32 == 0");
+    MASIC_REQUIRE(masic_conv3x3_resident_supported(B, C, H, W), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: needs C = 32 (H %% 16 == 0) or 64 (H %% 8 == 0), W %% 32 == 0");
     MASIC_REQUIRE(in_ctot % 16 == 0 && in_coff % 16 == 0 && in_coff >= 0 && in_coff + C <= in_ctot && out_ctot % 16 == 0 && out_coff % 16 == 0 &&
                       out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "conv3x3_resident_fwd: channel views");
     MASIC_REQUIRE(res1 != nullptr || res2 == nullptr, MASIC_ERR_ARG, "conv3x3_resident_fwd: res2 without res1");
     MASIC_REQUIRE((res1 == nullptr && mask == nullptr && y_pre_f16k == nullptr) || (res_ctot % 16 == 0 && res_ctot >= C), MASIC_ERR_SHAPE,
                   "conv3x3_resident_fwd: residual / mask / pre tensors need >= C channels, a multiple of 16");
     MASIC_REQUIRE(act == MASIC_ACT_NONE || act == MASIC_ACT_RELU || act == MASIC_ACT_LEAKY, MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: activation");
-    const int tiles_w = W / 32, tiles_h = H / 16;
+    const int tiles_w = W / 32, tiles_h = H / (512 / C);
     C3Args a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (const unsigned short*)res1, (const unsigned short*)res2,
              (const unsigned short*)mask, (unsigned short*)y_pre_f16k, (unsigned short*)y_f16k, B, H, W, in_ctot / 16, in_coff / 16, out_ctot, out_coff,
              res_ctot, act, mask_slope, tiles_w, tiles_w * tiles_h, B * tiles_w * tiles_h};
-    constexpr int LDS_BYTES = 9 * 2 * 2 * 32 * 16 + 3 * ((2 * 2 * 18 * 34 + 63) / 64) * 1024 + 1024;
+    // LDS: weights + patch ring + sink (the kernel's constants)
+    const int lds_bytes = C == 32 ? 9 * 2 * 2 * 32 * 16 + 3 * ((2 * 2 * 18 * 34 + 63) / 64) * 1024 + 1024
+                                  : 9 * 4 * 2 * 64 * 16 + 2 * ((4 * 2 * 10 * 34 + 63) / 64) * 1024 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 256;                                                  // one persistent workgroup per CU
     if (a.ntiles < grid) grid = round_up(a.ntiles, 8);
-    hipLaunchKernelGGL(conv3x3_resident_f16k<32>, dim3(grid), dim3(768), LDS_BYTES, (hipStream_t)stream, a);
+    if (C == 32) hipLaunchKernelGGL(conv3x3_resident_f16k<32>, dim3(grid), dim3(768), lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_resident_f16k<64>, dim3(grid), dim3(768), lds_bytes, (hipStream_t)stream, a);
     return masic_launch_status("conv3x3_resident_fwd");
 }

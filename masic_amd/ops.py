@@ -970,7 +970,7 @@ def pack_conv3x3_resident_weight(weight, transposed=False):
     _dev(weight, "weight")
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3) or lib.masic_conv3x3_resident_packed_bytes(C) == 0:
-        raise RuntimeError("masic_amd.pack_conv3x3_resident_weight: a [C, C, 3, 3] weight with a resident configuration (C = 32) expected")
+        raise RuntimeError("masic_amd.pack_conv3x3_resident_weight: a [C, C, 3, 3] weight with a resident configuration (C = 32 or 64) expected")
     wp = torch.empty(lib.masic_conv3x3_resident_packed_bytes(C) // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_conv3x3_resident_pack_weight(_p(weight.contiguous()), _p(wp), C, int(transposed), _stream()), "conv3x3_resident_pack_weight")
     return wp

@@ -432,14 +432,13 @@ def test_f16k_act_bwd_and_channel_sum_vs_torch():
     assert torch.allclose(s, ab.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (3, 48, 96)])
-def test_conv3x3_resident_kernel_vs_torch(B, H, W):
-    """masic_conv3x3_resident_fwd (32 -> 32, weights resident in LDS, persistent workgroups, loader wave): forward with LeakyReLU,
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 32, 64), (32, 3, 48, 96), (64, 2, 24, 64), (64, 3, 40, 96)])
+def test_conv3x3_resident_kernel_vs_torch(C, B, H, W):
+    """masic_conv3x3_resident_fwd (C -> C, C = 32 | 64, weights resident in LDS, persistent workgroups, loader waves): forward with LeakyReLU,
     pre-residual copy and two residuals into a channel slice of a wider buffer, and the input-gradient form (transposed pack, mask
     epilogue) -- against float32 torch on the same bf16-rounded operands."""
     import torch.nn.functional as F
     from masic_amd import ops
-    C = 32
     g = torch.Generator().manual_seed(B * 100 + H)
     bf = lambda t: t.bfloat16().float()
     x, r1, r2, m = (bf(torch.randn(B, C, H, W, generator=g)) for _ in range(4))
@@ -447,17 +446,18 @@ def test_conv3x3_resident_kernel_vs_torch(B, H, W):
     bias = torch.randn(C, generator=g)
     assert ops.conv3x3_resident_supported(B, C, H, W)
     to16 = lambda t: ops.nchw_to_f16k(t.to(DEV))
-    # forward: out = leaky(conv(x) + b) + r1 + r2 into channels [32, 64) of a 96-channel buffer; pre = leaky(conv(x) + b)
-    wide = ops.f16k_empty(B, 96, H, W, DEV)
+    # forward: out = leaky(conv(x) + b) + r1 + r2 into channels [32, 32 + C) of a wider buffer; pre = leaky(conv(x) + b)
+    CT = C + 64
+    wide = ops.f16k_empty(B, CT, H, W, DEV)
     wide.zero_()
     pre = ops.f16k_empty(B, C, H, W, DEV)
-    ops.conv3x3_resident(to16(x), ops.pack_conv3x3_resident_weight(w.to(DEV)), bias.to(DEV), B, C, H, W, act=ops.ACT_LEAKY, y16=wide, out_ctot=96,
+    ops.conv3x3_resident(to16(x), ops.pack_conv3x3_resident_weight(w.to(DEV)), bias.to(DEV), B, C, H, W, act=ops.ACT_LEAKY, y16=wide, out_ctot=CT,
                          out_coff=32, res1=to16(r1), res2=to16(r2), res_ctot=C, y_pre=pre)
     u = F.leaky_relu(F.conv2d(x.double(), bf(w).double(), bias.double(), padding=1), 0.01)
-    got = ops.f16k_to_nchw_dev(wide, B, 96, H, W).cpu()
-    assert float(got[:, :32].abs().max()) == 0.0 and float(got[:, 64:].abs().max()) == 0.0
+    got = ops.f16k_to_nchw_dev(wide, B, CT, H, W).cpu()
+    assert float(got[:, :32].abs().max()) == 0.0 and float(got[:, 32 + C:].abs().max()) == 0.0
     want = (u + r1 + r2).float()
-    assert float((got[:, 32:64] - want).abs().max()) <= 1e-2 * float(want.abs().max())          # one bf16 rounding of the result
+    assert float((got[:, 32:32 + C] - want).abs().max()) <= 1e-2 * float(want.abs().max())          # one bf16 rounding of the result
     gotp = ops.f16k_to_nchw_dev(pre, B, C, H, W).cpu()
     assert float((gotp - u.float()).abs().max()) <= 1e-2 * float(u.abs().max())
     # input gradient of the same layer: dgrad(g) * leaky'(m) + r1

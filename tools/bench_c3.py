@@ -1,10 +1,10 @@
-"""32 -> 32 3x3 layer at 8 x 512^2 on F16K: conv_f16k configuration vs the resident-weight persistent kernel."""
+"""C -> C (C = 32 | 64: argv[1]) 3x3 layer at 8 x 512^2 on F16K: conv_f16k configuration vs the resident-weight persistent kernel."""
 import sys, os, time, torch
 sys.path.insert(0, os.getcwd())
 from masic_amd import ops, _lib
 torch.manual_seed(0)
 dev = "cuda"
-B, C, H, W = 8, 32, 512, 512
+B, C, H, W = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 32, 512, 512
 x16 = ops.nchw_to_f16k(torch.randn(B, C, H, W, device=dev))
 r16 = ops.nchw_to_f16k(torch.randn(B, C, H, W, device=dev))
 w = torch.randn(C, C, 3, 3, device=dev) / (C * 9) ** 0.5
