@@ -467,3 +467,25 @@ def test_conv3x3_resident_kernel_vs_torch(C, B, H, W):
     wantg = F.conv_transpose2d(gy.double(), bf(w).double(), padding=1) * torch.where(m > 0, 1.0, 0.01).double() + r1.double()
     gotg = ops.f16k_to_nchw_dev(dg, B, C, H, W).cpu()
     assert float((gotg - wantg.float()).abs().max()) <= 1e-2 * float(wantg.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 512, 896), (1, 1216, 2176)])
+def test_independent_en_bf16_path_at_baseline_sizes(B, H, W):
+    """BASELINE configs 3 / 4 picture sizes: the bf16 inference path of Independent_EN at these sizes runs the large-layer kernel set
+    (two-workgroups-per-CU conv_f16k configuration for 96 channels, resident-weight persistent kernels for 32 / 64) -- checked against
+    the float32 parity path of the same weights (itself checked against the oracle at these sizes in tests/test_gpu_hsic.py)."""
+    from masic_amd import nn as mnn, ops, synth
+    net, _ = _en(21)
+    net.eval()
+    xa, xb, hm = (t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=21))
+    assert ops.conv3x3_resident_supported(B, 32, H, W) and ops.conv3x3_resident_supported(B, 64, H, W)
+    with torch.no_grad():
+        ref = net(xa, xb, hm)
+        mnn.set_precision("bf16")
+        try:
+            out = net(xa, xb, hm)
+        finally:
+            mnn.set_precision("f32")
+    for k in ("x1_hat", "x2_hat"):
+        e = assert_close(out[k], ref[k], f"cqe bf16 vs float32 path at {H}x{W}:" + k, 2e-2)
+        print(f"Independent_EN bf16 path at {B}x{H}x{W}, {k}: {e:.2e} from the float32 path")
