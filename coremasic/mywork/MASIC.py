@@ -1111,7 +1111,10 @@ class Independent_EN(nn.Module):
             inp = torch.empty((B, 6, H, W), dtype=torch.float32, device=dev)                  # other_warp * w0 | own * w1   (:1470-1471)
             _hip.quantize(x_other_warp, "copy", out=inp, out_coff=0, gate=w, gate_c=0)
             _hip.quantize(x_own, "copy", out=inp, out_coff=3, gate=w, gate_c=1)
-            t16 = _hip.nchw_to_f16k(self.conv1.run(inp))
+            if self.conv1.resident_supported(B, H, W):       # 6 -> 32 on the resident-weight kernel: one zero-padded record per pixel in, F16K out
+                t16 = self.conv1.run_f16k_res(_hip.nchw_to_f16k(inp), B, H, W)
+            else:
+                t16 = _hip.nchw_to_f16k(self.conv1.run(inp))
             feats.append(EB1.forward_f16k(t16, B, H, W))
         # stage 2: own * w1 | warp(other) * w0   (:1481-1482)
         c1 = _hip.f16k_empty(B, 64, H, W, dev)
@@ -1123,7 +1126,10 @@ class Independent_EN(nn.Module):
         for x_own, c, EB2, EB3 in ((x1_hat, c1, self.EBl2, self.EBl3), (x2_hat, c2, self.EBr2, self.EBr3)):
             d = _hip.f16k_empty(B, 96, H, W, dev)                                             # stage-2 output | conv0(x_hat)   (:1486-1487)
             EB2.forward_f16k(c, B, H, W, out16=d, out_ctot=96, out_coff=0)
-            _hip.nchw_to_f16k_view(self.conv0.run(x_own), d, 96, 64)
+            if self.conv0.resident_supported(B, H, W):       # 3 -> 32 straight into channels [64, 96) of the concat buffer
+                self.conv0.run_f16k_res(_hip.nchw_to_f16k(x_own), B, H, W, out16=d, out_ctot=96, out_coff=64)
+            else:
+                _hip.nchw_to_f16k_view(self.conv0.run(x_own), d, 96, 64)
             o16 = EB3.forward_f16k(d, B, H, W)
             if self.conv2.few_supported(B, H, W):
                 outs.append(self.conv2.run_f16k_few(o16, B, H, W, res32=x_own))               # 96 -> 3 on the MFMA kernel + the picture (:1495-1496)

@@ -214,16 +214,18 @@ int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const f
 int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream);
 size_t masic_f16k_channel_sum_workspace_bytes(int B, int C);
 int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream);
-/* Conv2d(C -> C, k3, s1, p1), C = 32, on F16K with the whole weight tensor resident in LDS and persistent workgroups (the 32-channel
- * stage of Independent_EN, reference MASIC.py:149-164 / layers.py:99-121; conv_f16k spends three quarters of such a launch in
- * per-workgroup prologue / epilogue).  Same operand meaning as masic_conv_f16k_res_ex_fwd; `transposed` in the pack selects the
- * slabs of the layer's input gradient.  Needs H % 16 == 0 and W % 32 == 0 (masic_conv3x3_resident_supported). */
-size_t masic_conv3x3_resident_packed_bytes(int C);
-int masic_conv3x3_resident_supported(int B, int C, int H, int W);
-int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int C, int transposed, void* stream);
+/* Conv2d(Cin -> Cout, k3, s1, p1) on F16K with the whole weight tensor resident in LDS and persistent workgroups: Cout = 32 | 64,
+ * Cin <= Cout (the input buffer holds round_up(Cin, 16) channels; a 3- or 6-channel picture is one zero-padded record per pixel) --
+ * the 32- / 64-channel stages of Independent_EN and its input layers (reference MASIC.py:149-164, 1456-1482 / layers.py:99-121;
+ * conv_f16k spends three quarters of such a launch in per-workgroup prologue / epilogue).  Same operand meaning as
+ * masic_conv_f16k_res_ex_fwd; `transposed` in the pack selects the slabs of the INPUT gradient of a Conv2d(Cout -> Cin) layer
+ * (weight [Cin][Cout][3][3]).  Needs W % 32 == 0 and H % 16 == 0 (Cout = 32) / H % 8 == 0 (Cout = 64). */
+size_t masic_conv3x3_resident_packed_bytes(int Cin, int Cout);
+int masic_conv3x3_resident_supported(int B, int Cin, int Cout, int H, int W);
+int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int Cin, int Cout, int transposed, void* stream);
 int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
-                               const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int C, int H, int W, int in_ctot,
-                               int in_coff, int out_ctot, int out_coff, int act, void* stream);
+                               const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int Cin, int Cout, int H, int W,
+                               int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream);
 /* diagnostics: 16 uint64 on the device, filled by every following conv_f16k launch with {core-clock, 100 MHz} stamp pairs at kernel
  * entry, K-loop entry, K-loop exit and kernel exit of its first and of its last workgroup; NULL switches it off (tools/f16k_stamps.py) */
 void masic_conv_f16k_set_stamps(void* device_buffer);

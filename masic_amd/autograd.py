@@ -384,7 +384,7 @@ class EnhancementBlockFn(Function):
 
         def dgrad(g16, w, **kw):            # the transposed convolution on the same weight, epilogue operands as conv2d_f16k_res
             if resident:
-                return ops.conv3x3_resident(g16, ops.pack_conv3x3_resident_weight(w.detach(), transposed=True), None, B, C, H, W, res_ctot=C, **kw)
+                return ops.conv3x3_resident(g16, ops.pack_conv3x3_resident_weight(w.detach(), transposed=True), None, B, C, C, H, W, res_ctot=C, **kw)
             return ops.conv2d_f16k_res(g16, ops.pack_conv_f16k_weight(w.detach(), d16), None, d16, res_ctot=C, **kw)
         go = g_out
         for i in (2, 1, 0):

@@ -1723,8 +1723,9 @@ extern "C" int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const
 extern "C" void masic_conv_f16k_set_stamps(void* device_buffer) { g_f16k_stamps = (unsigned long long*)device_buffer; }
 
 // ------------------------------------------------------------------------------------------ 3x3 layers with resident weights
-// Conv2d(C -> C, k3, s1, p1) (or its input gradient) on F16K for C = 32: the 32-channel stage of Independent_EN (reference
-// MASIC.py:149-164, 1470-1471 -- 12 of its 36 convolutions, and as many input gradients in training).  K = 288 is 18 MFMA k-steps: on
+// Conv2d(CI -> CO, k3, s1, p1) (or its input gradient) on F16K for CI in {16, 32, 64} (16: a 3- or 6-channel picture zero-padded to
+// one record per pixel), CO in {32, 64}: the 32- and 64-channel stages of Independent_EN and its two input layers (reference
+// MASIC.py:149-164, 1456-1482 -- 28 of its 40 convolutions, and the input gradients of 24 of them in training).  K = 288 is 18 MFMA k-steps: on
 // conv_f16k such a layer is three quarters per-workgroup prologue / epilogue (171 us per launch at 8 x 512^2 against an HBM floor of
 // ~45).  Here the whole weight tensor (18 KiB of bf16 fragments) stays in LDS for the life of a PERSISTENT workgroup that walks
 // over 16 x 32-pixel tiles of one XCD's share of the images:
@@ -1754,9 +1755,9 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int C>
+template <int CI, int C>      // input channels (a multiple of 16), output channels
 __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) {
-    constexpr int KB = C / 16;                         // 16-channel blocks = 32-byte records per pixel
+    constexpr int KB = CI / 16;                        // 16-channel blocks = 32-byte records per input pixel
     constexpr int NM = C / 32;                         // 32-channel accumulator tiles per pixel; a wave owns one of them for two image rows
     constexpr int TH = 16 / NM, TW = 32, PWd = TW + 2, NPIX = (TH + 2) * PWd;
     constexpr int PREC = KB * 2 * NPIX;                // 16-byte records of a patch: [kb][k-half][pixel]
@@ -1765,13 +1766,13 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
     constexpr int SLAB = 2 * C * 16;                   // one (tap, kb) weight slab: [k-half][co]
     constexpr int WBYTES = 9 * KB * SLAB;
     constexpr int NWI = WBYTES / 1024;
-    constexpr int NBUF = C == 32 ? 3 : 2;              // patch ring (64 channels: 72 KiB of weights leave room for two 43-KiB patches)
+    constexpr int NBUF = WBYTES + 3 * PBYTES + 1024 <= 160 * 1024 ? 3 : 2;   // patch ring (64 -> 64: 72 KiB of weights leave room for two 43-KiB patches)
     constexpr int PD = NBUF - 1;                       // tiles of look-ahead
     constexpr int NLW = 4;                             // loader waves (8 .. 11): one wave issues a 1-KiB piece every 60-185 cycles
     constexpr int NIW = (NI + NLW - 1) / NLW;          // pieces per loader wave and patch (the last wave pads with sink pieces)
     constexpr int NWW = (NWI + NLW - 1) / NLW;         // weight pieces per loader wave
     constexpr int SINK = WBYTES + NBUF * PBYTES;       // 1 KiB that padding pieces write zeros to
-    static_assert(C == 32 || C == 64, "8 compute waves = (16 / NM row pairs) x NM channel tiles");
+    static_assert((C == 32 || C == 64) && (CI == 16 || CI == 32 || CI == 64), "8 compute waves = (16 / NM row pairs) x NM channel tiles");
     static_assert(PD * NIW + NWW <= 60 && WBYTES % 1024 == 0 && SINK + 1024 <= 160 * 1024, "vmcnt is 6 bits; whole DMA pieces; LDS");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // [weights][NBUF patches][sink]
 
@@ -1927,11 +1928,12 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
     }
 }
 
-// weights of Conv2d(C -> C, 3x3) [C][C][3][3] float32 -> bf16 fragment slabs [tap][kb][k-half][co][8 k];  transposed: the slabs of the
-// layer's INPUT gradient (the stride-1 transposed convolution on the same tensor: taps mirrored, channel roles swapped)
-__global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int C, int transposed) {
+// weights of Conv2d(cin -> C, 3x3) [C][cin][3][3] float32 -> bf16 fragment slabs [tap][kb][k-half][co][8 k] with the input channels
+// zero-padded to CI;  transposed: the slabs of the INPUT gradient of a Conv2d(C -> cin) layer (the stride-1 transposed convolution
+// on the same tensor [cin][C][3][3]: taps mirrored, channel roles swapped)
+__global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cin, int CI, int C, int transposed) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                 // one 16-byte record: (tap, kb, hh, co)
-    const int KB = C / 16;
+    const int KB = CI / 16;
     if (idx >= 9 * KB * 2 * C) return;
     const int co = idx % C, hh = (idx / C) & 1, kb = (idx / (2 * C)) % KB, t = idx / (2 * C * KB);
     unsigned v[4];
@@ -1941,7 +1943,7 @@ __global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ci = kb * 16 + hh * 8 + 2 * p + q;
-            f[q] = transposed ? w[((size_t)ci * C + co) * 9 + (8 - t)] : w[((size_t)co * C + ci) * 9 + t];
+            f[q] = ci >= cin ? 0.0f : (transposed ? w[((size_t)ci * C + co) * 9 + (8 - t)] : w[((size_t)co * cin + ci) * 9 + t]);
         }
         v[p] = pack2bf(f[0], f[1]);
     }
@@ -1950,48 +1952,71 @@ __global__ __launch_bounds__(256) void pack_c3_weights_kernel(const float* __res
 
 }  // namespace
 
-extern "C" size_t masic_conv3x3_resident_packed_bytes(int C) { return (C == 32 || C == 64) ? (size_t)9 * (C / 16) * 2 * C * 16 : 0; }
+static bool c3_pair_ok(int CI, int C) { return (C == 32 || C == 64) && (CI == 16 || CI == 32 || CI == 64) && (CI <= C || CI == C); }
 
-extern "C" int masic_conv3x3_resident_supported(int B, int C, int H, int W) {
-    return B > 0 && (C == 32 || C == 64) && H % (512 / C) == 0 && W % 32 == 0 && (long)H * W * 32 * (C / 16) < (1l << 31);
+extern "C" size_t masic_conv3x3_resident_packed_bytes(int Cin, int Cout) {
+    const int CI = round_up(Cin, 16);
+    return c3_pair_ok(CI, Cout) ? (size_t)9 * (CI / 16) * 2 * Cout * 16 : 0;
 }
 
-extern "C" int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int C, int transposed, void* stream) {
-    MASIC_REQUIRE(w && w_packed && (C == 32 || C == 64), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_pack_weight: C = 32 or 64");
-    hipLaunchKernelGGL(pack_c3_weights_kernel, dim3(ceil_div(9 * (C / 16) * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)w_packed, C, transposed);
+// Cin: real input channels (any value <= 64; the F16K input buffer holds round_up(Cin, 16) of them, the padding zero or anything
+// finite: its weights are zero); Cout: 32 (needs H % 16 == 0) or 64 (H % 8 == 0); W % 32 == 0
+extern "C" int masic_conv3x3_resident_supported(int B, int Cin, int Cout, int H, int W) {
+    const int CI = round_up(Cin, 16);
+    return B > 0 && Cin > 0 && c3_pair_ok(CI, Cout) && H % (512 / Cout) == 0 && W % 32 == 0 && (long)H * W * 32 * (CI / 16) < (1l << 31);
+}
+
+extern "C" int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int Cin, int Cout, int transposed, void* stream) {
+    const int CI = round_up(Cin, 16);
+    MASIC_REQUIRE(w && w_packed && c3_pair_ok(CI, Cout), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_pack_weight: Cin <= 64, Cout = 32 or 64");
+    hipLaunchKernelGGL(pack_c3_weights_kernel, dim3(ceil_div(9 * (CI / 16) * 2 * Cout, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)w_packed, Cin, CI,
+                       Cout, transposed);
     return masic_launch_status("conv3x3_resident_pack_weight");
 }
 
 // y = act(conv3x3(x) + bias) * act'(mask) + res1 + res2 on F16K buffers, y_pre = the value before the adds (see
-// masic_conv_f16k_res_ex_fwd: same meaning of every operand); x: channels [in_coff, in_coff + C) of an in_ctot-channel buffer,
-// y: channels [out_coff, out_coff + C) of an out_ctot-channel buffer, residual / mask / pre tensors: res_ctot channels.
+// masic_conv_f16k_res_ex_fwd: same meaning of every operand); x: channels [in_coff, in_coff + round_up(Cin, 16)) of an in_ctot-channel
+// buffer, y: channels [out_coff, out_coff + Cout) of an out_ctot-channel buffer, residual / mask / pre tensors: res_ctot channels.
 extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
-                                          const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int C, int H, int W, int in_ctot,
-                                          int in_coff, int out_ctot, int out_coff, int act, void* stream) {
+                                          const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int Cin, int Cout, int H, int W,
+                                          int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream) {
+    const int CI = round_up(Cin, 16), C = Cout;
     MASIC_REQUIRE(x_f16k && w_packed && y_f16k, MASIC_ERR_ARG, "conv3x3_resident_fwd: null pointer");
-    MASIC_REQUIRE(masic_conv3x3_resident_supported(B, C, H, W), MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: needs C = 32 (H %% 16 == 0) or 64 (H %% 8 == 0), W %% 32 == 0");
-    MASIC_REQUIRE(in_ctot % 16 == 0 && in_coff % 16 == 0 && in_coff >= 0 && in_coff + C <= in_ctot && out_ctot % 16 == 0 && out_coff % 16 == 0 &&
+    MASIC_REQUIRE(masic_conv3x3_resident_supported(B, Cin, Cout, H, W), MASIC_ERR_UNSUPPORTED,
+                  "conv3x3_resident_fwd: needs Cin <= 64, Cout = 32 (H %% 16 == 0) or 64 (H %% 8 == 0), W %% 32 == 0");
+    MASIC_REQUIRE(in_ctot % 16 == 0 && in_coff % 16 == 0 && in_coff >= 0 && in_coff + CI <= in_ctot && out_ctot % 16 == 0 && out_coff % 16 == 0 &&
                       out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "conv3x3_resident_fwd: channel views");
     MASIC_REQUIRE(res1 != nullptr || res2 == nullptr, MASIC_ERR_ARG, "conv3x3_resident_fwd: res2 without res1");
     MASIC_REQUIRE((res1 == nullptr && mask == nullptr && y_pre_f16k == nullptr) || (res_ctot % 16 == 0 && res_ctot >= C), MASIC_ERR_SHAPE,
-                  "conv3x3_resident_fwd: residual / mask / pre tensors need >= C channels, a multiple of 16");
+                  "conv3x3_resident_fwd: residual / mask / pre tensors need >= Cout channels, a multiple of 16");
     MASIC_REQUIRE(act == MASIC_ACT_NONE || act == MASIC_ACT_RELU || act == MASIC_ACT_LEAKY, MASIC_ERR_UNSUPPORTED, "conv3x3_resident_fwd: activation");
-    const int tiles_w = W / 32, tiles_h = H / (512 / C);
+    const int TH = 512 / C, tiles_w = W / 32, tiles_h = H / TH;
     C3Args a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (const unsigned short*)res1, (const unsigned short*)res2,
              (const unsigned short*)mask, (unsigned short*)y_pre_f16k, (unsigned short*)y_f16k, B, H, W, in_ctot / 16, in_coff / 16, out_ctot, out_coff,
              res_ctot, act, mask_slope, tiles_w, tiles_w * tiles_h, B * tiles_w * tiles_h};
     // LDS: weights + patch ring + sink (the kernel's constants)
-    const int lds_bytes = C == 32 ? 9 * 2 * 2 * 32 * 16 + 3 * ((2 * 2 * 18 * 34 + 63) / 64) * 1024 + 1024
-                                  : 9 * 4 * 2 * 64 * 16 + 2 * ((4 * 2 * 10 * 34 + 63) / 64) * 1024 + 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const int wbytes = 9 * (CI / 16) * 2 * C * 16, pbytes = ((CI / 16) * 2 * (TH + 2) * 34 + 63) / 64 * 1024;
+    const int lds_bytes = wbytes + (wbytes + 3 * pbytes + 1024 <= 160 * 1024 ? 3 : 2) * pbytes + 1024;
     int grid = 256;                                                  // one persistent workgroup per CU
     if (a.ntiles < grid) grid = round_up(a.ntiles, 8);
-    if (C == 32) hipLaunchKernelGGL(conv3x3_resident_f16k<32>, dim3(grid), dim3(768), lds_bytes, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3x3_resident_f16k<64>, dim3(grid), dim3(768), lds_bytes, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+#define C3_LAUNCH(CIV, CV)                                                                                                    \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<CIV, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((conv3x3_resident_f16k<CIV, CV>), dim3(grid), dim3(768), lds_bytes, st, a);                         \
+    } while (0)
+    if (C == 32) {
+        if (CI == 16) C3_LAUNCH(16, 32);
+        else C3_LAUNCH(32, 32);
+    } else {
+        if (CI == 16) C3_LAUNCH(16, 64);
+        else if (CI == 32) C3_LAUNCH(32, 64);
+        else C3_LAUNCH(64, 64);
+    }
+#undef C3_LAUNCH
     return masic_launch_status("conv3x3_resident_fwd");
 }

@@ -258,16 +258,17 @@ class _PackedWeightMixin:
             # 32 -> 32 3x3 layers: weights resident in LDS, persistent workgroups (conv_f16k.hip: conv3x3_resident_f16k)
             w = self.weight
             wp = _cached(self, "_packed_c3_cache", (w._version, w.data_ptr(), str(w.device)), (), lambda: ops.pack_conv3x3_resident_weight(w.detach()))
-            return ops.conv3x3_resident(x16, wp, bias, B, self.in_channels, Hi, Wi, act=act, y16=out16, out_ctot=oc, out_coff=out_coff,
+            return ops.conv3x3_resident(x16, wp, bias, B, self.in_channels, self.out_channels, Hi, Wi, act=act, y16=out16, out_ctot=oc, out_coff=out_coff,
                                         res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
         desc = self._desc_f16k(B, Hi, Wi, out_ctot=oc, out_coff=out_coff, act=act)
         return ops.conv2d_f16k_res(x16, self.packed_f16k_weight(desc), bias, desc, y16=out16,
                                    res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
 
     def resident_supported(self, B, Hi, Wi):
-        """Conv2d(32 -> 32, k3, s1, p1) at H % 16 == 0, W % 32 == 0: the resident-weight kernel (MASIC_C3_RESIDENT=0: conv_f16k, A/B timing)."""
-        return (_C3_RESIDENT and not self.transposed_conv and not self.masked_conv and self.in_channels == self.out_channels
-                and self._geometry() == (3, 3, 1, 1) and ops.conv3x3_resident_supported(B, self.in_channels, Hi, Wi))
+        """Conv2d(Cin -> 32 | 64, k3, s1, p1), Cin <= Cout, at W % 32 == 0 and H % 16 (8) == 0: the resident-weight kernel
+        (MASIC_C3_RESIDENT=0: conv_f16k, A/B timing)."""
+        return (_C3_RESIDENT and not self.transposed_conv and not self.masked_conv and self._geometry() == (3, 3, 1, 1)
+                and ops.conv3x3_resident_supported(B, self.in_channels, self.out_channels, Hi, Wi))
 
     def few_supported(self, B, Hi, Wi):
         kh, kw, s_, p_ = self._geometry()

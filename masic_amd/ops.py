@@ -961,27 +961,30 @@ def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res
     return y16
 
 
-def conv3x3_resident_supported(B, C, H, W):
-    return bool(lib.masic_conv3x3_resident_supported(int(B), int(C), int(H), int(W)))
+def conv3x3_resident_supported(B, Cin, Cout, H, W):
+    return bool(lib.masic_conv3x3_resident_supported(int(B), int(Cin), int(Cout), int(H), int(W)))
 
 
 def pack_conv3x3_resident_weight(weight, transposed=False):
-    """Conv2d(C -> C, 3x3) weight -> the LDS-resident fragment slabs of masic_conv3x3_resident_fwd (transposed: of its input gradient)."""
+    """Conv2d(Cin -> Cout, 3x3) weight [Cout, Cin, 3, 3] -> the LDS-resident fragment slabs of masic_conv3x3_resident_fwd;
+    transposed: the slabs of the INPUT gradient of the layer this weight belongs to (a Cout -> Cin convolution)."""
     _dev(weight, "weight")
-    C = weight.shape[0]
-    if tuple(weight.shape) != (C, C, 3, 3) or lib.masic_conv3x3_resident_packed_bytes(C) == 0:
-        raise RuntimeError("masic_amd.pack_conv3x3_resident_weight: a [C, C, 3, 3] weight with a resident configuration (C = 32 or 64) expected")
-    wp = torch.empty(lib.masic_conv3x3_resident_packed_bytes(C) // 2, dtype=torch.int16, device=weight.device)
-    check(lib.masic_conv3x3_resident_pack_weight(_p(weight.contiguous()), _p(wp), C, int(transposed), _stream()), "conv3x3_resident_pack_weight")
+    co, ci = weight.shape[:2]
+    cin, cout = (co, ci) if transposed else (ci, co)
+    nbytes = lib.masic_conv3x3_resident_packed_bytes(cin, cout)
+    if tuple(weight.shape[2:]) != (3, 3) or nbytes == 0:
+        raise RuntimeError("masic_amd.pack_conv3x3_resident_weight: a 3x3 weight with a resident configuration (Cout 32 | 64, Cin <= Cout) expected")
+    wp = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_conv3x3_resident_pack_weight(_p(weight.contiguous()), _p(wp), cin, cout, int(transposed), _stream()), "conv3x3_resident_pack_weight")
     return wp
 
 
-def conv3x3_resident(x16, packed, bias, B, C, H, W, act=ACT_NONE, y16=None, out_ctot=None, out_coff=0, in_ctot=None, in_coff=0,
+def conv3x3_resident(x16, packed, bias, B, Cin, Cout, H, W, act=ACT_NONE, y16=None, out_ctot=None, out_coff=0, in_ctot=None, in_coff=0,
                      res1=None, res2=None, res_ctot=0, mask=None, mask_slope=0.0, y_pre=None):
     """y = act(conv3x3(x) + bias) * act'(mask) + res1 + res2 on F16K buffers with LDS-resident weights (csrc/conv_f16k.hip:
-    conv3x3_resident_f16k); operands as conv2d_f16k_res."""
-    in_ctot = C if in_ctot is None else in_ctot
-    out_ctot = C if out_ctot is None else out_ctot
+    conv3x3_resident_f16k); operands as conv2d_f16k_res.  The input buffer holds ceil16(Cin) channels per pixel."""
+    in_ctot = (Cin + 15) // 16 * 16 if in_ctot is None else in_ctot
+    out_ctot = Cout if out_ctot is None else out_ctot
     if x16.dtype != torch.int16 or x16.numel() != B * in_ctot * H * W:
         raise RuntimeError("masic_amd.conv3x3_resident: input buffer does not match (B, in_ctot, H, W)")
     if y16 is None:
@@ -992,7 +995,7 @@ def conv3x3_resident(x16, packed, bias, B, C, H, W, act=ACT_NONE, y16=None, out_
         if r is not None and (r.dtype != torch.int16 or r.numel() != B * res_ctot * H * W):
             raise RuntimeError("masic_amd.conv3x3_resident: residual / mask / pre buffer does not match (B, res_ctot, H, W)")
     check(lib.masic_conv3x3_resident_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(mask), float(mask_slope), _p(y_pre), _p(y16),
-                                         B, C, H, W, in_ctot, in_coff, out_ctot, out_coff, int(act), _stream()), "conv3x3_resident_fwd")
+                                         B, Cin, Cout, H, W, in_ctot, in_coff, out_ctot, out_coff, int(act), _stream()), "conv3x3_resident_fwd")
     return y16
 
 

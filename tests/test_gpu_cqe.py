@@ -444,14 +444,14 @@ def test_conv3x3_resident_kernel_vs_torch(C, B, H, W):
     x, r1, r2, m = (bf(torch.randn(B, C, H, W, generator=g)) for _ in range(4))
     w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
     bias = torch.randn(C, generator=g)
-    assert ops.conv3x3_resident_supported(B, C, H, W)
+    assert ops.conv3x3_resident_supported(B, C, C, H, W)
     to16 = lambda t: ops.nchw_to_f16k(t.to(DEV))
     # forward: out = leaky(conv(x) + b) + r1 + r2 into channels [32, 32 + C) of a wider buffer; pre = leaky(conv(x) + b)
     CT = C + 64
     wide = ops.f16k_empty(B, CT, H, W, DEV)
     wide.zero_()
     pre = ops.f16k_empty(B, C, H, W, DEV)
-    ops.conv3x3_resident(to16(x), ops.pack_conv3x3_resident_weight(w.to(DEV)), bias.to(DEV), B, C, H, W, act=ops.ACT_LEAKY, y16=wide, out_ctot=CT,
+    ops.conv3x3_resident(to16(x), ops.pack_conv3x3_resident_weight(w.to(DEV)), bias.to(DEV), B, C, C, H, W, act=ops.ACT_LEAKY, y16=wide, out_ctot=CT,
                          out_coff=32, res1=to16(r1), res2=to16(r2), res_ctot=C, y_pre=pre)
     u = F.leaky_relu(F.conv2d(x.double(), bf(w).double(), bias.double(), padding=1), 0.01)
     got = ops.f16k_to_nchw_dev(wide, B, CT, H, W).cpu()
@@ -462,11 +462,30 @@ def test_conv3x3_resident_kernel_vs_torch(C, B, H, W):
     assert float((gotp - u.float()).abs().max()) <= 1e-2 * float(u.abs().max())
     # input gradient of the same layer: dgrad(g) * leaky'(m) + r1
     gy = bf(torch.randn(B, C, H, W, generator=g))
-    dg = ops.conv3x3_resident(to16(gy), ops.pack_conv3x3_resident_weight(w.to(DEV), transposed=True), None, B, C, H, W, res1=to16(r1), res_ctot=C,
+    dg = ops.conv3x3_resident(to16(gy), ops.pack_conv3x3_resident_weight(w.to(DEV), transposed=True), None, B, C, C, H, W, res1=to16(r1), res_ctot=C,
                               mask=to16(m), mask_slope=0.01)
     wantg = F.conv_transpose2d(gy.double(), bf(w).double(), padding=1) * torch.where(m > 0, 1.0, 0.01).double() + r1.double()
     gotg = ops.f16k_to_nchw_dev(dg, B, C, H, W).cpu()
     assert float((gotg - wantg.float()).abs().max()) <= 1e-2 * float(wantg.abs().max())
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(3, 32, 32, 64), (6, 32, 48, 32), (32, 64, 24, 64), (6, 64, 16, 96)])
+def test_conv3x3_resident_kernel_input_layers(Cin, Cout, H, W):
+    """Cin < Cout forms of the resident-weight kernel (Independent_EN.conv0 3 -> 32, conv1 6 -> 32: a picture as one zero-padded F16K
+    record per pixel) against float32 torch on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from masic_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(Cin * 10 + Cout)
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    assert ops.conv3x3_resident_supported(B, Cin, Cout, H, W)
+    y16 = ops.conv3x3_resident(ops.nchw_to_f16k(x.to(DEV)), ops.pack_conv3x3_resident_weight(w.to(DEV)), bias.to(DEV), B, Cin, Cout, H, W)
+    want = F.conv2d(x.double(), bf(w).double(), bias.double(), padding=1).float()
+    got = ops.f16k_to_nchw_dev(y16, B, Cout, H, W).cpu()
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 512, 896), (1, 1216, 2176)])
@@ -478,7 +497,7 @@ def test_independent_en_bf16_path_at_baseline_sizes(B, H, W):
     net, _ = _en(21)
     net.eval()
     xa, xb, hm = (t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=21))
-    assert ops.conv3x3_resident_supported(B, 32, H, W) and ops.conv3x3_resident_supported(B, 64, H, W)
+    assert ops.conv3x3_resident_supported(B, 32, 32, H, W) and ops.conv3x3_resident_supported(B, 64, 64, H, W)
     with torch.no_grad():
         ref = net(xa, xb, hm)
         mnn.set_precision("bf16")

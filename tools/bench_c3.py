@@ -20,7 +20,7 @@ def t(fn, reps=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
 for name, fn in (("conv_f16k          ", lambda: ops.conv2d_f16k_res(x16, wp, bias, d, y16=y)),
                  ("conv_f16k + res    ", lambda: ops.conv2d_f16k_res(x16, wp, bias, d, y16=y, res1=r16, res_ctot=C)),
-                 ("resident           ", lambda: ops.conv3x3_resident(x16, wr, bias, B, C, H, W, act=ops.ACT_LEAKY, y16=y)),
-                 ("resident + res     ", lambda: ops.conv3x3_resident(x16, wr, bias, B, C, H, W, act=ops.ACT_LEAKY, y16=y, res1=r16, res_ctot=C))):
+                 ("resident           ", lambda: ops.conv3x3_resident(x16, wr, bias, B, C, C, H, W, act=ops.ACT_LEAKY, y16=y)),
+                 ("resident + res     ", lambda: ops.conv3x3_resident(x16, wr, bias, B, C, C, H, W, act=ops.ACT_LEAKY, y16=y, res1=r16, res_ctot=C))):
     us = t(fn)
     print(f"{name} {us:7.1f} us   {2 * 9 * C * C * B * H * W / us / 1e6:6.0f} TFLOP/s   {(2 * B * C * H * W * 2) / us / 1e6:5.2f} TB/s in+out")
