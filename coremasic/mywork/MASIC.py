@@ -1026,6 +1026,7 @@ class mask2weights_EN(nn.Module):
 
     def __init__(self, Kw=2):
         super().__init__()
+        self.Kw = Kw
         self.maskconv = nn.Sequential(
             conv(1, Kw, kernel_size=3, stride=1), nn.ReLU(inplace=True),
             conv(Kw, Kw * 2, kernel_size=3, stride=1), nn.ReLU(inplace=True),
@@ -1034,6 +1035,9 @@ class mask2weights_EN(nn.Module):
 
     def forward(self, m):
         s = self.maskconv
+        if self.Kw == 2 and not (torch.is_grad_enabled() and (m.requires_grad or s[0].weight.requires_grad)):
+            # inference: the four layers and the softmax in one launch, intermediates in LDS (csrc/m2w.hip; bit-identical to the chain below)
+            return _hip.mask2weights_en(m, [p for i in (0, 2, 4, 6) for p in (s[i].weight, s[i].bias)])
         t = s[0].run(m, act=_RELU)
         t = s[2].run(t, act=_RELU)
         t = s[4].run(t, act=_RELU)

@@ -214,6 +214,11 @@ int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const f
 int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream);
 size_t masic_f16k_channel_sum_workspace_bytes(int B, int C);
 int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream);
+/* mask2weights_EN (reference MASIC.py:1411-1434, Kw = 2) in one launch: gates [B,2,H,W] = softmax over channels of four 3x3
+ * stride-1 convolutions 1 -> 2 -> 4 -> 4 -> 2 with ReLUs on mask [B,1,H,W]; w_i [Cout][Cin][3][3], b_i [Cout], float32 on the
+ * device.  Bit-identical to the four-launch form (masic_conv2d_fwd per layer). */
+int masic_mask2weights_en_fwd(const float* mask, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                              const float* b3, const float* w4, const float* b4, float* gates, int B, int H, int W, void* stream);
 /* Conv2d(Cin -> Cout, k3, s1, p1) on F16K with the whole weight tensor resident in LDS and persistent workgroups: Cout = 32 | 64,
  * Cin <= Cout (the input buffer holds round_up(Cin, 16) channels; a 3- or 6-channel picture is one zero-padded record per pixel) --
  * the 32- / 64-channel stages of Independent_EN and its input layers (reference MASIC.py:149-164, 1456-1482 / layers.py:99-121;

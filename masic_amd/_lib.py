@@ -74,6 +74,7 @@ SIGNATURES = {
     "masic_conv3x3_wgrad_f16k_workspace_bytes": (c_size_t, [c_int, c_int]),
     "masic_conv3x3_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv_f16k_set_stamps": (None, [_P]),
+    "masic_mask2weights_en_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, _P]),
     "masic_conv3x3_resident_packed_bytes": (c_size_t, [c_int, c_int]),
     "masic_conv3x3_resident_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "masic_conv3x3_resident_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

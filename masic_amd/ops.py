@@ -961,6 +961,20 @@ def conv2d_f16k_res(x16, packed, bias, desc, y16=None, res1=None, res2=None, res
     return y16
 
 
+def mask2weights_en(mask, params):
+    """mask2weights_EN (Kw = 2) in one launch: mask [B,1,H,W] float32 -> gates [B,2,H,W]; params = (w1, b1, ..., w4, b4) of the four
+    3x3 convolutions 1 -> 2 -> 4 -> 4 -> 2 (csrc/m2w.hip)."""
+    _dev(mask, "mask")
+    B, c, H, W = mask.shape
+    shapes = [(2, 1), (4, 2), (4, 4), (2, 4)]
+    if c != 1 or len(params) != 8 or any(tuple(params[2 * i].shape) != (co, ci, 3, 3) or tuple(params[2 * i + 1].shape) != (co,) for i, (co, ci) in enumerate(shapes)):
+        raise RuntimeError("masic_amd.mask2weights_en: a [B,1,H,W] mask and the 1 -> 2 -> 4 -> 4 -> 2 stack's weights / biases expected")
+    ps = [_dev(p.detach().contiguous(), "parameter") for p in params]
+    out = torch.empty((B, 2, H, W), dtype=torch.float32, device=mask.device)
+    check(lib.masic_mask2weights_en_fwd(_p(mask.contiguous()), *[_p(p) for p in ps], _p(out), B, H, W, _stream()), "mask2weights_en_fwd")
+    return out
+
+
 def conv3x3_resident_supported(B, Cin, Cout, H, W):
     return bool(lib.masic_conv3x3_resident_supported(int(B), int(Cin), int(Cout), int(H), int(W)))
 

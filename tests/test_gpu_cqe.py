@@ -469,6 +469,31 @@ def test_conv3x3_resident_kernel_vs_torch(C, B, H, W):
     assert float((gotg - wantg.float()).abs().max()) <= 1e-2 * float(wantg.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 50, 70), (3, 33, 31)])
+def test_mask2weights_en_fused_kernel_is_bit_identical_to_the_layer_chain(B, H, W):
+    """masic_mask2weights_en_fwd (four 3x3 layers + softmax of mask2weights_EN, reference MASIC.py:1411-1434, in one launch with the
+    intermediates in LDS) == the four-launch form the float32 parity tests pin against the oracle, bit for bit (ragged sizes: tiles
+    that overhang the picture, intermediate zero padding at the picture border)."""
+    from coremasic.mywork.MASIC import mask2weights_EN
+    from masic_amd import synth
+    torch.manual_seed(B + H)
+    net = mask2weights_EN().to(DEV).eval()
+    _, _, hm = synth.synth_inputs(B, H, W, seed=5)
+    from masic_amd.homography import warp_matrices
+    from masic_amd import ops
+    m, _ = warp_matrices(hm.to(DEV), (H, W), (H, W), want_inverse=True)
+    mask = ops.warp_perspective(None, m, (H, W), ones_like=(B, H, W))          # a real homography mask: ones, zeros, bilinear border
+    with torch.no_grad():
+        fused = net(mask)
+        s = net.maskconv
+        t = s[0].run(mask, act=ops.ACT_RELU)
+        t = s[2].run(t, act=ops.ACT_RELU)
+        t = s[4].run(t, act=ops.ACT_RELU)
+        chain = s[6].run(t, act=ops.ACT_SOFTMAX_C)
+    assert fused.shape == (B, 2, H, W) and torch.equal(fused, chain)
+    assert float((fused.sum(1) - 1).abs().max()) <= 1e-6
+
+
 @pytest.mark.parametrize("Cin,Cout,H,W", [(3, 32, 32, 64), (6, 32, 48, 32), (32, 64, 24, 64), (6, 64, 16, 96)])
 def test_conv3x3_resident_kernel_input_layers(Cin, Cout, H, W):
     """Cin < Cout forms of the resident-weight kernel (Independent_EN.conv0 3 -> 32, conv1 6 -> 32: a picture as one zero-padded F16K
