@@ -46,10 +46,10 @@ if sq:
                                    "lds_bank_conflict_over_lds_active": round(e.get("SQ_LDS_BANK_CONFLICT_avg", 0) / max(e.get("SQ_LDS_IDX_ACTIVE_avg", 1), 1), 4)}
     json.dump(out, open(R + f"profiles/{TAG}_sq_counters.json", "w"), indent=1, sort_keys=True)
     os.remove(R + f"profiles/{TAG}_sq_counters_raw.json")
-for name, log, n in (("train", "prof_train", 3), ("cqe", "prof_cqe", 3)):
+for name, log, n in (("train", "prof_train", 3), ("cqe", "prof_cqe", 3), ("cqe_train", "prof_cqetrain", 3)):
     dbs = glob.glob(R + f"gpurun_out/{log}/**/*results.db", recursive=True)
     m = re.search(r"ms/step ([0-9.]+)", open(R + f"gpurun_out/{log}.log").read()) if os.path.exists(R + f"gpurun_out/{log}.log") else None
     if dbs and m:
         txt = subprocess.run([sys.executable, R + "tools/prof_stats.py", dbs[0], str(n), m.group(1), "60"], capture_output=True, text=True).stdout
-        open(R + f"profiles/{TAG}_{name}_step_kernels.txt", "w").write(f"# rocprofv3 --kernel-trace -- python3 tools/{'train_prof' if name == 'train' else 'cqe_prof'}.py bf16 (commit {head}); ms/step under the profiler {m.group(1)}\n" + txt)
+        open(R + f"profiles/{TAG}_{name}_step_kernels.txt", "w").write(f"# rocprofv3 --kernel-trace -- python3 tools/{'train_prof.py bf16' if name == 'train' else ('cqe_prof.py bf16 train' if name == 'cqe_train' else 'cqe_prof.py bf16')} (commit {head}); ms/step under the profiler {m.group(1)}\n" + txt)
 print(dom, "value", d["value"], "frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
