@@ -15,6 +15,7 @@ a graph of ATen ops:
 There is no CPU path: tensors must live on an MI355X (`cuda`) device.
 """
 import math
+import os
 
 import numpy as np
 
@@ -33,6 +34,7 @@ from masic_amd.streams import ForkJoin as _ForkJoin
 from masic_amd import fp8 as _fp8
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
+_HEADS_GROUPED = os.environ.get("MASIC_HEADS_GROUPED", "1") != "0"     # layer i of a head's three stacks in one launch (0: A/B timing)
 
 
 class CompressionModel(nn.Module):
@@ -253,6 +255,33 @@ class _GmmHeads(nn.Module):
         t = _hip.gemm_f8k(t, wp, ws, l1.bias.detach(), B, l1.in_channels, l1.out_channels, H, W, acts[1], out="f16k")
         return _hip.gemm_f16k(t, l2.packed_gemm_dma_weight(), l2.bias.detach(), B, l2.in_channels, l2.out_channels, H, W, acts[2], want_nchw=True)
 
+    _STACKS = (("gmm_sigma", "h_sigma", (_RELU, _RELU, _RELU)), ("gmm_means", "h_means", (_LEAKY, _LEAKY, _NONE)),
+               ("gmm_weights", "h_weights", (_LEAKY, _LEAKY, _NONE)))
+
+    def _grouped_heads_ok(self):
+        return all(getattr(self, n)[i].in_channels % 16 == 0 and getattr(self, n)[i].out_channels % 32 == 0
+                   for n, _, _ in self._STACKS for i in (0, 2, 4))
+
+    def _heads_grouped(self, xf, sc, B, H, W):
+        """sigma, means, weight logits with layer i of the three stacks in one launch each (_hip.gemm_f16k_group); sc: the fp8
+        scales of this head (first two layers with fp8 operands, as _branch_f8k) or None (bf16 operands, as _branch_f16k)."""
+        t = [xf, xf, xf]
+        for i in range(3):
+            layers = []
+            for k, (name, tag, acts) in enumerate(self._STACKS):
+                layer = getattr(self, name)[2 * i]
+                L = dict(x=t[k], bias=layer.bias.detach(), Cin=layer.in_channels, Cout=layer.out_channels, act=acts[i],
+                         out="nchw" if i == 2 else "f16k")
+                if sc is not None and i < 2:
+                    L["wp"], L["ws"] = layer.packed_gemm_f8k_weight(sc["c"] if i == 0 else sc[tag])
+                    if i == 0:
+                        L["out"], L["out_scale"] = "f8k", sc[tag]
+                else:
+                    L["wp"] = layer.packed_gemm_dma_weight()
+                layers.append(L)
+            t = _hip.gemm_f16k_group(layers, B, H, W)
+        return tuple(t)
+
     def _f8k_heads_ok(self):
         return all(seq[i].in_channels % 32 == 0 and seq[i].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights) for i in (0, 2)) \
             and all(seq[4].in_channels % 16 == 0 and seq[4].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights))
@@ -265,7 +294,8 @@ class _GmmHeads(nn.Module):
         if _mnn.reduced_precision() and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
             B, _, H, W = x.shape
             sc = _fp8.scales(self)
-            if sc is not None and self._f8k_heads_ok():
+            use_f8 = sc is not None and self._f8k_heads_ok()
+            if use_f8:
                 x8 = _hip.nchw_to_f8k(x, sc["c"])          # quantised once, read by the three stacks
                 branch = lambda seq, tag, acts: self._branch_f8k(seq, x8, sc, tag, B, H, W, acts)
                 xf = x8
@@ -280,6 +310,9 @@ class _GmmHeads(nn.Module):
                                     if l0.in_channels % 16 == 0 and l0.out_channels % 32 == 0 else
                                     _hip.gemm1x1_bf16(xf, l0.packed_gemm_weight(), l0.bias.detach(), B, l0.in_channels, l0.out_channels, H, W, acts[0]))
                     return self._branch_f16k(seq, xf, B, H, W, acts)
+            # layer i of the three stacks as ONE launch (640 ... 864 workgroups instead of 3 x 192 ... 288): no streams needed
+            if _HEADS_GROUPED and not _fp8.recording() and self._grouped_heads_ok():
+                return self._heads_grouped(xf, sc if use_f8 else None, B, H, W)
             # the three stacks are independent and each of their GEMMs fills about one wave of workgroups: run them on
             # three HIP streams so that their tails overlap
             if not parallel:

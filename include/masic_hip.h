@@ -110,6 +110,23 @@ size_t masic_gemm_f16k_packed_bytes(int Cin, int Cout);
 int masic_gemm_f16k_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream);
 int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
                         int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
+/* Up to three such layers over the same B x HW pixels in ONE launch: layer i of the sigma / means / weights stacks of a GMM head
+ * (reference MASIC.py:330-468: nine 1x1 layers per head, three per stack) -- 640 ... 864 workgroups instead of three launches of
+ * 192 ... 288.  All groups bf16 operands (wscale NULL: x is F16K) or all fp8 (wscale set: x is F8K, weights from
+ * masic_gemm_f8k_pack_weight, wscale = weight scales x the input tensor's scale); per group exactly one of y_f16k / y_f8k (quantised
+ * with out_inv_scale) / y_nchw.  Results equal the single-layer calls bit for bit. */
+typedef struct masic_gemm_group {
+    const void* x;
+    const void* w_packed;
+    const float* wscale;
+    const float* bias;
+    void* y_f16k;
+    void* y_f8k;
+    float* y_nchw;
+    float out_inv_scale;
+    int Cin, Cout, out_ctot, out_coff, act;
+} masic_gemm_group_t;
+int masic_gemm_f16k_group_fwd(const masic_gemm_group_t* groups, int ngroups, int B, int HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The same convolutions (nn.Conv2d / nn.ConvTranspose2d / MaskedConv2d of MASIC.py:510-622, :170-187, :690-700) with

@@ -26,6 +26,14 @@ class ConvDesc(ctypes.Structure):
         "gate_ctot", "gate_c", "prec")]
 
 
+class GemmGroup(ctypes.Structure):
+    """masic_gemm_group_t"""
+    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("wscale", c_void_p), ("bias", c_void_p),
+                ("y_f16k", c_void_p), ("y_f8k", c_void_p), ("y_nchw", c_void_p), ("out_inv_scale", c_float),
+                ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32), ("out_ctot", ctypes.c_int32), ("out_coff", ctypes.c_int32),
+                ("act", ctypes.c_int32)]
+
+
 _P = c_void_p
 # name -> (restype, argtypes); every symbol of include/masic_hip.h
 SIGNATURES = {
@@ -43,6 +51,7 @@ SIGNATURES = {
     "masic_gemm_f16k_packed_bytes": (c_size_t, [c_int, c_int]),
     "masic_gemm_f16k_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "masic_gemm_f16k_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "masic_gemm_f16k_group_fwd": (c_int, [ctypes.POINTER(GemmGroup), c_int, c_int, c_int, _P]),
     "masic_conv_f16k_supported": (c_int, [_P]),
     "masic_conv_f16k_kernel_name": (c_int, [_P, c_int, ctypes.c_char_p, c_size_t]),
     "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),

@@ -1438,6 +1438,17 @@ struct GemmF16kArgs {
     float out_inv_scale;
 };
 
+// Up to three independent GEMMs over the same pixels in ONE launch (masic_gemm_f16k_group_fwd): the three entropy-parameter stacks
+// of a GMM head (MASIC.py:330-468) are three 3-layer chains of 6 / 8 / 9 co-blocks x 32 pixel tiles each at 8 x 32 x 32 latents --
+// 192 ... 288 workgroups on 256 CUs per launch, most of whose time is launch ramp, prologue and tail.  Layer i of the three stacks
+// as one grid (blockIdx.y walks the co-blocks of group 0, then 1, then 2) is 20 ... 27 co-blocks = 640 ... 864 workgroups.
+constexpr int GEMM_MAXG = 3;
+struct GemmGroupArgs {
+    GemmF16kArgs g[GEMM_MAXG];
+    int cb_end[GEMM_MAXG];        // first co-block (blockIdx.y) past group i
+    int n;
+};
+
 // fp8 operands: [co block][k32][hh][co 128][16 fp8] with per-output-channel scales ws[co] = max|W[co]| / 448
 __global__ void wscale_gemm_f8k_kernel(const float* __restrict__ w, float* __restrict__ ws, int Cin, int Cout, int transposed) {
     const int co = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1487,8 +1498,14 @@ __global__ void pack_gemm_f16k_kernel(const float* __restrict__ w, unsigned shor
 // 288 workgroups (nine 128-channel blocks x 32 pixel tiles) on 256 CUs needs.
 // F8: fp8 operands (F8K input, 32-channel blocks; one MFMA = two consecutive blocks of the chunk, one per lane half)
 template <int KC, bool F8 = false>
-__global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16kArgs a) {
+__global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmGroupArgs ga) {
     static_assert(!F8 || KC % 2 == 0, "fp8 operands consume channel blocks in pairs");
+    // group of this workgroup (uniform: scalar selects on blockIdx.y)
+    GemmF16kArgs a = ga.g[0];
+    int cb0 = 0;
+    if (ga.n > 1 && (int)blockIdx.y >= ga.cb_end[0]) { a = ga.g[1]; cb0 = ga.cb_end[0]; }
+    if (ga.n > 2 && (int)blockIdx.y >= ga.cb_end[1]) { a = ga.g[2]; cb0 = ga.cb_end[1]; }
+    const int cblk = (int)blockIdx.y - cb0;                                  // co-block inside the group
     constexpr int ACT0 = KC * 4096, STAGE = KC * 12288, NS = 3;
     constexpr int WPW = KC, APW = 2 * KC;                                    // weight / activation DMA pieces per wave per chunk
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -1498,11 +1515,11 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmF16k
     const int j = lane & 31, h = lane >> 5;
     const bool wrole = wave < 4;
     const int wq = wave & 3;
-    const int p0 = blockIdx.x * 256, m0 = blockIdx.y * 128, b = blockIdx.z;
+    const int p0 = blockIdx.x * 256, m0 = cblk * 128, b = blockIdx.z;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + (size_t)b * a.Cin16 * a.HW * 16), 0, a.Cin16 * a.HW * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.w + (size_t)blockIdx.y * a.nchunks * (KC * 2048)), 0, a.nchunks * (KC * 4096), 0x00020000);
+        (void*)(a.w + (size_t)cblk * a.nchunks * (KC * 2048)), 0, a.nchunks * (KC * 4096), 0x00020000);
     // activation pieces of this wave: piece I = k*4 + wq, k < 8: k16 = I >> 3, hh = (I >> 2) & 1, pixel block = I & 3 = wq
     const int px = wq * 64 + lane;
     const int avoff = p0 + px < a.HW ? px * 32 : 0x7ffffff0;                  // + hh*16 per piece
@@ -1654,26 +1671,61 @@ extern "C" int masic_gemm_f16k_pack_weight(const float* w, void* wp, int Cin, in
 // float32 NCHW channel view (y_nchw).  Cout must be a multiple of 32.
 extern "C" int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
                                    int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream) {
-    MASIC_REQUIRE(x_f16k && w_packed && ((y_f16k != nullptr) != (y_nchw != nullptr)), MASIC_ERR_ARG, "gemm_f16k_fwd: need input, weights and exactly one output");
-    MASIC_REQUIRE(B > 0 && HW > 0 && Cin % 16 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED, "gemm_f16k_fwd: needs Cin %% 16 == 0 and Cout %% 32 == 0");
-    MASIC_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot && (y_nchw != nullptr || (out_ctot % 16 == 0 && out_coff % 16 == 0)), MASIC_ERR_SHAPE,
-                  "gemm_f16k_fwd: output channel view");
-    MASIC_REQUIRE((long)(Cin / 16) * HW * 32 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_f16k_fwd: activation plane too large for 32-bit offsets");
-    const int Cin16 = Cin / 16, nk16 = round_up(Cin16, 4);
-    dim3 grid(ceil_div(HW, 256), ceil_div(Cout, 128), B);
-    // two co-resident workgroups per CU (32-channel chunks) unless the grid is a whole number of single-workgroup rounds anyway
+    const masic_gemm_group_t g{x_f16k, w_packed, nullptr, bias, y_f16k, nullptr, y_nchw, 0.0f, Cin, Cout, out_ctot, out_coff, act};
+    return masic_gemm_f16k_group_fwd(&g, 1, B, HW, stream);
+}
+
+// Up to three such layers over the same B x HW pixels in one launch (GemmGroupArgs above).  All groups bf16 operands (wscale NULL
+// everywhere: x is F16K, Cin % 16 == 0) or all fp8 (wscale set everywhere: x is F8K, Cin % 32 == 0, weights from
+// masic_gemm_f8k_pack_weight); per group exactly one of y_f16k / y_f8k / y_nchw.  Results are those of the single-layer calls, bit for bit.
+extern "C" int masic_gemm_f16k_group_fwd(const masic_gemm_group_t* groups, int ngroups, int B, int HW, void* stream) {
+    MASIC_REQUIRE(groups != nullptr && ngroups >= 1 && ngroups <= GEMM_MAXG, MASIC_ERR_ARG, "gemm_f16k_group_fwd: 1 ... %d groups", GEMM_MAXG);
+    MASIC_REQUIRE(B > 0 && HW > 0, MASIC_ERR_SHAPE, "gemm_f16k_group_fwd: non-positive size");
+    const bool f8 = groups[0].wscale != nullptr;
+    const int cblk = f8 ? 32 : 16;
+    GemmGroupArgs ga{};
+    int ncb = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const masic_gemm_group_t& g = groups[i];
+        MASIC_REQUIRE((g.wscale != nullptr) == f8, MASIC_ERR_ARG, "gemm_f16k_group_fwd: bf16 and fp8 groups cannot share a launch");
+        MASIC_REQUIRE(g.x && g.w_packed && ((g.y_f16k != nullptr) + (g.y_f8k != nullptr) + (g.y_nchw != nullptr) == 1), MASIC_ERR_ARG,
+                      "gemm_f16k_fwd: need input, weights and exactly one output");
+        MASIC_REQUIRE(g.Cin > 0 && g.Cin % cblk == 0 && g.Cout > 0 && g.Cout % 32 == 0, MASIC_ERR_UNSUPPORTED,
+                      "gemm_f16k_fwd: needs Cin %% %d == 0 and Cout %% 32 == 0", cblk);
+        const int oalign = f8 ? 32 : 16;
+        MASIC_REQUIRE(g.out_coff >= 0 && g.out_coff + g.Cout <= g.out_ctot && (g.y_nchw != nullptr || (g.out_ctot % oalign == 0 && g.out_coff % oalign == 0)),
+                      MASIC_ERR_SHAPE, "gemm_f16k_fwd: output channel view");
+        MASIC_REQUIRE(g.y_f8k == nullptr || g.out_inv_scale > 0.0f, MASIC_ERR_ARG, "gemm_f8k_fwd: an fp8 output needs out_inv_scale > 0");
+        MASIC_REQUIRE((long)(g.Cin / cblk) * HW * 32 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_f16k_fwd: activation plane too large for 32-bit offsets");
+        ncb += ceil_div(g.Cout, 128);
+        ga.cb_end[i] = ncb;
+    }
+    ga.n = ngroups;
+    dim3 grid(ceil_div(HW, 256), ncb, B);
+    // bf16 operands: 32-channel chunks, 72 KiB of LDS -- two workgroups per CU, or one next to a workgroup of another stream's kernel.
+    // The 64-channel form (144 KiB, a CU to itself) is as fast when the launch has the chip to itself, but inside the three-stream
+    // forward it shuts the other streams' kernels out of its CUs: 2.54 -> 2.41 ms per step at 8 x 512 x 512 with KC = 2 everywhere
+    // (A/B on one box, 100 replays each, twice).  fp8 operands: 128-channel chunks only.  MASIC_GEMM_KC = 4 restores the old rule
+    // (64-channel chunks when the grid is a whole number of 256-workgroup rounds).
     const long blocks = (long)grid.x * grid.y * grid.z;
-    const bool kc2 = blocks % 256 != 0 || blocks < 256;
-    GemmF16kArgs a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (unsigned short*)y_f16k, y_nchw,
-                   Cin16, nk16 / (kc2 ? 2 : 4), Cout, HW, out_ctot, out_coff, act, nullptr, nullptr, 0.0f};
+    static const int forced = getenv("MASIC_GEMM_KC") ? atoi(getenv("MASIC_GEMM_KC")) : 0;
+    const bool kc2 = !f8 && (forced != 4 || blocks % 256 != 0 || blocks < 256);
+    for (int i = 0; i < ngroups; ++i) {
+        const masic_gemm_group_t& g = groups[i];
+        const int cin_b = g.Cin / cblk, nkb = round_up(cin_b, 4);
+        ga.g[i] = GemmF16kArgs{(const unsigned short*)g.x, (const unsigned short*)g.w_packed, g.bias, (unsigned short*)g.y_f16k, g.y_nchw,
+                               cin_b, nkb / (kc2 ? 2 : 4), g.Cout, HW, g.out_ctot, g.out_coff, g.act, g.wscale, (unsigned char*)g.y_f8k, g.out_inv_scale};
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_f16k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_f16k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_f16k<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (kc2) hipLaunchKernelGGL(gemm_f16k<2>, grid, dim3(512), 3 * 2 * 12288, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gemm_f16k<4>, grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
+    if (f8) hipLaunchKernelGGL((gemm_f16k<4, true>), grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, ga);
+    else if (kc2) hipLaunchKernelGGL(gemm_f16k<2>, grid, dim3(512), 3 * 2 * 12288, (hipStream_t)stream, ga);
+    else hipLaunchKernelGGL(gemm_f16k<4>, grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, ga);
     return masic_launch_status("gemm_f16k_fwd");
 }
 
@@ -1697,24 +1749,9 @@ extern "C" int masic_gemm_f8k_pack_weight(const float* w, void* wp, float* wscal
 
 extern "C" int masic_gemm_f8k_fwd(const void* x_f8k, const void* w_packed, const float* wscale, const float* bias, void* y_f16k, void* y_f8k,
                                   float* y_nchw, float out_inv_scale, int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream) {
-    MASIC_REQUIRE(x_f8k && w_packed && wscale && ((y_f16k != nullptr) + (y_f8k != nullptr) + (y_nchw != nullptr) == 1), MASIC_ERR_ARG,
-                  "gemm_f8k_fwd: need input, weights, scales and exactly one output");
-    MASIC_REQUIRE(B > 0 && HW > 0 && Cin % 32 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED, "gemm_f8k_fwd: needs Cin %% 32 == 0 and Cout %% 32 == 0");
-    MASIC_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot && (y_nchw != nullptr || (out_ctot % 32 == 0 && out_coff % 32 == 0)), MASIC_ERR_SHAPE,
-                  "gemm_f8k_fwd: output channel view");
-    MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "gemm_f8k_fwd: an fp8 output needs out_inv_scale > 0");
-    MASIC_REQUIRE((long)(Cin / 32) * HW * 32 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_f8k_fwd: activation plane too large for 32-bit offsets");
-    const int Cin32 = Cin / 32, nk32 = round_up(Cin32, 4);
-    dim3 grid(ceil_div(HW, 256), ceil_div(Cout, 128), B);
-    GemmF16kArgs a{(const unsigned short*)x_f8k, (const unsigned short*)w_packed, bias, (unsigned short*)y_f16k, y_nchw,
-                   Cin32, nk32 / 4, Cout, HW, out_ctot, out_coff, act, wscale, (unsigned char*)y_f8k, out_inv_scale};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_f16k<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_f16k<4, true>), grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, a);
-    return masic_launch_status("gemm_f8k_fwd");
+    MASIC_REQUIRE(wscale != nullptr, MASIC_ERR_ARG, "gemm_f8k_fwd: need input, weights, scales and exactly one output");
+    const masic_gemm_group_t g{x_f8k, w_packed, wscale, bias, y_f16k, y_f8k, y_nchw, out_inv_scale, Cin, Cout, out_ctot, out_coff, act};
+    return masic_gemm_f16k_group_fwd(&g, 1, B, HW, stream);
 }
 
 // Diagnostics: a device buffer of 16 uint64 that every following conv_f16k launch fills with {s_memtime (core clock), s_memrealtime

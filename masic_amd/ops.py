@@ -751,6 +751,35 @@ def gemm_f16k(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_coff
     return y32 if y32 is not None else y16
 
 
+def gemm_f16k_group(layers, B, H, W):
+    """Up to three independent 1x1 layers over the same B x H x W pixels in ONE launch (masic_gemm_f16k_group_fwd): layer i of the
+    three entropy-parameter stacks of a GMM head.  layers: dicts with x, wp, bias, Cin, Cout, act and out = "f16k" | "nchw" | "f8k";
+    fp8-operand layers (all or none) add ws (dequantisation scales) and, for out = "f8k", out_scale.  Returns the outputs in order;
+    each equals what gemm_f16k / gemm_f8k return for that layer, bit for bit."""
+    HW = H * W
+    arr = (_lib.GemmGroup * len(layers))()
+    outs = []
+    for g, L in zip(arr, layers):
+        x, Cout, out = L["x"], L["Cout"], L.get("out", "f16k")
+        y16 = y8 = y32 = None
+        if out == "nchw":
+            y32 = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+            out_ctot = Cout
+        elif out == "f8k":
+            out_ctot = (Cout + 31) // 32 * 32
+            y8 = torch.empty(B * out_ctot * HW, dtype=torch.uint8, device=x.device)
+        else:
+            out_ctot = (Cout + 31) // 32 * 32 if L.get("ws") is not None else (Cout + 15) // 16 * 16
+            y16 = torch.empty(B * out_ctot * HW, dtype=torch.int16, device=x.device)
+        g.x, g.w_packed, g.wscale, g.bias = _p(x), _p(L["wp"]), _p(L.get("ws")), _p(L["bias"])
+        g.y_f16k, g.y_f8k, g.y_nchw = _p(y16), _p(y8), _p(y32)
+        g.out_inv_scale = 1.0 / float(L["out_scale"]) if out == "f8k" else 0.0
+        g.Cin, g.Cout, g.out_ctot, g.out_coff, g.act = L["Cin"], Cout, out_ctot, 0, int(L["act"])
+        outs.append(y32 if y32 is not None else (y8 if y8 is not None else y16))
+    check(lib.masic_gemm_f16k_group_fwd(arr, len(layers), B, HW, _stream()), "gemm_f16k_group_fwd")
+    return outs
+
+
 # --------------------------------------------------------------------------------------------- fp8 operand path (F8K)
 def f8k_to_nchw(y8, B, C, H, W, scale):
     """F8K uint8 buffer -> float32 NCHW (torch ops; tests only)."""

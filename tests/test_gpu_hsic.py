@@ -349,6 +349,33 @@ def test_bf16_operand_path_config1_accuracy_streams_and_graph():
     assert bad <= 0.06 * total
 
 
+@pytest.mark.parametrize("which", ["y1", "y2"])
+def test_gmm_heads_grouped_launches_equal_per_stack_launches(which, monkeypatch):
+    """The entropy-parameter heads (reference MASIC.py:330-468) with layer i of the sigma / means / weights stacks as one grouped
+    GEMM launch (the default of the bf16-operand eval forward) against the nine single-layer launches: bit for bit."""
+    import MASIC
+    from masic_amd import nn as mnn, synth
+    N, M, K = 32, 32, 5                                   # 4M, 5M, 6M, MK multiples of 32: every layer on the DMA-staged GEMM
+    cls = MASIC.gmm_hyper_y1_same_resolution if which == "y1" else MASIC.gmm_hyper_y2_same_resolution
+    head = cls(N, M, K)
+    head.load_state_dict(synth.synth_state_dict(head.state_dict(), seed=5))
+    head = head.to(DEV).eval()
+    x = torch.randn(2, (4 if which == "y1" else 5) * M, 12, 20, generator=torch.Generator().manual_seed(3)).to(DEV)
+    mnn.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            monkeypatch.setattr(MASIC, "_HEADS_GROUPED", False)
+            want = head.heads(x)
+            monkeypatch.setattr(MASIC, "_HEADS_GROUPED", True)
+            assert head._grouped_heads_ok()
+            got = head.heads(x)
+            torch.cuda.synchronize()
+    finally:
+        mnn.set_precision("f32")
+    for a, b, name in zip(got, want, ("sigma", "means", "logits")):
+        assert a.shape == (2, M * K, 12, 20) and torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,H,W", [(8, 512, 512), (2, 512, 896)])
 def test_full_size_properties_bf16_vs_f32_paths(B, H, W):
     """BASELINE config shapes (no CPU oracle at this size): size-independent properties -- the bf16-operand path is

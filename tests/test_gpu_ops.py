@@ -539,6 +539,40 @@ def test_gemm_f16k_dma_stack(B, Cin, Cmid, Cout, H, W, tr):
     assert torch.equal(out[:, 8:8 + Cout], y) and torch.all(out[:, :8] == 3.0) and torch.all(out[:, 8 + Cout:] == 3.0)
 
 
+@pytest.mark.parametrize("B,H,W,f8", [(2, 16, 24, False), (1, 13, 9, False), (2, 16, 24, True)])
+def test_gemm_f16k_group_equals_single_layer_calls(B, H, W, f8):
+    """masic_gemm_f16k_group_fwd -- layer i of the three entropy-parameter stacks of a GMM head (reference MASIC.py:330-468) in ONE
+    launch -- against the single-layer launches: same kernel, same k order, so every output (F16K, F8K, float32 NCHW; ragged pixel
+    counts; different Cin / Cout / activation per group) must agree bit for bit.  Also the argument checks of the grouped entry."""
+    ops = _ops()
+    shapes = [(768, 1152, ops.ACT_RELU, "f16k"), (960, 768, ops.ACT_LEAKY, "nchw"), (768, 960, ops.ACT_NONE, "f8k" if f8 else "f16k")]
+    layers, singles = [], []
+    for k, (Cin, Cout, act, out) in enumerate(shapes):
+        x = _rand(B, Cin, H, W, seed=10 + k, scale=1.0).to(DEV)
+        w = _rand(Cout, Cin, seed=20 + k, scale=(2.0 / Cin) ** 0.5).to(DEV)
+        b = _rand(Cout, seed=30 + k, scale=0.1).to(DEV)
+        if f8:
+            x8 = ops.nchw_to_f8k(x, 0.02)
+            wp, ws = ops.pack_gemm_f8k_weight(w, Cin, Cout, False)
+            ws = (ws * 0.02).contiguous()
+            layers.append(dict(x=x8, wp=wp, ws=ws, bias=b, Cin=Cin, Cout=Cout, act=act, out=out, out_scale=0.05))
+            singles.append(ops.gemm_f8k(x8, wp, ws, b, B, Cin, Cout, H, W, act, out=out, out_scale=0.05))
+        else:
+            xf = ops.nchw_to_f16k(x)
+            wp = ops.pack_gemm_f16k_weight(w, Cin, Cout, False)
+            layers.append(dict(x=xf, wp=wp, bias=b, Cin=Cin, Cout=Cout, act=act, out=out))
+            singles.append(ops.gemm_f16k(xf, wp, b, B, Cin, Cout, H, W, act, want_nchw=out == "nchw"))
+    for n in (3, 2, 1):
+        got = ops.gemm_f16k_group(layers[:n], B, H, W)
+        for k in range(n):
+            assert got[k].dtype == singles[k].dtype and torch.equal(got[k], singles[k]), f"group of {n}, layer {k} ({shapes[k]})"
+    if not f8:
+        with pytest.raises(RuntimeError):
+            ops.gemm_f16k_group(layers + layers[:1], B, H, W)                       # more than three groups
+        with pytest.raises(RuntimeError):
+            ops.gemm_f16k_group([dict(layers[0], Cout=1000)], B, H, W)              # Cout % 32
+
+
 def test_homography_from_corners_vs_restatement():
     """corner offsets -> h_matrix (get_perspective_transform + inverse + h_adjust) in one kernel against the
     float64 restatement (oracle/udh_oracle.py; kornia absent: parity unpinned), plus the defining property: before h_adjust

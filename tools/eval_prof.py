@@ -17,5 +17,6 @@ with torch.no_grad():
     step = net if serial else GraphedHSIC(net, x1, x2, hm)
     for _ in range(3): step(x1, x2, hm)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): step(x1, x2, hm)
-    torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 5 * 1e3)
+    n = int(os.environ.get("EVAL_PROF_STEPS", "5"))
+    for _ in range(n): step(x1, x2, hm)
+    torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / n * 1e3)
