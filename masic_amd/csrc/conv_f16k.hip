@@ -533,6 +533,17 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
     int cb = PATCH0, pb = PATCH0 + (L % NB) * a.PB;           // byte offsets of the patch buffer of chunk c / of chunk c+L
     int xsoff = L * (KS * plane_bytes);                       // patch producer: byte offset of chunk c+L in the input
 
+    v4u tvq;                                                  // tap offsets (LDS bytes inside a patch buffer) of the next step
+    unsigned tv4q = 0;
+    auto table_request = [&](int t) {
+        if constexpr (T == 5) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(tvq) : "v"(ldsb + table_off + t * 32) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(tv4q) : "v"(ldsb + table_off + t * 32) : "memory");
+        } else if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvq) : "v"(ldsb + table_off + t * 16) : "memory");
+        else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvq)) : "v"(ldsb + table_off + t * 8) : "memory");
+    };
+    table_request(0);
+
     // One step: slice S of the patch DMA (or none), T taps x KS k-steps of 2x2 MFMAs, counted wait, barrier.
     auto step = [&](auto slice, int t, bool last) {
         constexpr int S = decltype(slice)::value;
@@ -563,14 +574,14 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
         // LDS reads of the K loop go through inline asm with hand-counted lgkmcnt: for a compiler-visible ds_read hipcc puts
         // `s_waitcnt vmcnt(0)` in front (the DMA in flight might alias it), which would drain the prefetch queue every step.
         // The fragments of k-step i+1 are requested before the MFMAs of k-step i are issued.
-        v4u tvv;
-        unsigned tv4 = 0;
-        if constexpr (T == 5) {
-            asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 32) : "memory");
-            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(tv4) : "v"(ldsb + table_off + t * 32) : "memory");
-        } else if constexpr (T == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tvv) : "v"(ldsb + table_off + t * 16) : "memory");
-        else asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<v2u*>(&tvv)) : "v"(ldsb + table_off + t * 8) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvv), "+v"(tv4)::"memory");
+        // tap offsets of this step: requested a step ago (table_request), so the wait is over before it starts; the next step's
+        // request goes out now and returns under this step's MFMAs (LDS returns in order: it is older than every fragment read the
+        // counted waits below leave outstanding).  Read at the top of the step they cost every wave an LDS round trip right after
+        // the barrier, with nothing else to issue.
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvq), "+v"(tv4q)::"memory");
+        const v4u tvv = tvq;
+        const unsigned tv4 = tv4q;
+        table_request(last ? 0 : t + 1);
         const unsigned wst = ldsb + al + cslot + msub * 512;
         constexpr int NQ = F8 ? 2 : 1;                            // ds_read_b128 per fragment
         constexpr int NKS = F8 ? (T * KS) / 2 : T * KS;           // MFMA k-steps per step
@@ -664,6 +675,7 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
         xsoff += KS * plane_bytes;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tvq), "+v"(tv4q)::"memory");      // the last step's table request must not land in reused registers
     if (stamp) { stamp[4] = __builtin_amdgcn_s_memtime(); stamp[5] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- epilogue
