@@ -417,6 +417,12 @@ size_t masic_gdn_bwd_fused_workspace_bytes(void);
 int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const float* gamma, float* gx,
                         float* g_beta, float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse,
                         double beta_min, void* stream);
+/* The same with F16K operands: exactly one of x / x_f16k and of g / g_f16k (float32 NCHW or F16K bf16 [B][8][HW][16]); dx goes to
+ * gx (float32 NCHW) and / or gx_f16k; g_sum [128] (or NULL) receives the per-channel sums of dx over batch and pixels -- the bias
+ * gradient of the convolution in front of the GDN (autograd of `conv -> GDN`, reference MASIC.py:515-529, :538-552). */
+int masic_gdn_bwd_fused_ex(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
+                           float* gx, void* gx_f16k, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
+                           int B, int C, int H, int W, int inverse, double beta_min, void* stream);
 /* GaussianMixtureConditional_gf backward (entropy_models.py:808-858 + both LowerBound rules, bound_ops.py:40-42).
  * y_hat as returned by the forward; g_yhat may be NULL; weights_are_logits as in the forward. */
 int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,

@@ -65,8 +65,11 @@ class ConvFn(Function):
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
 
-def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None):
+def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None, g16=None, gb=None, gx_f16k=False):
     """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW (x16: x in F16K if the caller has it).
+    g16 / gb: dy in F16K and its channel sums when the caller's producer already wrote them (ops.gdn_bwd_fused_ex): no conversion and
+    no reduction pass here.  gx_f16k: return dx as an F16K buffer (int16) when the F16K kernel computes it (the consumer is another
+    F16K-operand kernel), float32 NCHW otherwise.
     (Issuing dW / db on a side stream next to dx was measured: 24.9 -> 25.2 ms per HSIC training step, i.e. nothing -- not kept.)"""
     g = _c(g)
     if act != ops.ACT_NONE:
@@ -91,7 +94,8 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     # 3x3 stride-1 layers (Independent_EN, hyper transforms): dW from both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
     dw_f16k = (need_gw and _WGRAD3_F16K and bf16 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
-    g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k) else None      # dy in F16K, converted once for both gradients
+    if g16 is None or act != ops.ACT_NONE:
+        g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k) else None  # dy in F16K, converted once for both gradients
 
     def input_gradient():
         if dx_gemm:
@@ -99,19 +103,20 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
             return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
         if dx_f16k:
-            return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=True)
+            return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=not (gx_f16k and Cin % 16 == 0))
         return ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
 
     def parameter_gradients():
-        gw = gb = None
+        gw = None
+        gb_ = gb if act == ops.ACT_NONE else None
         if dw_f16k:
             gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
         elif need_gw:
             dw = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
             gw = ops.conv2d_wgrad(x, g, dw, tuple(weight.shape))
-        if need_gb:
-            gb = ops.channel_sum(g)
-        return gw, gb
+        if need_gb and gb_ is None:
+            gb_ = ops.channel_sum(g)
+        return gw, gb_ if need_gb else None
 
     gx = input_gradient() if need_gx else None
     return (gx,) + parameter_gradients()
@@ -491,6 +496,21 @@ class RateDistortionFn(Function):
 # float32 activations the per-layer nodes keep -- and the backward converts each to float32 NCHW right before the kernel that
 # needs it (weight gradient: the layer's input; GDN backward: the GDN's input).  Gradients are those of the same function evaluated
 # on bf16-rounded activations; the float32 mode keeps the per-layer nodes (the parity path).
+_GDN_BWD_F16K = os.environ.get("MASIC_GDN_BWD_F16K", "1") != "0"
+
+
+def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True):
+    """GDN backward inside the fused transforms: (dx float32 NCHW, dx F16K | None, channel sums of dx | None, d beta, d gamma); u16: the
+    GDN's saved input (F16K), g: float32 NCHW or F16K."""
+    if not _GDN_BWD_F16K:
+        B, C, H, W = shape
+        g32 = g if g.dtype == torch.float32 else ops.f16k_to_nchw_dev(g, B, C, H, W)
+        gx, gb, gg = gdn_backward(ops.f16k_to_nchw_dev(u16, B, C, H, W), g32, gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min)
+        return gx, None, None, gb, gg
+    return ops.gdn_bwd_fused_ex(u16, _c(g), shape, gdn.beta.detach(), gdn.gamma.detach(), gdn.inverse, gdn.beta_min, want_nchw=True,
+                                want_f16k=want_f16k, want_sum=True)
+
+
 class AnalysisFn(Function):
     """conv(3->128)+GDN, conv+GDN, conv+GDN, conv(128->M) of Encoder1 / Encoder2 (reference MASIC.py:510-531): x float32 NCHW -> y float32 NCHW."""
 
@@ -520,12 +540,16 @@ class AnalysisFn(Function):
         B = x.shape[0]
         nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
         grads = {}
-        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE)
+        # The GDN backward reads its saved input (and the gradient, when an F16K kernel produced it) as F16K and writes dx twice --
+        # float32 NCHW for the weight-gradient kernel, F16K for the input-gradient convolution -- plus dx's channel sums (the bias
+        # gradient): no F16K -> NCHW pass on u, no NCHW -> F16K pass and no reduction pass on dx.  MASIC_GDN_BWD_F16K=0: the separate passes.
+        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE, gx_f16k=_GDN_BWD_F16K)
         for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
-            gu, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = gdn_backward(nchw(u, hw), gx, gdns[i].beta, gdns[i].gamma, gdns[i].inverse, gdns[i].beta_min)
-            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE)
-        gu, grads["beta1"], grads["gamma1"] = gdn_backward(nchw(u1, ctx.sizes[0]), gx, gdns[0].beta, gdns[0].gamma, gdns[0].inverse, gdns[0].beta_min)
-        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0])
+            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i])
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE,
+                                                                                g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
+        gu, _, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0], want_f16k=False)
+        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], gb=gsum)
         return (gimg, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
                 grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
 
@@ -586,12 +610,14 @@ class SynthesisFn(Function):
         B = y_hat.shape[0]
         nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
         grads = {}
-        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE)
+        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE, gx_f16k=_GDN_BWD_F16K)
         for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
-            gu, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = gdn_backward(nchw(u, hw), gx, gdns[i].beta, gdns[i].gamma, gdns[i].inverse, gdns[i].beta_min)
-            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE)
-        gu, grads["beta1"], grads["gamma1"] = gdn_backward(nchw(u1, ctx.sizes[0]), gx, gdns[0].beta, gdns[0].gamma, gdns[0].inverse, gdns[0].beta_min)
-        gy, grads["w1"], grads["b1"] = conv_backward(convs[0], y_hat, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0])
+            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i])
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE,
+                                                                                g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
+        gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0])
+        gy, grads["w1"], grads["b1"] = conv_backward(convs[0], y_hat, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0],
+                                                     g16=gu16, gb=gsum)
         return (gy, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
                 grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
 

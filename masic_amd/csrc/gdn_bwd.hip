@@ -19,6 +19,14 @@
 //                       with B = ones.
 // Workgroups are persistent (one per CU, 135 KiB of LDS); their partial d gamma^ / d beta^ go to a workspace and a second
 // kernel adds them in a fixed order and applies the parametrizer rule.
+//
+// F16K operands (masic_gdn_bwd_fused_ex; the fused transforms of the training step keep their activations in that layout,
+// masic_amd/autograd.py: AnalysisFn / SynthesisFn): the accumulator layout of a wave IS the tile layout of conv_f16k's epilogue, so
+//   x, g  may come as F16K bf16 (8-byte loads of 4 channels, no conversion pass in front of this kernel),
+//   dx    may ALSO be written as F16K bf16 (what the input-gradient convolution of the producing layer reads; whole 32-byte
+//         records through v_permlane32_swap) next to -- or instead of -- the float32 NCHW tensor the weight gradient reads,
+//   and the per-channel sums of dx (the bias gradient of the convolution in front of the GDN) ride along: per-lane float32
+//   sums over the workgroup's tiles, reduced across lanes and waves once at the end, one more row of the partial slot.
 #include "common.h"
 
 namespace {
@@ -54,14 +62,44 @@ __global__ __launch_bounds__(256) void gdn_bwd_pack_kernel(const float* __restri
     }
 }
 
+constexpr int GB_SLOT = 128 * 128 + 256;        // floats per partial slot: d gamma^ | d beta^ | channel sums of dx
+
 struct GdnBwdArgs {
     const float* x; const float* g; float* gx;
+    const unsigned short* x16;   // X16: x as F16K [B][8][HW][16] bf16 (then x is unused)
+    const unsigned short* g16;   // G16: g as F16K
+    unsigned short* gx16;        // dx as F16K too, or null (gx may then be null)
     const uint4* img;            // two fragment images + beta^
-    float* part;                 // [GB_NBLK][128*128 + 128]
+    float* part;                 // [GB_NBLK][GB_SLOT]
     long long npix;              // B * HW
-    int HW, ntiles, inverse;
+    int HW, ntiles, inverse, want_sum;
 };
 
+__device__ __forceinline__ unsigned gb_pack2bf(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// lane (j, h) of a wave holds channels 32m + 8q + 4h + i (registers [m][4q + i]) of its pixel: 4 consecutive bf16 of record
+// 2m + (q >> 1), elements 8(q & 1) + 4h ...  rec: address of the pixel in record 0 (+ 4h elements); rs: elements between records
+__device__ __forceinline__ void gb_load_f16k(f32x16 (&v)[4], const unsigned short* rec, size_t rs, bool ok) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 r = make_uint2(0u, 0u);
+            if (ok) r = *reinterpret_cast<const uint2*>(rec + (size_t)(2 * m + (q >> 1)) * rs + 8 * (q & 1));
+            v[m][4 * q + 0] = __builtin_bit_cast(float, r.x << 16);
+            v[m][4 * q + 1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+            v[m][4 * q + 2] = __builtin_bit_cast(float, r.y << 16);
+            v[m][4 * q + 3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+        }
+}
+
+template <bool X16, bool G16>
 __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* tl = lds + 2 * GB_IMG;            // t tile   [128 ch][272 B]
@@ -77,9 +115,13 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
     }
     __syncthreads();
 
-    f32x16 dg[4], db;
+    f32x16 dg[4], db, dsum[4];                       // dsum: this lane's share of the per-channel sums of dx
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dg[0][e] = 0.0f; dg[1][e] = 0.0f; dg[2][e] = 0.0f; dg[3][e] = 0.0f; db[e] = 0.0f; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dsum[m][e] = 0.0f;
     gbf16x8 ones;
 #pragma unroll
     for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
@@ -92,17 +134,20 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
         const long long p = (long long)tile * 128 + w * 32 + j;
         const bool ok = p < a.npix;
         const long long b = ok ? p / a.HW : 0;
-        const size_t base = (size_t)b * 128 * hw + (size_t)(ok ? p - b * a.HW : 0) + (size_t)(4 * h) * hw;
-        const float* xp = a.x + base;
-        const float* gp = a.g + base;
+        const size_t pix = (size_t)(ok ? p - b * a.HW : 0);
+        const size_t base = (size_t)b * 128 * hw + pix + (size_t)(4 * h) * hw;
+        const size_t base16 = ((size_t)b * 8 * hw + pix) * 16 + 4 * h;       // F16K: record 0 of the pixel, + 4h elements
+        const size_t rs16 = (size_t)hw * 16;
         f32x16 xv[4], gv[4];
+        if constexpr (X16) gb_load_f16k(xv, a.x16 + base16, rs16, ok);
+        if constexpr (G16) gb_load_f16k(gv, a.g16 + base16, rs16, ok);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const unsigned off = (unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw;
-                xv[m][e] = ok ? xp[off] : 0.0f;
-                gv[m][e] = ok ? gp[off] : 0.0f;
+                if constexpr (!X16) xv[m][e] = ok ? a.x[base + off] : 0.0f;
+                if constexpr (!G16) gv[m][e] = ok ? a.g[base + off] : 0.0f;
             }
 
         // ---- n = beta^ + gamma^ x^2; x^2 (bf16) also goes to its LDS tile
@@ -161,14 +206,38 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
                 uv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[m], 0, 0, 0);
             }
         }
-        // ---- dx = s + 2 x u
-        if (ok) {
+        // ---- dx = s + 2 x u (kept in uv); rows past the end contribute zeros (x = g = 0 there)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                uv[m][e] = fmaf(2.0f * xv[m][e], uv[m][e], nv[m][e]);
+                dsum[m][e] += uv[m][e];
+            }
+        if (ok && a.gx != nullptr) {
             float* op = a.gx + base;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    op[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = fmaf(2.0f * xv[m][e], uv[m][e], nv[m][e]);
+                for (int e = 0; e < 16; ++e) op[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = uv[m][e];
+        }
+        if (a.gx16 != nullptr) {
+            // as conv_f16k.hip: store_f16k_tile -- the two halves of the wave swap their middle quarters so that lane (j, h) writes
+            // the 8 consecutive channels 8h .. 8h+7 of each 16-channel record with one 16-byte store (every lane takes part in
+            // the swap; only valid pixels store)
+            unsigned short* rec = a.gx16 + ((size_t)b * 8 * hw + pix) * 16 + 8 * h;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned a0 = gb_pack2bf(uv[m][8 * r + 0], uv[m][8 * r + 1]), a1 = gb_pack2bf(uv[m][8 * r + 2], uv[m][8 * r + 3]);
+                    const unsigned b0 = gb_pack2bf(uv[m][8 * r + 4], uv[m][8 * r + 5]), b1 = gb_pack2bf(uv[m][8 * r + 6], uv[m][8 * r + 7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    uint4 st;
+                    st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
+                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * m + r) * rs16) = st;
+                }
         }
         __syncthreads();                                           // both tiles complete
         // ---- d gamma^[32w + .][.] += t x^2^T over the 128 pixels, d beta^ with B = ones
@@ -186,7 +255,24 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
         }
     }
 
-    float* pp = a.part + (size_t)blockIdx.x * (128 * 128 + 128);
+    float* pp = a.part + (size_t)blockIdx.x * GB_SLOT;
+    if (a.want_sum) {
+        // channel sums of dx: lanes of one half hold the same channels for 32 different pixels -> butterfly over j, then the four
+        // waves through LDS (the t tile is free now), in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tl);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = dsum[m][e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (j == 0) red[w * 128 + 32 * m + (e & 3) + 8 * (e >> 2) + 4 * h] = v;
+            }
+        __syncthreads();
+        if (tid < 128) pp[128 * 128 + 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -204,16 +290,17 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
 // bound or the step would raise it): g = 2 max(p, bound) dL/dp^.  Block = 32 entries x 8 slices of the partial list.
 __global__ __launch_bounds__(256) void gdn_bwd_reduce_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ beta,
                                                              const float* __restrict__ gamma, float* __restrict__ g_beta,
-                                                             float* __restrict__ g_gamma, float beta_bound, float gamma_bound) {
+                                                             float* __restrict__ g_gamma, float* __restrict__ g_sum, float beta_bound, float gamma_bound) {
     __shared__ float red[8][32];
     const int l = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + l;                      // 128*128 + 128 is a multiple of 32
+    const int idx = blockIdx.x * 32 + l;                      // 128*128 + 128 (+ 128 with the dx sums) is a multiple of 32
     float s = 0.0f;
-    for (int k = sl; k < nblk; k += 8) s += part[(size_t)k * (128 * 128 + 128) + idx];
+    for (int k = sl; k < nblk; k += 8) s += part[(size_t)k * GB_SLOT + idx];
     red[sl][l] = s;
     __syncthreads();
     if (sl != 0) return;
     for (int k = 1; k < 8; ++k) s += red[k][l];
+    if (idx >= 128 * 128 + 128) { g_sum[idx - (128 * 128 + 128)] = s; return; }      // plain sums: no parametrizer in front of a bias
     const bool isg = idx < 128 * 128;
     const float p = isg ? gamma[idx] : beta[idx - 128 * 128], bound = isg ? gamma_bound : beta_bound;
     const float gr = s * 2.0f * fmaxf(p, bound);
@@ -224,13 +311,17 @@ __global__ __launch_bounds__(256) void gdn_bwd_reduce_kernel(const float* __rest
 }  // namespace
 
 extern "C" size_t masic_gdn_bwd_fused_workspace_bytes(void) {
-    return (size_t)2 * GB_IMG + 512 + (size_t)GB_NBLK * (128 * 128 + 128) * sizeof(float);
+    return (size_t)2 * GB_IMG + 512 + (size_t)GB_NBLK * GB_SLOT * sizeof(float);
 }
 
-extern "C" int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const float* gamma, float* gx,
-                                   float* g_beta, float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse,
-                                   double beta_min, void* stream) {
-    MASIC_REQUIRE(x && g && beta && gamma && gx && g_beta && g_gamma && workspace, MASIC_ERR_ARG, "gdn_bwd_fused: null pointer");
+// x / x_f16k, g / g_f16k: exactly one of each (float32 NCHW or F16K bf16 [B][8][HW][16]); gx / gx_f16k: at least one; g_sum [128] or
+// NULL: per-channel sums of dx over batch and pixels (the bias gradient of the convolution whose output the GDN normalises).
+extern "C" int masic_gdn_bwd_fused_ex(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
+                                      float* gx, void* gx_f16k, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
+                                      int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    MASIC_REQUIRE(((x != nullptr) != (x_f16k != nullptr)) && ((g != nullptr) != (g_f16k != nullptr)) && (gx || gx_f16k), MASIC_ERR_ARG,
+                  "gdn_bwd_fused: exactly one of x / x_f16k and of g / g_f16k, at least one of gx / gx_f16k");
+    MASIC_REQUIRE(beta && gamma && g_beta && g_gamma && workspace, MASIC_ERR_ARG, "gdn_bwd_fused: null pointer");
     MASIC_REQUIRE(C == 128, MASIC_ERR_UNSUPPORTED, "gdn_bwd_fused: C=%d (128 only; other widths use the unfused pieces)", C);
     MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W * 128 < (1ll << 31), MASIC_ERR_SHAPE, "gdn_bwd_fused: shape");
     hipStream_t st = (hipStream_t)stream;
@@ -241,19 +332,33 @@ extern "C" int masic_gdn_bwd_fused(const float* x, const float* g, const float* 
     hipLaunchKernelGGL(gdn_bwd_pack_kernel, dim3(16), dim3(256), 0, st, beta, gamma, img, beta_bound, gamma_bound, pedestal);
     GdnBwdArgs a{};
     a.x = x; a.g = g; a.gx = gx; a.img = img; a.part = part;
-    a.HW = H * W; a.npix = (long long)B * H * W; a.inverse = inverse;
+    a.x16 = (const unsigned short*)x_f16k; a.g16 = (const unsigned short*)g_f16k; a.gx16 = (unsigned short*)gx_f16k;
+    a.HW = H * W; a.npix = (long long)B * H * W; a.inverse = inverse; a.want_sum = g_sum != nullptr;
     a.ntiles = (int)((a.npix + 127) / 128);
     const int nblk = a.ntiles < GB_NBLK ? a.ntiles : GB_NBLK;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gdn_bwd_c128, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess) {
-            masic_set_error("gdn_bwd_fused: cannot reserve %d bytes of LDS", GB_LDS);
-            return MASIC_ERR_LAUNCH;
-        }
+        const void* fns[4] = {(const void*)gdn_bwd_c128<false, false>, (const void*)gdn_bwd_c128<true, false>, (const void*)gdn_bwd_c128<false, true>,
+                              (const void*)gdn_bwd_c128<true, true>};
+        for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess) {
+                masic_set_error("gdn_bwd_fused: cannot reserve %d bytes of LDS", GB_LDS);
+                return MASIC_ERR_LAUNCH;
+            }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gdn_bwd_c128, dim3(nblk), dim3(256), GB_LDS, st, a);
-    hipLaunchKernelGGL(gdn_bwd_reduce_kernel, dim3((128 * 128 + 128) / 32), dim3(256), 0, st, (const float*)part, nblk,
-                       beta, gamma, g_beta, g_gamma, beta_bound, gamma_bound);
+    if (x_f16k && g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
+    else if (x_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, false>), dim3(nblk), dim3(256), GB_LDS, st, a);
+    else if (g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<false, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
+    else hipLaunchKernelGGL((gdn_bwd_c128<false, false>), dim3(nblk), dim3(256), GB_LDS, st, a);
+    hipLaunchKernelGGL(gdn_bwd_reduce_kernel, dim3((128 * 128 + 128 + (g_sum ? 128 : 0)) / 32), dim3(256), 0, st, (const float*)part, nblk,
+                       beta, gamma, g_beta, g_gamma, g_sum, beta_bound, gamma_bound);
     return masic_launch_status("gdn_bwd_fused");
+}
+
+extern "C" int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const float* gamma, float* gx,
+                                   float* g_beta, float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse,
+                                   double beta_min, void* stream) {
+    MASIC_REQUIRE(x && g && gx, MASIC_ERR_ARG, "gdn_bwd_fused: null pointer");
+    return masic_gdn_bwd_fused_ex(x, nullptr, g, nullptr, beta, gamma, gx, nullptr, nullptr, g_beta, g_gamma, workspace, B, C, H, W, inverse, beta_min, stream);
 }

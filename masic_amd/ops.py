@@ -509,6 +509,36 @@ def gdn_bwd_fused(x, g, beta, gamma, inverse=False, beta_min=1e-6):
     return gx, g_beta, g_gamma
 
 
+def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, want_nchw=True, want_f16k=False, want_sum=True):
+    """gdn_bwd_fused with F16K operands (masic_gdn_bwd_fused_ex): x and g are float32 NCHW tensors or F16K int16 buffers of
+    shape = (B, 128, H, W); returns (dx float32 NCHW | None, dx F16K | None, channel sums of dx [128] | None, d beta, d gamma)."""
+    B, C, H, W = shape
+    for t, name in ((x, "x"), (g, "g")):
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError(f"masic_amd.gdn_bwd_fused_ex: {name} must be a contiguous device tensor")
+        if t.dtype == torch.int16:
+            if t.numel() != B * C * H * W:
+                raise RuntimeError(f"masic_amd.gdn_bwd_fused_ex: F16K buffer {name} does not hold {shape}")
+        elif t.dtype != torch.float32 or tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f"masic_amd.gdn_bwd_fused_ex: {name} must be float32 {shape} or an F16K int16 buffer")
+    if not (want_nchw or want_f16k):
+        raise RuntimeError("masic_amd.gdn_bwd_fused_ex: no output requested")
+    dev = x.device
+    ws = _GDN_BWD_WS.get(dev)
+    if ws is None:
+        ws = _GDN_BWD_WS[dev] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+    gx = torch.empty(shape, dtype=torch.float32, device=dev) if want_nchw else None
+    gx16 = torch.empty(B * C * H * W, dtype=torch.int16, device=dev) if want_f16k else None
+    g_sum = torch.empty(C, dtype=torch.float32, device=dev) if want_sum else None
+    g_beta = torch.empty(C, dtype=torch.float32, device=dev)
+    g_gamma = torch.empty(C, C, dtype=torch.float32, device=dev)
+    x16, g16 = x.dtype == torch.int16, g.dtype == torch.int16
+    check(lib.masic_gdn_bwd_fused_ex(_p(None if x16 else x), _p(x if x16 else None), _p(None if g16 else g), _p(g if g16 else None),
+                                     _p(_dev(beta.contiguous())), _p(_dev(gamma.contiguous())), _p(gx), _p(gx16), _p(g_sum), _p(g_beta), _p(g_gamma),
+                                     _p(ws), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_bwd_fused_ex")
+    return gx, gx16, g_sum, g_beta, g_gamma
+
+
 def conv2d_wgrad(x, dy, desc, weight_shape):
     _dev(x, "x"); _dev(dy, "dy")
     if tuple(dy.shape) != (desc.B, desc.Cout, desc.Ho, desc.Wo):

@@ -222,6 +222,34 @@ def test_gdn_backward_fused_bf16(B, H, W, inverse):
         assert float((got - ref).abs().max()) <= 3e-2 * peak, (name, "autograd", float((got - ref).abs().max()), peak)
 
 
+@pytest.mark.parametrize("B,H,W,inverse", [(2, 16, 32, False), (3, 5, 7, True), (1, 64, 64, False)])
+def test_gdn_backward_fused_f16k_operands(B, H, W, inverse):
+    """masic_gdn_bwd_fused_ex: x and / or g handed over as F16K bf16, dx also written as F16K, and the per-channel sums of dx (the
+    bias gradient of the convolution in front of the GDN) -- against masic_gdn_bwd_fused (pinned by the test above) on the same
+    bf16-representable values: the operands are identical then, so dx, d beta, d gamma must agree bit for bit for all four operand
+    combinations; the F16K dx is the bf16 rounding of the float32 dx; the sums equal a float64 channel sum of dx to float32 accuracy."""
+    from masic_amd import ops, synth
+    C = 128
+    rs = np.random.RandomState(7 * B + H)
+    beta = synth.synth_tensor("g.beta", (C,), rs).to(DEV)
+    gamma = synth.synth_tensor("g.gamma", (C, C), rs).to(DEV)
+    x = _rand(B, C, H, W, seed=20, scale=3.0).bfloat16().float().to(DEV)
+    go = _rand(B, C, H, W, seed=21).bfloat16().float().to(DEV)
+    gx0, gb0, gg0 = ops.gdn_bwd_fused(x, go, beta, gamma, inverse=inverse, beta_min=1e-6)
+    x16, g16 = ops.nchw_to_f16k(x), ops.nchw_to_f16k(go)
+    shape = (B, C, H, W)
+    for xa, ga in ((x16, go), (x, g16), (x16, g16), (x, go)):
+        gx, gx16, gs, gb, gg = ops.gdn_bwd_fused_ex(xa, ga, shape, beta, gamma, inverse=inverse, beta_min=1e-6, want_nchw=True, want_f16k=True, want_sum=True)
+        assert torch.equal(gx, gx0) and torch.equal(gb, gb0) and torch.equal(gg, gg0), (xa.dtype, ga.dtype)
+        assert torch.equal(ops.f16k_to_nchw_dev(gx16, B, C, H, W), gx0.bfloat16().float())
+        want = gx0.double().sum((0, 2, 3))
+        assert float((gs.double() - want).abs().max()) <= 1e-5 * float(gx0.abs().sum((0, 2, 3)).max()), "channel sums of dx"
+    gx, gx16, gs, gb, gg = ops.gdn_bwd_fused_ex(x16, g16, shape, beta, gamma, inverse=inverse, beta_min=1e-6, want_nchw=False, want_f16k=True, want_sum=False)
+    assert gx is None and gs is None and torch.equal(ops.f16k_to_nchw_dev(gx16, B, C, H, W), gx0.bfloat16().float()) and torch.equal(gg, gg0)
+    with pytest.raises(RuntimeError):
+        ops.gdn_bwd_fused_ex(x16, g16, shape, beta, gamma, want_nchw=False, want_f16k=False)
+
+
 def test_entropy_bottleneck_backward_and_aux():
     from compressai.entropy_models import EntropyBottleneck
     from masic_amd import synth

@@ -10,5 +10,6 @@ x1, x2, hm = (t.cuda() for t in synth.synth_inputs(8, 512, 512, seed=100))
 opt, aopt = make_optimizers(net)
 for _ in range(2): train_step(net, opt, aopt, x1, x2, hm, 0.01)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(3): train_step(net, opt, aopt, x1, x2, hm, 0.01)
-torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 3 * 1e3)
+n = int(os.environ.get("TRAIN_PROF_STEPS", "3"))
+for _ in range(n): train_step(net, opt, aopt, x1, x2, hm, 0.01)
+torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / n * 1e3)
