@@ -209,6 +209,15 @@ int masic_conv_f16k_gdn_dual_fwd(const void* x_f16k, const void* w_packed, const
                                  void* y_pre_f16k, void* y_f16k, const masic_conv_desc_t* d, void* stream);
 int masic_conv_a_gdn_dual_fwd(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse,
                               void* y_pre_f16k, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream);
+/* Training step, input gradients of the picture-end layers (newtrain_codec_real.py:141 `loss.backward()` through MASIC.py:515, :550):
+ * masic_conv_a_fwd -- Conv2d(3 -> 128, k5, s2, p2) alone (the first-layer kernel without its GDN) on a float32 NCHW channel view,
+ *   F16K out: the input gradient of g_s_conv4 = ConvTranspose2d(128 -> 3) (its weight tensor [128][3][5][5] is that convolution's);
+ * masic_deconv_s2_as_conv_weight -- ConvTranspose2d(Cin -> C <= 8, k5, s2, p2, op1) weight [Cin][C][5][5] (+ bias [C] or NULL) ->
+ *   weight [32][Cin][3][3] and bias [32] of the stride-1 convolution masic_conv_f16k_d2s_fwd runs; with a Conv2d(C -> Cin) weight
+ *   [Cin][C][5][5] passed as it is, that launch computes the convolution's input gradient (g_a_conv1). */
+int masic_conv_a_fwd(const float* x, const void* w_packed, const float* bias, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff,
+                     void* stream);
+int masic_deconv_s2_as_conv_weight(const float* w, const float* bias, float* w_out, float* bias_out, int Cin, int C, void* stream);
 /* weight gradient of Conv2d(Cin -> Cout, k3, s1, p1) with both operands in F16K (Cin, Cout multiples of 32): the 3x3 layers of
  * Independent_EN in the CQE training step (newtrain_cqe_real.py:128-174).  Pixel-major records become MFMA operands through the
  * hardware transpose read ds_read_b64_tr_b16 (masic_amd/csrc/wgrad_f16k.hip).  dw: float32 [Cout][Cin][3][3]; workspace:

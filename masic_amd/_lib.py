@@ -80,6 +80,8 @@ SIGNATURES = {
     "masic_conv_f16k_gdn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "masic_conv_f16k_gdn_dual_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv_a_gdn_dual_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_conv_a_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_deconv_s2_as_conv_weight": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "masic_conv3x3_wgrad_f16k_workspace_bytes": (c_size_t, [c_int, c_int]),
     "masic_conv3x3_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv_f16k_set_stamps": (None, [_P]),

@@ -62,6 +62,7 @@ class ConvFn(Function):
         return gx, gw, gb, None, None
 
 
+_PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
 
@@ -97,7 +98,22 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     if g16 is None or act != ops.ACT_NONE:
         g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k) else None  # dy in F16K, converted once for both gradients
 
+    pic_end = _PIC_END_DGRAD and bf16 and need_gx and act == ops.ACT_NONE and (kh, kw, s, p) == (5, 5, 2, 2)
+    # the two picture-end layers (MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128), :550 g_s_conv4 = ConvTranspose2d(128 -> 3)); without
+    # these forms their input gradients run on the float32 NCHW kernels (266 / 170 us per launch at 8 x 512 x 512)
+    dx_d2s = pic_end and not mod.transposed_conv and Cin <= 8 and Cout % 32 == 0 and g16 is not None
+    dx_conv_a = pic_end and mod.transposed_conv and (Cin, Cout) == (128, 3) and gx_f16k
+
     def input_gradient():
+        if dx_d2s:
+            # dx of Conv2d(C <= 8 -> Cout) = ConvTranspose2d(Cout -> C) on the same tensor: the depth-to-space form of inference
+            dd = ops.make_conv_desc(B, Cout, Ho, Wo, 32, 3, 3, 1, 1, prec=PREC_BF16)
+            if ops.conv_f16k_supported(dd) and (Hi, Wi) == (2 * Ho, 2 * Wo):
+                wc, bc = ops.deconv_s2_as_conv_weight_dev(weight.detach().contiguous())
+                return ops.conv2d_f16k_d2s(g16, ops.pack_conv_f16k_weight(wc, dd), bc, dd, Cin)
+        if dx_conv_a:
+            # dx of ConvTranspose2d(128 -> 3) = Conv2d(3 -> 128) with the same tensor: the first-layer kernel without its GDN, F16K out
+            return ops.conv_a_f16k(g, ops.pack_conv_a_weight(weight.detach().contiguous()))[0]
         if dx_gemm:
             # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
             wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
@@ -548,8 +564,8 @@ class AnalysisFn(Function):
             gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i])
             gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE,
                                                                                 g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
-        gu, _, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0], want_f16k=False)
-        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], gb=gsum)
+        gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0], want_f16k=ctx.needs_input_grad[0])
+        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], g16=gu16, gb=gsum)
         return (gimg, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
                 grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
 

@@ -860,7 +860,9 @@ __global__ void pack_conv_a_kernel(const float* __restrict__ w, uint4* __restric
     wimg[idx] = __builtin_bit_cast(uint4, v);
 }
 
-// X3: three-product GDN contraction; OUT: 0 F16K, 1 F8K (fp8), 2 F16K + the pre-GDN result (training).  Compile-time variants: with
+// X3: three-product GDN contraction; OUT: 0 F16K, 1 F8K (fp8), 2 F16K + the pre-GDN result (training), 3 F16K WITHOUT the GDN (the
+// plain Conv2d(3 -> 128, k5, s2): the input gradient of g_s_conv4 = ConvTranspose2d(128 -> 3), MASIC.py:550, in the training step --
+// no gamma^ image is loaded).  Compile-time variants: with
 // the choices as run-time branches both GDN forms were inlined and the kernel spilled 68 VGPRs in its tile loop (129 us per launch
 // at 8x512x512 against 80 for the round-1 kernel).
 template <bool X3, int OUT>
@@ -875,15 +877,17 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
     {
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, 20480, 0x00020000);
+        if constexpr (OUT != 3) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
+            for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (wave * 3 + k < 20) dma_buf16(rw, lds + WIMG + (wave * 3 + k) * 1024, lane * 16, (wave * 3 + k) * 1024);
         float* vec = reinterpret_cast<float*>(lds + VEC);
         if (tid < 128) {
             vec[tid] = a.bias != nullptr ? a.bias[tid] : 0.0f;
-            vec[128 + tid] = reinterpret_cast<const float*>(a.gdn_img + 4 * 8 * 2 * 64)[tid];
+            if constexpr (OUT != 3) vec[128 + tid] = reinterpret_cast<const float*>(a.gdn_img + 4 * 8 * 2 * 64)[tid];
         }
     }
     // ---- patch element map of this thread (tile independent): element = tid + 512 i -> (ci, row, col)
@@ -971,7 +975,9 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k(const ConvAArgs a) {
                 for (int m = 0; m < 4; ++m) store_f16k_tile(acc[m], yp + (size_t)(2 * m) * op16, op16);
             }
         }
-        if (CONVA_ABLATE != 1) gdn_in_registers<X3>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
+        if constexpr (OUT != 3) {
+            if (CONVA_ABLATE != 1) gdn_in_registers<X3>(acc, gimg, vec + 128 + 4 * h, a.gdn_inverse & 1);
+        }
         if (CONVA_ABLATE != 4) {
             const int b = tile / a.tiles_per_img, t = tile - b * a.tiles_per_img;
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
@@ -1252,6 +1258,28 @@ extern "C" int masic_conv_f16k_gdn_fwd(const void* x_f16k, const void* w_packed,
     return f16k_launch(x_f16k, w_packed, bias, gate, gdn_packed, gdn_inverse, 0, y_nchw, y_f16k, d, stream);
 }
 
+// ConvTranspose2d(Cin -> C, k5, s2, p2, output_padding 1) weight [Cin][C][5][5] -> the weight [32][Cin][3][3] (+ bias [32]) of the
+// equivalent stride-1 3x3 convolution to 4C (<= 32) channels whose 2x2 depth-to-space is the transposed convolution's output:
+// row 4c + 2ph + pw, tap (u, v) = W[:, c, ph + 2(2-u), pw + 2(2-v)], zero where that kernel index exceeds 4 (masic_amd/ops.py:
+// deconv_s2_as_conv_weight is the torch-op form the inference path caches; a training step changes the weight every iteration).
+namespace {
+__global__ void d2s_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wo, float* __restrict__ bo, int Cin, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 32) bo[idx] = (bias != nullptr && idx < 4 * C) ? bias[idx >> 2] : 0.0f;
+    if (idx >= 32 * Cin * 9) return;
+    const int v = idx % 3, u = (idx / 3) % 3, ci = (idx / 9) % Cin, row = idx / (9 * Cin);
+    const int c = row >> 2, ph = (row >> 1) & 1, pw = row & 1;
+    const int kh = ph + 2 * (2 - u), kw = pw + 2 * (2 - v);
+    wo[idx] = (c < C && kh <= 4 && kw <= 4) ? w[(((size_t)ci * C + c) * 5 + kh) * 5 + kw] : 0.0f;
+}
+}  // namespace
+extern "C" int masic_deconv_s2_as_conv_weight(const float* w, const float* bias, float* w_out, float* bias_out, int Cin, int C, void* stream) {
+    MASIC_REQUIRE(w && w_out && bias_out && Cin > 0 && C > 0 && 4 * C <= 32, MASIC_ERR_ARG, "deconv_s2_as_conv_weight: null pointer or more than 8 output channels");
+    const int total = 32 * Cin * 9;
+    hipLaunchKernelGGL(d2s_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w_out, bias_out, Cin, C);
+    return masic_launch_status("deconv_s2_as_conv_weight");
+}
+
 // A stride-2 transposed convolution to few channels (g_s_conv4: 128 -> 3, MASIC.py:550, :598) run as its equivalent
 // stride-1 3x3 convolution to (4 phases x C) channels with a depth-to-space store: `d` describes that equivalent
 // Conv2d (Cout = 32, weights re-laid out by the caller), y_nchw is [B][out_ctot][2 Ho][2 Wo], channels out_coff..out_coff+C-1.
@@ -1398,10 +1426,17 @@ extern "C" int masic_conv_a_gdn_fwd_ex(const float* x, const void* w_packed, con
                                        void* y_f16k, void* y_f8k, float out_inv_scale, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
     return conv_a_launch(x, w_packed, bias, gdn_packed, gdn_inverse, y_f16k, y_f8k, out_inv_scale, nullptr, B, Hi, Wi, in_ctot, in_coff, stream);
 }
+// the convolution alone (no GDN), F16K out: Conv2d(3 -> 128, k5, s2, p2) on a float32 NCHW channel view
+extern "C" int masic_conv_a_fwd(const float* x, const void* w_packed, const float* bias, void* y_f16k, int B, int Hi, int Wi, int in_ctot, int in_coff,
+                                void* stream) {
+    MASIC_REQUIRE(y_f16k != nullptr, MASIC_ERR_ARG, "conv_a_fwd: null pointer");
+    return conv_a_launch(x, w_packed, bias, nullptr, 0, y_f16k, nullptr, 0.0f, nullptr, B, Hi, Wi, in_ctot, in_coff, stream);
+}
 namespace {
 int conv_a_launch(const float* x, const void* w_packed, const float* bias, const void* gdn_packed, int gdn_inverse, void* y_f16k, void* y_f8k,
                   float out_inv_scale, void* y_pre, int B, int Hi, int Wi, int in_ctot, int in_coff, void* stream) {
-    MASIC_REQUIRE(x && w_packed && gdn_packed && ((y_f16k != nullptr) != (y_f8k != nullptr)), MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer / exactly one output");
+    MASIC_REQUIRE(x && w_packed && ((y_f16k != nullptr) != (y_f8k != nullptr)), MASIC_ERR_ARG, "conv_a_gdn_fwd: null pointer / exactly one output");
+    MASIC_REQUIRE(gdn_packed != nullptr || (y_f16k != nullptr && y_pre == nullptr), MASIC_ERR_ARG, "conv_a_fwd: without a GDN the output is one F16K tensor");
     MASIC_REQUIRE(y_f8k == nullptr || out_inv_scale > 0.0f, MASIC_ERR_ARG, "conv_a_gdn_fwd: an fp8 output needs out_inv_scale > 0");
     MASIC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && in_coff >= 0 && in_coff + 3 <= in_ctot, MASIC_ERR_SHAPE, "conv_a_gdn_fwd: bad shape");
     const int Ho = (Hi + 4 - 5) / 2 + 1, Wo = (Wi + 4 - 5) / 2 + 1;
@@ -1422,7 +1457,8 @@ int conv_a_launch(const float* x, const void* w_packed, const float* bias, const
     } while (0)
     const bool x3 = (gdn_inverse & 2) != 0;
     const int out = y_f8k != nullptr ? 1 : (y_pre != nullptr ? 2 : 0);
-    if (x3) { if (out == 0) CONV_A_LAUNCH(true, 0); else if (out == 1) CONV_A_LAUNCH(true, 1); else CONV_A_LAUNCH(true, 2); }
+    if (gdn_packed == nullptr) CONV_A_LAUNCH(false, 3);
+    else if (x3) { if (out == 0) CONV_A_LAUNCH(true, 0); else if (out == 1) CONV_A_LAUNCH(true, 1); else CONV_A_LAUNCH(true, 2); }
     else { if (out == 0) CONV_A_LAUNCH(false, 0); else if (out == 1) CONV_A_LAUNCH(false, 1); else CONV_A_LAUNCH(false, 2); }
 #undef CONV_A_LAUNCH
     return masic_launch_status("conv_a_gdn_fwd");

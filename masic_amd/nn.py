@@ -216,7 +216,7 @@ class _PackedWeightMixin:
         w = self.weight
 
         def build():
-            wc, bc = ops.deconv_s2_as_conv_weight(w.detach(), None if self.bias is None else self.bias.detach())
+            wc, bc = ops.deconv_s2_as_conv_weight_dev(w.detach().contiguous(), None if self.bias is None else self.bias.detach())
             return ops.pack_conv_f16k_weight(wc, desc), bc
         wp, bc = _cached(self, "_packed_d2s_cache", (w._version, w.data_ptr(), str(w.device), None if self.bias is None else self.bias._version),
                          (B, Hi, Wi), build)

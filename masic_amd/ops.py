@@ -1129,6 +1129,28 @@ def conv_a_gdn_dual(x, packed, bias, gdn, in_coff=0, products=3):
     return pre, y, Ho, Wo
 
 
+def conv_a_f16k(x, packed, bias=None, in_coff=0):
+    """Conv2d(3 -> 128, k5, s2, p2) on channels in_coff.. of a float32 NCHW tensor, no GDN -> (F16K, Ho, Wo) (masic_conv_a_fwd)."""
+    _dev(x, "x")
+    B, ctot, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B * 128 * Ho * Wo, dtype=torch.int16, device=x.device)
+    check(lib.masic_conv_a_fwd(_p(x), _p(packed), _p(bias), _p(y), B, H, W, ctot, in_coff, _stream()), "conv_a_fwd")
+    return y, Ho, Wo
+
+
+def deconv_s2_as_conv_weight_dev(weight, bias=None):
+    """deconv_s2_as_conv_weight in one launch (masic_deconv_s2_as_conv_weight): weight [Cin, C <= 8, 5, 5] -> ([32, Cin, 3, 3], [32])."""
+    _dev(weight, "weight")
+    Cin, C, KH, KW = weight.shape
+    if (KH, KW) != (5, 5) or 4 * C > 32 or not weight.is_contiguous():
+        raise RuntimeError("masic_amd.deconv_s2_as_conv_weight_dev: needs a contiguous 5x5 kernel and at most 8 output channels")
+    w = torch.empty((32, Cin, 3, 3), dtype=torch.float32, device=weight.device)
+    b = torch.empty(32, dtype=torch.float32, device=weight.device)
+    check(lib.masic_deconv_s2_as_conv_weight(_p(weight), _p(bias), _p(w), _p(b), Cin, C, _stream()), "deconv_s2_as_conv_weight")
+    return w, b
+
+
 def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     """dW [Cout, Cin, 3, 3] (float32) of Conv2d(k3, s1, p1) from x and dy in F16K (bf16 operands, float32 accumulate)."""
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:

@@ -250,6 +250,39 @@ def test_gdn_backward_fused_f16k_operands(B, H, W, inverse):
         ops.gdn_bwd_fused_ex(x16, g16, shape, beta, gamma, want_nchw=False, want_f16k=False)
 
 
+def test_picture_end_input_gradients_f16k_forms():
+    """bf16 mode, input gradients of the two picture-end layers (reference MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128, k5, s2), :550
+    g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)) on the F16K kernels -- the depth-to-space transposed convolution and the
+    first-layer kernel without its GDN -- against torch's float32 operators on the bf16-rounded operands the kernels see."""
+    from compressai.models.utils import conv, deconv
+    from masic_amd import autograd as ag, nn as mnn, ops
+    q = lambda t: t.bfloat16().float()
+    B, H, W = 2, 48, 80
+    mnn.set_precision("bf16")
+    try:
+        ca = conv(3, 128).to(DEV)                                   # dx = ConvTranspose2d(128 -> 3)(dy)
+        x = _rand(B, 3, H, W, seed=1).to(DEV)
+        dy = _rand(B, 128, H // 2, W // 2, seed=2)
+        want = F.conv_transpose2d(q(dy), q(ca.weight.detach().cpu()), None, stride=2, padding=2, output_padding=1)
+        gx, gw, gb = ag.conv_backward(ca, x, ca.weight, None, dy.to(DEV), ops.ACT_NONE, need_gw=False, need_gb=False, g16=ops.nchw_to_f16k(dy.to(DEV)))
+        assert gx.dtype == torch.float32 and gw is None and gb is None
+        assert_close(gx, want, "dx of Conv2d(3->128) (depth-to-space form)", 2e-3)
+        dt = deconv(128, 3).to(DEV)                                 # dx = Conv2d(3 -> 128)(dy)
+        xin = _rand(B, 128, H // 2, W // 2, seed=3).to(DEV)
+        dy = _rand(B, 3, H, W, seed=4)
+        want = F.conv2d(q(dy), q(dt.weight.detach().cpu()), None, stride=2, padding=2)
+        gx, _, _ = ag.conv_backward(dt, xin, dt.weight, None, dy.to(DEV), ops.ACT_NONE, need_gw=False, need_gb=False, gx_f16k=True)
+        assert gx.dtype == torch.int16
+        assert_close(ops.f16k_to_nchw_dev(gx, B, 128, H // 2, W // 2), want, "dx of ConvTranspose2d(128->3) (first-layer kernel, no GDN)", 2 ** -8)
+    finally:
+        mnn.set_precision("f32")
+    # the one-launch weight relayout equals the torch-op form
+    w, b = _rand(128, 3, 5, 5, seed=5).to(DEV), _rand(3, seed=6).to(DEV)
+    w1, b1 = ops.deconv_s2_as_conv_weight(w, b)
+    w2, b2 = ops.deconv_s2_as_conv_weight_dev(w, b)
+    assert torch.equal(w1, w2) and torch.equal(b1, b2)
+
+
 def test_entropy_bottleneck_backward_and_aux():
     from compressai.entropy_models import EntropyBottleneck
     from masic_amd import synth
