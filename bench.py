@@ -144,7 +144,7 @@ def oracle_reference_sample(N, M, K, H, W, seed):
         ref = O.hsic_forward(sd, x1, x2, hm, K=K, keep=True)
     crit = O.rd_loss(ref, x1, x2, 0.01)
     return {"inputs": (x1, x2, hm), "sym": O.symbols(ref["_aux"], sd), "x1_hat": ref["x1_hat"], "x2_hat": ref["x2_hat"],
-            "bpp": float(crit["bpp_loss"]), "psnr1": crit["psnr1"], "psnr2": crit["psnr2"]}
+            "bpp": float(crit["bpp_loss"]), "psnr1": float(crit["psnr1"]), "psnr2": float(crit["psnr2"])}
 
 
 # ------------------------------------------------------------------------------------------------ HBM traffic (PMC child passes)

@@ -657,7 +657,11 @@ class HSIC(CompressionModel):
         x1 = x1.contiguous()
         x2 = x2.contiguous()
         B, _, H, W = x1.shape
-        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        # reduced-precision training: the sampling matrices from the float64 device kernel -- the host evaluation of the reference's
+        # float32 chain (bit-compatible, the float32 parity path keeps it) costs a device -> host copy that makes the host wait for
+        # the previous step's last kernel before it may launch this step's first
+        from masic_amd import nn as _mnn
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True, device=_mnn.reduced_precision())
         y1 = self.encoder1.latent_train(x1)
         z1 = self._h_a1(y1)
         z1_hat, z1_lik = self.entropy_bottleneck1(z1)                                   # draw 1

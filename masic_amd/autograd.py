@@ -224,7 +224,8 @@ class AuxLossFn(Function):
     @staticmethod
     def backward(ctx, g):
         q, table = ctx.saved_tensors
-        return ops.entropy_bottleneck_auxloss_bwd(table, q.detach(), float(g), ctx.tail_mass), None, None
+        # the incoming gradient stays on the device (float(g) would make the host wait for the stream in the middle of every step)
+        return ops.entropy_bottleneck_auxloss_bwd(table, q.detach(), 1.0, ctx.tail_mass) * g, None, None
 
 
 class GmmFn(Function):
@@ -498,10 +499,11 @@ class RateDistortionFn(Function):
     @staticmethod
     def backward(ctx, g):
         x1, x2, x1_hat, x2_hat, *liks = ctx.saved_tensors
-        gs = float(g)
-        g1 = ops.elementwise(ops.EW_DIFF_SCALE, x1_hat, x1, s0=gs * ctx.cm * 2.0 / x1.numel())
-        g2 = ops.elementwise(ops.EW_DIFF_SCALE, x2_hat, x2, s0=gs * ctx.cm * 2.0 / x2.numel())
-        gl = [ops.elementwise(ops.EW_RECIP_SCALE, l, None, s0=gs * ctx.cb) for l in liks]
+        # g (a device scalar, 1 for `loss.backward()`) multiplies on the device: float(g) here would make the host wait for the whole
+        # forward before it may launch the first kernel of the backward
+        g1 = ops.elementwise(ops.EW_DIFF_SCALE, x1_hat, x1, s0=ctx.cm * 2.0 / x1.numel()).mul_(g)
+        g2 = ops.elementwise(ops.EW_DIFF_SCALE, x2_hat, x2, s0=ctx.cm * 2.0 / x2.numel()).mul_(g)
+        gl = [ops.elementwise(ops.EW_RECIP_SCALE, l, None, s0=ctx.cb).mul_(g) for l in liks]
         return (None, None, None, g1, g2, *gl)
 
 

@@ -26,10 +26,11 @@ def _normal_transform_pixel(h, w):
     return t.unsqueeze(0)
 
 
-def warp_matrices(h_matrix, src_hw, dst_hw, want_inverse=False):
+def warp_matrices(h_matrix, src_hw, dst_hw, want_inverse=False, device=False):
     """Returns the normalised sampling matrix for warp(., h_matrix) and, if asked, for
-    warp(., inverse(h_matrix)) (the second warp of MASIC.py:644), as [B,3,3] float32 device tensors."""
-    if os.environ.get("MASIC_WARP_MATRIX", "host") == "device":
+    warp(., inverse(h_matrix)) (the second warp of MASIC.py:644), as [B,3,3] float32 device tensors.
+    device=True: the float64 device kernel (no host round trip, hence no stream synchronisation in front of the forward)."""
+    if device or os.environ.get("MASIC_WARP_MATRIX", "host") == "device":
         fwd = ops.warp_matrix(h_matrix.contiguous(), src_hw, dst_hw)
         back = ops.warp_matrix(h_matrix.contiguous(), src_hw, dst_hw, invert_first=True) if want_inverse else None
         return fwd, back

@@ -21,6 +21,46 @@ class RateDistortionLoss:
         return rate_distortion(output, target1, target2, self.lmbda)
 
 
+class LazyPSNR:
+    """mse2psnr(mse) = 10 log10(1 / mse) (newtrain_codec_real.py:62-65) of a device scalar, as a float-like value that is read back --
+    and makes the host wait for the stream -- when it is first USED (formatted, compared, added to a meter), not when the criterion
+    returns: the reference's `math.log10(1 / mse)` on a device tensor stalls the host once per step right after the forward, and the
+    device then idles until the host has caught up with the backward's launches."""
+    __slots__ = ("_mse", "_v")
+
+    def __init__(self, mse):
+        self._mse, self._v = mse, None
+
+    def __float__(self):
+        if self._v is None:
+            self._v = 10 * math.log10(1 / float(self._mse))
+            self._mse = None
+        return self._v
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __add__(self, o): return float(self) + o
+    def __radd__(self, o): return o + float(self)
+    def __sub__(self, o): return float(self) - o
+    def __rsub__(self, o): return o - float(self)
+    def __mul__(self, o): return float(self) * o
+    def __rmul__(self, o): return o * float(self)
+    def __truediv__(self, o): return float(self) / o
+    def __rtruediv__(self, o): return o / float(self)
+    def __neg__(self): return -float(self)
+    def __abs__(self): return abs(float(self))
+    def __lt__(self, o): return float(self) < o
+    def __le__(self, o): return float(self) <= o
+    def __gt__(self, o): return float(self) > o
+    def __ge__(self, o): return float(self) >= o
+    def __eq__(self, o): return float(self) == o
+    def __hash__(self): return hash(float(self))
+
+
 def rate_distortion(output, target1, target2, lmbda):
     import torch
     liks = output["likelihoods"]
@@ -41,8 +81,8 @@ def rate_distortion(output, target1, target2, lmbda):
     out = {"bpp_loss": bpp.float(), "mse_loss": mse.float(), "loss": (lmbda * 255 ** 2 * mse + bpp).float(),
            "mse1": mse1, "mse2": mse2}
     out.update({"bpp_" + k: v for k, v in per.items()})
-    out["psnr1"] = 10 * math.log10(1 / float(mse1))
-    out["psnr2"] = 10 * math.log10(1 / float(mse2))
+    out["psnr1"] = LazyPSNR(mse1)
+    out["psnr2"] = LazyPSNR(mse2)
     return out
 
 
@@ -61,4 +101,4 @@ def distortion(output, target1, target2, lmbda):
     else:
         loss = (lmbda * 255 ** 2 * mse).float()
     return {"mse_loss": mse.float(), "loss": loss, "mse1": mse1, "mse2": mse2,
-            "psnr1": 10 * math.log10(1 / float(mse1)), "psnr2": 10 * math.log10(1 / float(mse2))}
+            "psnr1": LazyPSNR(mse1), "psnr2": LazyPSNR(mse2)}
