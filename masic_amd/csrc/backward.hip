@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 constexpr int CS_SPLIT = 64;
 
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, double* __restrict__ partial,
-                                                          int B, int C, int HW, int ctot, int coff) {
+                                                          int B, int C, int HW, int ctot, int coff, float* __restrict__ out_direct) {
     __shared__ double red[256];
     const int c = blockIdx.x, sp = blockIdx.y;
     // chunks of 4096 pixels (16-byte loads: 4 per thread), dealt round-robin over (b, chunk) pairs to the CS_SPLIT blocks of this
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
     const int chunks = (HW + 4095) / 4096;
     const bool vec = (HW & 3) == 0;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    for (int w = sp; w < B * chunks; w += CS_SPLIT) {
+    for (int w = sp; w < B * chunks; w += (int)gridDim.y) {
         const int b = w / chunks, ck = w - b * chunks;
         const float* p = x + ((size_t)b * ctot + coff + c) * HW;
         const int lo = ck * 4096, hi = lo + 4096 < HW ? lo + 4096 : HW;
@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[(size_t)c * CS_SPLIT + sp] = red[0];
+    if (threadIdx.x == 0) {
+        if (out_direct != nullptr) out_direct[c] = (float)red[0];      // one block per channel (gridDim.y == 1): no second stage
+        else partial[(size_t)c * CS_SPLIT + sp] = red[0];
+    }
 }
 
 __global__ __launch_bounds__(64) void channel_sum_stage2(const double* __restrict__ partial, float* __restrict__ out, int C) {
@@ -453,7 +456,13 @@ extern "C" size_t masic_channel_sum_workspace_bytes(int C) { return (size_t)C * 
 extern "C" int masic_channel_sum(const float* x, float* out, void* workspace, int B, int C, int HW, int ctot, int coff, void* stream) {
     MASIC_REQUIRE(x && out && workspace, MASIC_ERR_ARG, "channel_sum: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "channel_sum: view out of range");
-    hipLaunchKernelGGL(channel_sum_stage1, dim3(C, CS_SPLIT), dim3(256), 0, (hipStream_t)stream, x, (double*)workspace, B, C, HW, ctot, coff);
+    // latent-resolution tensors of many channels (the 1x1 layers of the entropy-parameter stacks: 8 x 32 x 32 pixels, <= 1152 channels):
+    // one block per channel already fills the chip and a second launch would cost more than the sum itself
+    if ((long)B * HW <= 16384 && C >= 128) {
+        hipLaunchKernelGGL(channel_sum_stage1, dim3(C, 1), dim3(256), 0, (hipStream_t)stream, x, (double*)workspace, B, C, HW, ctot, coff, out);
+        return masic_launch_status("channel_sum");
+    }
+    hipLaunchKernelGGL(channel_sum_stage1, dim3(C, CS_SPLIT), dim3(256), 0, (hipStream_t)stream, x, (double*)workspace, B, C, HW, ctot, coff, (float*)nullptr);
     hipLaunchKernelGGL(channel_sum_stage2, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, out, C);
     return masic_launch_status("channel_sum");
 }

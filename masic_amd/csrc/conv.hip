@@ -140,21 +140,22 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
 // ------------------------------------------------------------------------------------------ pack
 
 __global__ void pack_weight_kernel(const PackArgs a) {
+    const ConvGeom g = a.gs[blockIdx.y];
     const size_t per_tap = (size_t)a.Cin_pad * a.Cout_pad;
-    const size_t total = (size_t)a.g.ntaps * per_tap;
+    const size_t total = (size_t)g.ntaps * per_tap;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int t = (int)(i / per_tap);
         const int rem = (int)(i - (size_t)t * per_tap);
         const int ci = rem / a.Cout_pad, co = rem - ci * a.Cout_pad;
         float v = 0.0f;
         if (ci < a.Cin && co < a.Cout) {
-            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
-            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const int ta = t / g.ntw, tb = t - ta * g.ntw;
+            const int kh = g.kh0 + ta * g.khs, kw = g.kw0 + tb * g.kws;
             const size_t src = a.transposed ? (((size_t)ci * a.Cout + co) * a.KH + kh) * a.KW + kw
                                             : (((size_t)co * a.Cin + ci) * a.KH + kh) * a.KW + kw;
             v = a.w[src];
         }
-        a.wp[(size_t)a.g.tap_base * per_tap + i] = v;
+        a.wp[(size_t)g.tap_base * per_tap + i] = v;
     }
 }
 
@@ -977,20 +978,17 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
                            w, (float*)w_packed, d->Cin, d->Cout, d->transposed);
         return masic_launch_status("conv_pack_weight");
     }
+    PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, {}};
+    int max_taps = 0;
     for (int p = 0; p < np; ++p) {
-        PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, g[p]};
-        if (c.bf16) {
-            const size_t tot = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
-            int nb = (int)((tot + 255) / 256);
-            if (nb > 4096) nb = 4096;
-            hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
-            continue;
-        }
-        const size_t total = (size_t)g[p].ntaps * c.Cin_pad * c.Cout_pad;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        a.gs[p] = g[p];
+        max_taps = max_taps > g[p].ntaps ? max_taps : g[p].ntaps;
     }
+    const size_t total = (size_t)max_taps * c.Cin_pad * c.Cout_pad;           // the largest phase sizes the grid (grid-stride loops)
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (c.bf16) hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks, np), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+    else hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks, np), dim3(256), 0, (hipStream_t)stream, a);
     return masic_launch_status("conv_pack_weight");
 }
 

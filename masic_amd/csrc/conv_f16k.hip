@@ -229,12 +229,14 @@ struct PackStreamArgs {
     const float* w;
     int Cin, Cout, KH, KW, transposed;
     int KS, T, nchunks, ncb;
-    ConvGeom g;
-    unsigned phase_off;       // bytes
+    ConvGeom gs[4];           // one launch packs every phase (blockIdx.y)
+    unsigned phase_offs[4];   // bytes
 };
 
 __global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* __restrict__ wp) {
-    const int spc = (a.g.ntaps + a.T - 1) / a.T;
+    const ConvGeom g = a.gs[blockIdx.y];
+    const unsigned phase_off = a.phase_offs[blockIdx.y];
+    const int spc = (g.ntaps + a.T - 1) / a.T;
     const size_t total = (size_t)a.ncb * a.nchunks * spc * a.T * a.KS * 2048;        // bf16 elements
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
@@ -249,15 +251,15 @@ __global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* 
         const int tap = t * a.T + tt;
         const int ci = (c * a.KS + ks) * 16 + hh * 8 + e, cog = cb * 128 + co;
         float v = 0.0f;
-        if (tap < a.g.ntaps && ci < a.Cin && cog < a.Cout) {
-            const int ta = tap / a.g.ntw, tb = tap - ta * a.g.ntw;
-            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+        if (tap < g.ntaps && ci < a.Cin && cog < a.Cout) {
+            const int ta = tap / g.ntw, tb = tap - ta * g.ntw;
+            const int kh = g.kh0 + ta * g.khs, kw = g.kw0 + tb * g.kws;
             const size_t src = a.transposed ? (((size_t)ci * a.Cout + cog) * a.KH + kh) * a.KW + kw
                                             : (((size_t)cog * a.Cin + ci) * a.KH + kh) * a.KW + kw;
             v = a.w[src];
         }
         const __bf16 bv = (__bf16)v;
-        wp[(a.phase_off >> 1) + i] = __builtin_bit_cast(unsigned short, bv);
+        wp[(phase_off >> 1) + i] = __builtin_bit_cast(unsigned short, bv);
     }
 }
 
@@ -281,7 +283,9 @@ __global__ void wscale_f8k_kernel(const float* __restrict__ w, float* __restrict
 }
 
 __global__ void pack_f8k_stream_kernel(const PackStreamArgs a, const float* __restrict__ ws, unsigned char* __restrict__ wp) {
-    const int spc = (a.g.ntaps + a.T - 1) / a.T;
+    const ConvGeom g = a.gs[blockIdx.y];
+    const unsigned phase_off = a.phase_offs[blockIdx.y];
+    const int spc = (g.ntaps + a.T - 1) / a.T;
     const size_t total = (size_t)a.ncb * a.nchunks * spc * a.T * a.KS * 4096;        // fp8 elements = bytes
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
@@ -296,14 +300,14 @@ __global__ void pack_f8k_stream_kernel(const PackStreamArgs a, const float* __re
         const int tap = t * a.T + tt;
         const int ci = (c * a.KS + ks) * 32 + hh * 16 + e, cog = cb * 128 + co;
         float v = 0.0f;
-        if (tap < a.g.ntaps && ci < a.Cin && cog < a.Cout) {
-            const int ta = tap / a.g.ntw, tb = tap - ta * a.g.ntw;
-            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+        if (tap < g.ntaps && ci < a.Cin && cog < a.Cout) {
+            const int ta = tap / g.ntw, tb = tap - ta * g.ntw;
+            const int kh = g.kh0 + ta * g.khs, kw = g.kw0 + tb * g.kws;
             const size_t src = a.transposed ? (((size_t)ci * a.Cout + cog) * a.KH + kh) * a.KW + kw
                                             : (((size_t)cog * a.Cin + ci) * a.KH + kh) * a.KW + kw;
             v = a.w[src] / ws[cog];
         }
-        wp[a.phase_off + i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff);
+        wp[phase_off + i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff);
     }
 }
 
@@ -1145,13 +1149,17 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
+    PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, {}, {}};
+    size_t tot = 0;
     for (int p = 0; p < np; ++p) {
-        PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, g[p], c.phase_off[p]};
-        const size_t tot = (size_t)c.stream_bytes[p] / 2 * c.ncb;
-        int nb = (int)((tot + 255) / 256);
-        if (nb > 8192) nb = 8192;
-        hipLaunchKernelGGL(pack_f16k_stream_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+        a.gs[p] = g[p];
+        a.phase_offs[p] = c.phase_off[p];
+        const size_t t = (size_t)c.stream_bytes[p] / 2 * c.ncb;
+        tot = tot > t ? tot : t;
     }
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_f16k_stream_kernel, dim3(nb, np), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
     return masic_launch_status("conv_f16k_pack_weight");
 }
 
@@ -1233,13 +1241,17 @@ extern "C" int masic_conv_f8k_pack_weight(const float* w, void* w_packed, float*
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f8k: layer shape has no fp8 configuration");
     hipLaunchKernelGGL(wscale_f8k_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, w, wscale, d->Cin, d->Cout, d->KH * d->KW, d->transposed);
+    PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, {}, {}};
+    size_t tot = 0;
     for (int p = 0; p < np; ++p) {
-        PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, g[p], c.phase_off[p]};
-        const size_t tot = (size_t)c.stream_bytes[p] * c.ncb;
-        int nb = (int)((tot + 255) / 256);
-        if (nb > 8192) nb = 8192;
-        hipLaunchKernelGGL(pack_f8k_stream_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (const float*)wscale, (unsigned char*)w_packed);
+        a.gs[p] = g[p];
+        a.phase_offs[p] = c.phase_off[p];
+        const size_t t = (size_t)c.stream_bytes[p] * c.ncb;
+        tot = tot > t ? tot : t;
     }
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_f8k_stream_kernel, dim3(nb, np), dim3(256), 0, (hipStream_t)stream, a, (const float*)wscale, (unsigned char*)w_packed);
     return masic_launch_status("conv_f8k_pack_weight");
 }
 

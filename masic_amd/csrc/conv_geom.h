@@ -79,13 +79,14 @@ int build_geoms(const masic_conv_desc_t& d, ConvGeom* g) {
 struct PackArgs {
     const float* w; float* wp;
     int Cin, Cout, KH, KW, Cin_pad, Cout_pad, transposed;
-    ConvGeom g;
+    ConvGeom gs[4];           // one launch packs every phase: blockIdx.y = phase (a training step re-packs every weight every iteration)
 };
 
 // packed bf16 weights: [phase-tap][ci/16][co (padded to BM)][16 ci]
 __global__ void pack_weight_bf16_kernel(const PackArgs a, unsigned short* __restrict__ wp) {
+    const ConvGeom g = a.gs[blockIdx.y];
     const size_t per_tap = (size_t)a.Cin_pad * a.Cout_pad;
-    const size_t total = (size_t)a.g.ntaps * per_tap;
+    const size_t total = (size_t)g.ntaps * per_tap;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int t = (int)(i / per_tap);
         const size_t rem = i - (size_t)t * per_tap;
@@ -94,14 +95,14 @@ __global__ void pack_weight_bf16_kernel(const PackArgs a, unsigned short* __rest
         const int co = rem2 >> 4, ci = c16 * 16 + (rem2 & 15);
         float v = 0.0f;
         if (ci < a.Cin && co < a.Cout) {
-            const int ta = t / a.g.ntw, tb = t - ta * a.g.ntw;
-            const int kh = a.g.kh0 + ta * a.g.khs, kw = a.g.kw0 + tb * a.g.kws;
+            const int ta = t / g.ntw, tb = t - ta * g.ntw;
+            const int kh = g.kh0 + ta * g.khs, kw = g.kw0 + tb * g.kws;
             const size_t src = a.transposed ? (((size_t)ci * a.Cout + co) * a.KH + kh) * a.KW + kw
                                             : (((size_t)co * a.Cin + ci) * a.KH + kh) * a.KW + kw;
             v = a.w[src];
         }
         const __bf16 bv = (__bf16)v;
-        wp[(size_t)a.g.tap_base * per_tap + i] = __builtin_bit_cast(unsigned short, bv);
+        wp[(size_t)g.tap_base * per_tap + i] = __builtin_bit_cast(unsigned short, bv);
     }
 }
 
