@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 extern "C" int masic_elementwise(const float* a, const float* b, float* y, size_t n, int op, float s0, float s1, void* stream) {
     MASIC_REQUIRE(a && y, MASIC_ERR_ARG, "elementwise: null pointer");
     MASIC_REQUIRE(op >= 0 && op <= EW_ADD, MASIC_ERR_ARG, "elementwise: op %d", op);
+    const bool binary = op == EW_ACT_BWD || op == EW_ABS_BWD || op == EW_DIFF_SCALE || op == EW_MUL || op == EW_REPARAM_BWD || op == EW_ADD;
+    MASIC_REQUIRE(!binary || b != nullptr, MASIC_ERR_ARG, "elementwise: op %d needs a second operand", op);
     hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, op, s0, s1);
     return masic_launch_status("elementwise");
 }

@@ -573,6 +573,15 @@ def test_gemm_f16k_group_equals_single_layer_calls(B, H, W, f8):
             ops.gemm_f16k_group([dict(layers[0], Cout=1000)], B, H, W)              # Cout % 32
 
 
+def test_elementwise_binary_op_without_second_operand_is_an_error_not_a_fault():
+    from masic_amd import _lib, ops
+    x = torch.ones(64, device=DEV)
+    y = torch.empty_like(x)
+    for op in (ops.EW_ACT_BWD, ops.EW_MUL, ops.EW_ADD, ops.EW_DIFF_SCALE):
+        assert _lib.lib.masic_elementwise(ops._p(x), None, ops._p(y), 64, int(op), 0.0, 0.0, ops._stream()) != 0
+    assert _lib.lib.masic_elementwise(ops._p(x), None, ops._p(y), 64, int(ops.EW_SQUARE), 0.0, 0.0, ops._stream()) == 0
+
+
 def test_homography_from_corners_vs_restatement():
     """corner offsets -> h_matrix (get_perspective_transform + inverse + h_adjust) in one kernel against the
     float64 restatement (oracle/udh_oracle.py; kornia absent: parity unpinned), plus the defining property: before h_adjust
