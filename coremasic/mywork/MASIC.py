@@ -1111,7 +1111,8 @@ class Independent_EN(nn.Module):
         x1_hat = x1_hat.contiguous()
         x2_hat = x2_hat.contiguous()
         B, _, H, W = x1_hat.shape
-        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
+        from masic_amd import nn as _mnn     # reduced-precision training: device kernel, no host round trip (see HSIC._forward_graph)
+        m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True, device=_mnn.reduced_precision())
         mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
         mask_L = _hip.warp_perspective(mask_R, m_back, (H, W))
         w_R = self.mask2weights_unit(mask_R)
