@@ -318,12 +318,15 @@ def main():
         step = net if args.no_graph else GraphedHSIC(net, x1, x2, hm)
         # the batch is resident in HBM in the graph's own input buffers (where an uploader / decoder would put it): no copy per step
         xa, xb = (x1, x2) if args.no_graph else step.inputs
+        # the homography of the next batch is handed over with the current one (a loader one batch ahead): its device -> host read,
+        # the host-side float32 chain and the upload of the sampling matrices run under the current replay; every step still does all of it
+        ahead = {} if args.no_graph else {"next_h_matrix": hm}
         for _ in range(args.warmup):
-            step(xa, xb, hm)
+            step(xa, xb, hm, **ahead)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step(xa, xb, hm)
+            out = step(xa, xb, hm, **ahead)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
 
@@ -467,11 +470,11 @@ def main():
             g8 = GraphedHSIC(net, x1, x2, hm)
             a8, b8 = g8.inputs
             for _ in range(args.warmup):
-                g8(a8, b8, hm)
+                g8(a8, b8, hm, next_h_matrix=hm)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                g8(a8, b8, hm)
+                g8(a8, b8, hm, next_h_matrix=hm)
             barrier()
             t8 = max_over_ranks(time.perf_counter() - t0)
             del g8

@@ -205,7 +205,7 @@ class EntropyBottleneckFn(Function):
     @staticmethod
     def backward(ctx, g_zhat, g_lik):
         z_hat, table = ctx.saved_tensors
-        g_lik = _c(g_lik) if g_lik is not None else torch.zeros_like(z_hat)
+        g_lik = _c(g_lik) if g_lik is not None else ops.zeros(z_hat.shape, z_hat.dtype, z_hat.device)
         g_zhat = _c(g_zhat) if g_zhat is not None else None
         g_z, g_t = ops.entropy_bottleneck_bwd(z_hat, table.detach(), g_lik, g_zhat, ctx.lik_bound)
         return g_z, g_t, None, None, None
@@ -245,7 +245,7 @@ class GmmFn(Function):
     @staticmethod
     def backward(ctx, g_yhat, g_lik):
         y_hat, sigma, mu, logits = ctx.saved_tensors
-        g_lik = _c(g_lik) if g_lik is not None else torch.zeros_like(y_hat)
+        g_lik = _c(g_lik) if g_lik is not None else ops.zeros(y_hat.shape, y_hat.dtype, y_hat.device)
         g_yhat = _c(g_yhat) if g_yhat is not None else None
         g_y, g_s, g_m, g_w = ops.gmm_likelihood_bwd(y_hat, sigma, mu, logits, g_lik, g_yhat, ctx.K, ctx.are_logits, ctx.sb, ctx.lb)
         return g_y, None, g_s, g_m, g_w, None, None, None, None
@@ -391,9 +391,9 @@ class EnhancementBlockFn(Function):
             Ct = tail.out_channels
             w_t = ctx.saved_tensors[12]
             g_res = g if ctx.needs_input_grad[3] else None
-            dy32 = torch.zeros(B * 32 * H * W, dtype=torch.int16, device=g.device)
+            dy32 = ops.zeros(B * 32 * H * W, torch.int16, g.device)
             ops.nchw_to_f16k_view(g, dy32, 32, 0)
-            wpad = torch.zeros((32, C, 3, 3), dtype=torch.float32, device=g.device)
+            wpad = ops.zeros((32, C, 3, 3), torch.float32, g.device)
             wpad[:Ct] = w_t.detach()
             dt = ops.make_conv_desc(B, 32, H, W, C, 3, 3, 1, 1, transposed=True, in_ctot=32, out_ctot=C, prec=PREC_BF16)
             g_out = ops.conv2d_f16k_res(dy32, ops.pack_conv_f16k_weight(wpad, dt), None, dt)

@@ -24,6 +24,22 @@ static inline int masic_launch_status(const char* what) {
     return MASIC_OK;
 }
 
+// Zero fill as a KERNEL node.  hipMemsetAsync becomes a memset node when the stream is being captured, and in a replayed graph of the
+// training step those nodes were observed to run out of order with the kernels around them on this ROCm (weight-gradient workspaces
+// read back with garbage in them, different tensors from run to run; masic_amd/graph.py: GraphedTrainStep) -- a kernel node keeps
+// its place.  bytes must be a multiple of 4 and ptr 4-byte aligned.
+__global__ static void masic_zero_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t masic_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    size_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(masic_zero_kernel, dim3((unsigned)nb), dim3(256), 0, st, (unsigned*)ptr, n);
+    return hipGetLastError();
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

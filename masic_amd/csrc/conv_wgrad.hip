@@ -695,14 +695,14 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         int nsplit = ceil_div(512, base);
         if (nsplit > g.ntk) nsplit = g.ntk;
         g.nsplit = nsplit < 1 ? 1 : nsplit;
-        if (hipMemsetAsync(dw, 0, wbytes, st) != hipSuccess) {
+        if (masic_zero_async(dw, wbytes, st) != hipSuccess) {
             masic_set_error("conv2d_wgrad: memset failed");
             return MASIC_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(conv_wgrad_1x1_bf16, dim3(base, 1, g.nsplit), dim3(256), 0, st, g);
         return masic_launch_status("conv2d_wgrad");
     }
-    if (hipMemsetAsync(workspace, 0, wbytes, st) != hipSuccess) {
+    if (masic_zero_async(workspace, wbytes, st) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }

@@ -244,7 +244,7 @@ extern "C" int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k,
                   "conv3x3_wgrad_f16k: needs Cin, Cout multiples of 32");
     MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv3x3_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+    if (masic_zero_async(workspace, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
         masic_set_error("conv3x3_wgrad_f16k: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }

@@ -51,6 +51,12 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _current_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else torch.cuda.current_device
 
 
+def zeros(shape, dtype=torch.float32, device=None):
+    """torch.zeros through a fill KERNEL: torch's zeros / zero_ use hipMemsetAsync, which becomes a memset node under stream capture, and
+    those nodes were observed to run out of order inside a replayed training-step graph (masic_amd/csrc/common.h: masic_zero_async)."""
+    return torch.empty(shape, dtype=dtype, device=device).fill_(0)
+
+
 def _stream():
     # the current HIP stream's handle; torch.cuda.current_stream() builds a Stream object through three layers of Python (8 us of
     # the ~13 us a launch costs the host, and a training step makes ~1000 of them), the raw accessor is one C call
@@ -471,7 +477,7 @@ def gate_bwd(g, x, gate, gate_c):
     _dev(g, "g"); _dev(x, "x"); _dev(gate, "gate")
     B, C, H, W = x.shape
     gx = torch.empty_like(x)
-    ggate = torch.zeros_like(gate)
+    ggate = zeros(gate.shape, gate.dtype, gate.device)
     check(lib.masic_gate_bwd(_p(g), _p(x), _p(gate), _p(gx), _p(ggate), B, C, H * W, gate.shape[1], gate_c, _stream()), "gate_bwd")
     return gx, ggate
 
@@ -596,7 +602,7 @@ def warp_perspective_bwd(g_dst, minv_norm, src_shape):
     _dev(g_dst); _dev(minv_norm)
     B, C, Hs, Ws = src_shape
     Hd, Wd = g_dst.shape[-2:]
-    g_src = torch.zeros(src_shape, dtype=torch.float32, device=g_dst.device)
+    g_src = zeros(src_shape, torch.float32, g_dst.device)
     check(lib.masic_warp_perspective_bwd(_p(g_dst), _p(minv_norm), _p(g_src), B, C, Hs, Ws, Hd, Wd, _stream()), "warp_perspective_bwd")
     return g_src
 

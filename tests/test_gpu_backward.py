@@ -427,6 +427,82 @@ def test_training_step_gradients_vs_reference_golden():
         assert_close(grads[nm].grad, torch.from_numpy(fx["train/auxgrad/" + nm]), "aux:" + nm, GTOL)
 
 
+@pytest.mark.parametrize("N,M,K,B,H,W", [(16, 32, 3, 2, 64, 64), (128, 192, 5, 1, 128, 128)])
+def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
+    """masic_amd.graph.GraphedTrainStep -- the whole optimisation step of newtrain_codec_real.py:135-146 as one HIP-graph replay --
+    against the eager masic_amd.train.train_step with the same (capturable) Adam on the same batches and the same noise (the
+    seven draws of a step come from static buffers refilled before each step): losses per step and the parameters after three
+    steps.  The weight gradients use float atomics, so two runs of the SAME path already differ in the last bits: tolerance, not equality.
+    Also: the eager model keeps working after replays (per-version pack caches are invalidated), at full width the fused
+    analysis / synthesis nodes are inside the capture."""
+    import MASIC
+    from compressai.entropy_models import EntropyModel
+    from masic_amd import nn as mnn, synth, train
+    from masic_amd.graph import GraphedTrainStep
+    sd0 = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=55)
+    batches = [tuple(t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=60 + i)) for i in range(3)]
+    noises = [synth.synth_noise(B, N, M, H, W, seed=70 + i) for i in range(3)]
+    slots = [noises[0][k].to(DEV).clone() for k in O.NOISE_KEYS]
+    state = {"i": 0}
+
+    def static_noise(self, x):
+        t = slots[state["i"] % len(slots)]
+        state["i"] += 1
+        return t.reshape(x.shape)
+
+    def load_noise(it):
+        state["i"] = 0
+        for s, k in zip(slots, O.NOISE_KEYS):
+            s.copy_(noises[it][k].to(DEV))
+
+    orig = EntropyModel._get_noise_cached
+    EntropyModel._get_noise_cached = static_noise
+    mnn.set_precision("bf16")
+    try:
+        def fresh():
+            net = MASIC.HSIC(N, M, K)
+            net.load_state_dict(sd0)
+            return net.to(DEV).train()
+        # eager
+        net_e = fresh()
+        opt = torch.optim.Adam(net_e.parameters(), lr=1e-4, capturable=True)
+        aopt = torch.optim.Adam(net_e.aux_parameters(), lr=1e-3, capturable=True)
+        want = []
+        for it in range(3):
+            load_noise(it)
+            crit, aux = train.train_step(net_e, opt, aopt, *batches[it], 0.01)
+            want.append((float(crit["loss"]), float(aux), float(crit["psnr1"])))
+        # graphed
+        net_g = fresh()
+        load_noise(0)
+        step = GraphedTrainStep(net_g, *batches[0], 0.01)
+        for n, p in net_g.named_parameters():
+            assert torch.equal(p.detach().cpu(), sd0[n]), f"warm-up steps must not leave a trace ({n})"
+        got = []
+        for it in range(3):
+            load_noise(it)
+            crit, aux = step(*batches[it])
+            got.append((float(crit["loss"]), float(aux), float(crit["psnr1"])))
+        torch.cuda.synchronize()
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                assert abs(a - b) <= 2e-4 * abs(a) + 1e-6, (want, got)
+        for (n, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
+            de, dg = (pe.detach().cpu() - sd0[n]).double(), (pg.detach().cpu() - sd0[n]).double()
+            assert float((de - dg).norm()) <= 0.1 * float(de.norm()) + 1e-12, (n, float((de - dg).norm()), float(de.norm()))
+        # the model still works eagerly after replays: its pack caches must not serve the packs of the capture
+        net_g.eval()
+        net_e.eval()
+        with torch.no_grad():
+            oe, og = net_e(*batches[0]), net_g(*batches[0])
+        assert_close(og["x1_hat"], oe["x1_hat"].cpu(), "eager forward after graphed steps", 2e-2)
+        with pytest.raises(RuntimeError):
+            step(*batches[0])                      # eval mode: the capture was of the training-mode step
+    finally:
+        EntropyModel._get_noise_cached = orig
+        mnn.set_precision("f32")
+
+
 def test_two_optimizer_steps_match_cpu_oracle_training():
     """newtrain_codec_real.py:135-146 for two iterations (RD loss backward, Adam 1e-4, aux loss backward, aux Adam 1e-3)
     on HSIC(16,24,3): parameter updates against the same loop driven by torch autograd over the CPU oracle."""

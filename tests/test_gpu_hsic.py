@@ -349,6 +349,46 @@ def test_bf16_operand_path_config1_accuracy_streams_and_graph():
     assert bad <= 0.06 * total
 
 
+def test_graphed_forward_homography_lookahead():
+    """GraphedHSIC(..., next_h_matrix=): the next call's homography staged under the current replay.  Results must equal the plain
+    calls bit for bit -- also when the announced homography is NOT the one the next call brings (the staged matrices are dropped),
+    when it is modified in place in between (version check), and for a CPU tensor."""
+    import MASIC
+    from masic_amd import synth
+    from masic_amd.graph import GraphedHSIC
+    N, M, K = 16, 32, 3
+    net = MASIC.HSIC(N, M, K)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=9))
+    net = net.to(DEV).eval()
+    x1, x2, h0 = (t.to(DEV) for t in synth.synth_inputs(2, 64, 128, seed=9))
+    h1 = h0.clone()
+    h1[:, 0, 2] += 1.5
+    h2 = h0.clone()
+    h2[:, 1, 2] -= 0.75
+    keys = ("x2_hat", "x1_mask_R", "x1_mask_L")
+    with torch.no_grad():
+        g = GraphedHSIC(net, x1, x2, h0)
+        want = {}
+        for name, h in (("h0", h0), ("h1", h1), ("h2", h2)):
+            out = g(x1, x2, h)
+            want[name] = {k: out[k].clone() for k in keys}
+        assert not torch.equal(want["h0"]["x1_mask_R"], want["h1"]["x1_mask_R"])
+        seq = [(h0, h1, "h0"), (h1, h2, "h1"), (h2, h0, "h2"),          # announced == delivered
+               (h0, h1, "h0"), (h2, None, "h2"),                        # announced h1, delivered h2
+               (h1, h2.cpu(), "h1"), (h2.cpu(), h0, "h2"), (h0, h0, "h0")]
+        for h, nxt, name in seq:
+            out = g(x1, x2, h, next_h_matrix=nxt)
+            for k in keys:
+                assert torch.equal(out[k], want[name][k]), (name, k)
+        # announced tensor modified in place before it is delivered: the staged matrices must not be used
+        hv = h0.clone()
+        g(x1, x2, h0, next_h_matrix=hv)
+        hv.copy_(h1)
+        out = g(x1, x2, hv)
+        for k in keys:
+            assert torch.equal(out[k], want["h1"][k]), k
+
+
 @pytest.mark.parametrize("which", ["y1", "y2"])
 def test_gmm_heads_grouped_launches_equal_per_stack_launches(which, monkeypatch):
     """The entropy-parameter heads (reference MASIC.py:330-468) with layer i of the sigma / means / weights stacks as one grouped

@@ -8,6 +8,10 @@ mnn.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 net = MASIC.HSIC(128, 192, 5); net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100)); net = net.cuda().train()
 x1, x2, hm = (t.cuda() for t in synth.synth_inputs(int(os.environ.get("TRAIN_PROF_B", "8")), 512, 512, seed=100))
 opt, aopt = make_optimizers(net)
+if os.environ.get("TRAIN_PROF_GRAPH"):            # the whole step as one HIP-graph replay (masic_amd/graph.py: GraphedTrainStep)
+    from masic_amd.graph import GraphedTrainStep
+    g = GraphedTrainStep(net, x1, x2, hm, 0.01)
+    train_step = lambda net, opt, aopt, x1, x2, hm, l: g(x1, x2, hm)
 for _ in range(2): train_step(net, opt, aopt, x1, x2, hm, 0.01)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = int(os.environ.get("TRAIN_PROF_STEPS", "3"))
