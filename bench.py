@@ -617,7 +617,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"HSIC(N=128,M=192,K=5) eval forward (enc+dec both views), {B}x3x{H}x{W} stereo pairs per GPU "
-                                   "(BASELINE.json configs[1] shape), inputs resident in HBM (the graph's static input buffers)",
+                                   "(BASELINE.json configs[1] shape), inputs resident in HBM (the graph's static input buffers); "
+                                   "the device homography of batch k+1 is handed over with batch k (one-batch look-ahead of a loader): its device->host "
+                                   "read, the float32 host chain and the upload of the sampling matrices are done every step, under the running replay",
                        "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world} (pairs sharded, no data-path collective)"},
             "roofline": roofline,
         }
