@@ -338,13 +338,13 @@ def main():
             cur = torch.cuda.current_stream()
             # (a) synchronous: upload on the compute stream, then the step
             for _ in range(2):
-                xa.copy_(x1p, non_blocking=True); xb.copy_(x2p, non_blocking=True); step(xa, xb, hm)
+                xa.copy_(x1p, non_blocking=True); xb.copy_(x2p, non_blocking=True); step(xa, xb, hm, **ahead)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 xa.copy_(x1p, non_blocking=True)
                 xb.copy_(x2p, non_blocking=True)
-                step(xa, xb, hm)
+                step(xa, xb, hm, **ahead)
             barrier()
             t_sync = max_over_ranks(time.perf_counter() - t0)
             # (b) overlapped: batch n+1 goes up on a copy stream into the other of two staging buffers while batch n runs;
@@ -370,7 +370,7 @@ def main():
                     if i + 1 < n:
                         upload_into(1 - p)
                     cur.wait_event(up[p])
-                    step(stage[p][0], stage[p][1], hm)
+                    step(stage[p][0], stage[p][1], hm, **ahead)
                     free[p].record(cur)
             run_overlapped(3)
             barrier()
