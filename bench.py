@@ -546,7 +546,7 @@ def main():
             from masic_amd.parallel import GradientAllReducer
             from masic_amd.train import cqe_train_step
             en.train()
-            opt2 = torch.optim.Adam(en.parameters(), lr=1e-4)
+            opt2 = torch.optim.Adam(list(en.parameters()), lr=1e-4, fused=True)      # cqe_train_step bumps the version counters a fused step leaves alone
             red2 = GradientAllReducer(en) if world > 1 else None
             cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
             barrier()

@@ -211,8 +211,8 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs the bf16 / fp8 operand mode (masic_amd.nn.set_precision): the float32 parity path "
                                "evaluates the sampling matrices on the host, which a captured step cannot do")
         self.model, self.lmbda = model, lmbda
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
-        self.aux_optimizer = torch.optim.Adam(model.aux_parameters(), lr=aux_lr, capturable=True)
+        self.optimizer = torch.optim.Adam(list(model.parameters()), lr=lr, capturable=True, fused=True)
+        self.aux_optimizer = torch.optim.Adam(list(model.aux_parameters()), lr=aux_lr, capturable=True, fused=True)
         self.d1, self.d2, self.h = d1.clone(), d2.clone(), h_matrix.clone()
         self._params = [p for _, p in model.named_parameters()]
         self._precision = _mnn.get_precision()

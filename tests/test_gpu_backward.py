@@ -465,8 +465,8 @@ def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
             return net.to(DEV).train()
         # eager
         net_e = fresh()
-        opt = torch.optim.Adam(net_e.parameters(), lr=1e-4, capturable=True)
-        aopt = torch.optim.Adam(net_e.aux_parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.Adam(list(net_e.parameters()), lr=1e-4, capturable=True, fused=True)        # the graph's optimizer flavour
+        aopt = torch.optim.Adam(list(net_e.aux_parameters()), lr=1e-3, capturable=True, fused=True)
         want = []
         for it in range(3):
             load_noise(it)
