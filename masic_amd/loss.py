@@ -66,11 +66,11 @@ def rate_distortion(output, target1, target2, lmbda):
     liks = output["likelihoods"]
     if torch.is_grad_enabled() and any(t.requires_grad for t in (output["x1_hat"], output["x2_hat"], *liks.values())):
         from .autograd import RateDistortionFn
-        loss = RateDistortionFn.apply(lmbda, target1, target2, output["x1_hat"], output["x2_hat"], *liks.values())
-        with torch.no_grad():
-            rest = rate_distortion(output, target1, target2, lmbda)
-        rest["loss"] = loss
-        return rest
+        loss, mse1, mse2, bpp, *per = RateDistortionFn.apply(lmbda, target1, target2, output["x1_hat"], output["x2_hat"], *liks.values())
+        out = {"bpp_loss": bpp.float(), "mse_loss": (mse1 + mse2).float(), "loss": loss, "mse1": mse1, "mse2": mse2}
+        out.update({"bpp_" + k: v for k, v in zip(liks.keys(), per)})
+        out["psnr1"], out["psnr2"] = LazyPSNR(mse1), LazyPSNR(mse2)
+        return out
     B, _, H, W = target1.shape
     num_pixels = B * H * W
     per = {k: ops.sum_log(v.contiguous()) / (-math.log(2) * num_pixels) for k, v in output["likelihoods"].items()}
@@ -92,13 +92,14 @@ def distortion(output, target1, target2, lmbda):
     are reporting only and need pytorch_msssim, which is outside the path)."""
     import torch
     x1_hat, x2_hat = output["x1_hat"], output["x2_hat"]
-    mse1 = ops.sse(x1_hat.detach().contiguous(), target1.contiguous()) / target1.numel()
-    mse2 = ops.sse(x2_hat.detach().contiguous(), target2.contiguous()) / target2.numel()
-    mse = mse1 + mse2
     if torch.is_grad_enabled() and (x1_hat.requires_grad or x2_hat.requires_grad):
         from .autograd import RateDistortionFn
-        loss = RateDistortionFn.apply(lmbda, target1, target2, x1_hat, x2_hat)      # no likelihood terms: distortion only
+        loss, mse1, mse2, _ = RateDistortionFn.apply(lmbda, target1, target2, x1_hat, x2_hat)      # no likelihood terms: distortion only
+        mse = mse1 + mse2
     else:
+        mse1 = ops.sse(x1_hat.detach().contiguous(), target1.contiguous()) / target1.numel()
+        mse2 = ops.sse(x2_hat.detach().contiguous(), target2.contiguous()) / target2.numel()
+        mse = mse1 + mse2
         loss = (lmbda * 255 ** 2 * mse).float()
     return {"mse_loss": mse.float(), "loss": loss, "mse1": mse1, "mse2": mse2,
             "psnr1": LazyPSNR(mse1), "psnr2": LazyPSNR(mse2)}
