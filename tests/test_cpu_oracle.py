@@ -214,3 +214,31 @@ def test_oracle_cqe_vs_golden():
         out = O.independent_en_forward(sd, xa, xb, hm)
     for k in ("x1_hat", "x2_hat"):
         assert float((out[k] - torch.from_numpy(fx[k])).abs().max()) <= 1e-6 * float(np.abs(fx[k]).max()), k
+
+
+def test_lazy_psnr_is_a_float_when_used():
+    """masic_amd.loss.LazyPSNR: mse2psnr (newtrain_codec_real.py:62-65) evaluated when first used -- formatting, arithmetic, comparison
+    and meters see a float; the (device) scalar is read exactly once."""
+    import math
+    import torch
+    from masic_amd.loss import LazyPSNR
+
+    class Counting:
+        def __init__(self, v):
+            self.v, self.reads = v, 0
+
+        def __float__(self):
+            self.reads += 1
+            return self.v
+    src = Counting(0.004)
+    p = LazyPSNR(src)
+    want = 10 * math.log10(1 / 0.004)
+    assert src.reads == 0
+    assert abs(float(p) - want) < 1e-12 and f"{p:.3f}" == f"{want:.3f}" and repr(p) == repr(want)
+    assert p - 1.0 == want - 1.0 and 1.0 - p == 1.0 - want and p + p == 2 * want and 2 * p == 2 * want and p / 2 == want / 2
+    assert (p > 20) == (want > 20) and abs(p) == abs(want) and -p == -want and p == want
+    assert src.reads == 1
+    total = 0.0
+    total += p * 3                      # AverageMeter.update(val, n): sum += val * n
+    assert total == want * 3
+    assert abs(float(LazyPSNR(torch.tensor(0.25, dtype=torch.float64))) - 10 * math.log10(4.0)) < 1e-12
