@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--no-cqe", action="store_true", help="skip the Independent_EN (CQE) forward / training-step extras")
     ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive timings (extras.with_upload)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--train-steps", type=int, default=3,
+    ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
                          "2x Adam) after the headline region; reported under extras.train_step, 0 to skip")
     args = ap.parse_args()
@@ -548,7 +548,8 @@ def main():
             en.train()
             opt2 = torch.optim.Adam(list(en.parameters()), lr=1e-4, fused=True)      # cqe_train_step bumps the version counters a fused step leaves alone
             red2 = GradientAllReducer(en) if world > 1 else None
-            cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
+            for _ in range(2):                        # warm-up: weight packs of both kinds, optimizer state, allocator pools
+                cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.train_steps):
@@ -570,7 +571,8 @@ def main():
         net.train()
         optimizer, aux_optimizer = make_optimizers(net)
         reducer = GradientAllReducer(net) if world > 1 else None
-        train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)        # warm-up (packs dgrad weights etc.)
+        for _ in range(2):                                                         # warm-up (weight packs of both kinds, optimizer state, allocator pools)
+            train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):

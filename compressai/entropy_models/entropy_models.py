@@ -170,8 +170,9 @@ class EntropyBottleneck(EntropyModel):
         return self.quantiles[:, :, 1:2]
 
     def _table(self, differentiable=False):
-        if differentiable:      # torch.cat is tracked: autograd routes the table gradient back to the 14 parameters
-            return _hip.eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
+        if differentiable:      # one autograd node: the table gradient goes back to the 14 parameters with one launch
+            from masic_amd.autograd import eb_param_table
+            return eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
         # inference: the [C, 58] table only changes with the parameters -- rebuilt per parameter version, not per forward
         params = list(self._matrices) + list(self._biases) + list(self._factors)
         key = tuple((p._version, p.data_ptr()) for p in params)

@@ -441,6 +441,10 @@ int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float
 /* EntropyBottleneck backward: g_z [B,C,H,W] and g_params [C,58] (same table layout as the forward) */
 int masic_entropy_bottleneck_bwd(const float* z_hat, const float* params, const float* g_lik, const float* g_zhat,
                                  float* g_z, float* g_params, int B, int C, int H, int W, float lik_bound, void* stream);
+/* Gradient of the [C][58] parameter table (torch.cat of the 14 per-channel tensors of an EntropyBottleneck, reference
+ * entropy_models.py:289-300) split into the parameters' gradients in one launch: part t (width widths[t]) becomes the contiguous
+ * block [C][widths[t]] at flat + C * (widths[0] + ... + widths[t-1]). */
+int masic_eb_table_split(const float* g_table, float* flat, int C, const int* widths, int nparts, void* stream);
 int masic_entropy_bottleneck_auxloss_bwd(const float* params, const float* quantiles, float* g_quantiles,
                                          int C, double tail_mass, float gout, void* stream);
 /* warp backward w.r.t. the source image; g_src [B,C,Hs,Ws] must be ZERO-FILLED by the caller (float atomics) */

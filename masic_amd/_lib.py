@@ -148,6 +148,7 @@ SIGNATURES = {
     "masic_gdn_bwd_fused_ex": (c_int, [_P] * 12 + [c_int] * 5 + [c_double, _P]),
     "masic_gmm_likelihood_bwd": (c_int, [_P] * 10 + [c_int] * 6 + [c_float, c_float, _P]),
     "masic_entropy_bottleneck_bwd": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
+    "masic_eb_table_split": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int), c_int, _P]),
     "masic_entropy_bottleneck_auxloss_bwd": (c_int, [_P, _P, _P, c_int, c_double, c_float, _P]),
     "masic_warp_perspective_bwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
 }

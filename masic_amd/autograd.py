@@ -211,6 +211,25 @@ class EntropyBottleneckFn(Function):
         return g_z, g_t, None, None, None
 
 
+class EbTableFn(Function):
+    """The [C,58] parameter table of an EntropyBottleneck from its 14 per-channel tensors (ops.eb_param_table) as ONE node: the backward
+    splits the table gradient with one launch into contiguous blocks of one buffer (torch.cat's own backward: 14 strided views that
+    AccumulateGrad then copies one by one -- 28 small launches per bottleneck and step)."""
+
+    @staticmethod
+    def forward(ctx, n_m, n_b, *params):
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return ops.eb_param_table(list(params[:n_m]), list(params[n_m:n_m + n_b]), list(params[n_m + n_b:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(ops.eb_table_split(_c(g), ctx.shapes))
+
+
+def eb_param_table(matrices, biases, factors):
+    return EbTableFn.apply(len(matrices), len(biases), *matrices, *biases, *factors)
+
+
 class AuxLossFn(Function):
     """EntropyBottleneck.loss(): sum |logits(quantiles) - target|, density parameters detached."""
 

@@ -499,6 +499,34 @@ extern "C" int masic_gate_bwd(const float* g, const float* x, const float* gate,
     return masic_launch_status("gate_bwd");
 }
 
+// Backward of the [C][58] parameter table of an EntropyBottleneck (torch.cat of 14 per-channel tensors, entropy_models.py:289-300): the
+// table gradient split into the 14 parameter gradients with ONE launch, each a contiguous [C][w] block of `flat` (the caller hands
+// views of it to autograd) -- torch's CatBackward + AccumulateGrad make 14 strided views and then 14 copies, per bottleneck and step.
+namespace {
+struct EbSplitArgs { int widths[16]; int nparts; };
+__global__ void eb_table_split_kernel(const float* __restrict__ g, float* __restrict__ flat, int C, int ncol, const EbSplitArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ncol) return;
+    const int c = i / ncol, col = i - c * ncol;
+    int start = 0, t = 0;
+    while (t + 1 < a.nparts && col >= start + a.widths[t]) { start += a.widths[t]; ++t; }
+    flat[(size_t)C * start + (size_t)c * a.widths[t] + (col - start)] = g[i];
+}
+}  // namespace
+extern "C" int masic_eb_table_split(const float* g_table, float* flat, int C, const int* widths, int nparts, void* stream) {
+    MASIC_REQUIRE(g_table && flat && widths && C > 0 && nparts > 0 && nparts <= 16, MASIC_ERR_ARG, "eb_table_split: bad argument");
+    EbSplitArgs a{};
+    int ncol = 0;
+    for (int t = 0; t < nparts; ++t) {
+        MASIC_REQUIRE(widths[t] > 0, MASIC_ERR_ARG, "eb_table_split: non-positive width");
+        a.widths[t] = widths[t];
+        ncol += widths[t];
+    }
+    a.nparts = nparts;
+    hipLaunchKernelGGL(eb_table_split_kernel, dim3((unsigned)((C * ncol + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_table, flat, C, ncol, a);
+    return masic_launch_status("eb_table_split");
+}
+
 extern "C" int masic_softmax_k_bwd(const float* g, const float* y, float* gx, int B, int M, int K, int HW, void* stream) {
     MASIC_REQUIRE(g && y && gx, MASIC_ERR_ARG, "softmax_k_bwd: null pointer");
     const size_t total = (size_t)B * M * HW;

@@ -258,6 +258,24 @@ def eb_param_table(matrices, biases, factors):
     return table
 
 
+def eb_table_split(g_table, shapes):
+    """The gradient of eb_param_table's output split into gradients of its inputs (shapes: their shapes, [C, ...] each): one launch,
+    the results are contiguous views of one buffer (masic_eb_table_split)."""
+    _dev(g_table, "g_table")
+    C, ncol = g_table.shape
+    widths = [int(torch.Size(s[1:]).numel()) for s in shapes]
+    if sum(widths) != ncol or any(s[0] != C for s in shapes):
+        raise RuntimeError("masic_amd.eb_table_split: shapes do not tile the table")
+    flat = torch.empty(C * ncol, dtype=torch.float32, device=g_table.device)
+    w = (ctypes.c_int * len(widths))(*widths)
+    check(lib.masic_eb_table_split(_p(g_table.contiguous()), _p(flat), C, w, len(widths), _stream()), "eb_table_split")
+    outs, off = [], 0
+    for s, wd in zip(shapes, widths):
+        outs.append(flat[off:off + C * wd].view(s))
+        off += C * wd
+    return outs
+
+
 def entropy_bottleneck(z, table, medians, training=False, noise=None, lik_bound=LIK_BOUND):
     _dev(z, "z"); _dev(table, "EB table"); _dev(medians, "medians")
     B, C, H, W = z.shape
