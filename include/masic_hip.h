@@ -225,6 +225,8 @@ int masic_deconv_s2_as_conv_weight(const float* w, const float* bias, float* w_o
 size_t masic_conv3x3_wgrad_f16k_workspace_bytes(int Cin, int Cout);
 int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
                              int B, int Cin, int Cout, int H, int W, void* stream);
+int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                             int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream);
 /* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
  * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */
@@ -395,6 +397,10 @@ int masic_sse(const float* a, const float* b, size_t n, double* out, void* works
  * Cin/Cout swapped on the same weight tensor (and vice versa), see masic_amd/autograd.py. */
 size_t masic_conv2d_wgrad_workspace_bytes(const masic_conv_desc_t* d);
 int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, const masic_conv_desc_t* d, void* stream);
+/* The same with a caller-owned PERSISTENT workspace: workspace_clean != 0 promises zeros on entry and gets zeros back on exit (the
+ * last pass of the call re-zeroes what it reads), so a training step's ~80 weight gradients need no fill launch each. */
+int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, void* workspace, const masic_conv_desc_t* d, int workspace_clean,
+                          void* stream);
 
 /* y = op(a, b) elementwise over n floats; ops (s0,s1 scalars):
  *   0 act_bwd (a=grad, b=activation output, s0=MASIC_ACT_*)   1 abs_bwd (a=grad, b=x)   2 square   3 abs

@@ -641,12 +641,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
 }
 
 // ws [T][CA][CQ] -> dw [CA][CQ][T]
-__global__ __launch_bounds__(256) void wgrad_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int AQ) {
+// rezero: every workspace element is read by exactly one thread of this pass, which then puts the zero back -- a persistent workspace
+// is clean again for the next weight gradient and needs no fill launch of its own (masic_conv2d_wgrad_ws)
+__global__ __launch_bounds__(256) void wgrad_transpose_kernel(float* __restrict__ ws, float* __restrict__ dw, int T, int AQ, int rezero) {
     const size_t total = (size_t)T * AQ;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t aq = i / T;
         const int t = (int)(i - aq * T);
         dw[i] = ws[(size_t)t * AQ + aq];
+        if (rezero) ws[(size_t)t * AQ + aq] = 0.0f;
     }
 }
 
@@ -659,6 +662,14 @@ extern "C" size_t masic_conv2d_wgrad_workspace_bytes(const masic_conv_desc_t* d)
 
 extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace,
                                   const masic_conv_desc_t* d, void* stream) {
+    return masic_conv2d_wgrad_ws(x, dy, dw, workspace, d, 0, stream);
+}
+
+// workspace_clean != 0: `workspace` holds zeros on entry (a persistent buffer: zeroed once by its owner) and holds zeros again when the
+// call's last kernel has run -- no fill launch per weight gradient (a training step computes ~80 of them; a launch costs the device
+// ~10 us whatever it does).  0: contents unknown, zeroed here, left dirty (the behaviour of masic_conv2d_wgrad).
+extern "C" int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, void* workspace,
+                                     const masic_conv_desc_t* d, int workspace_clean, void* stream) {
     MASIC_REQUIRE(x && dy && dw && workspace && d, MASIC_ERR_ARG, "conv2d_wgrad: null pointer");
     MASIC_REQUIRE(d->KH * d->KW == 1 || d->KH * d->KW <= 28, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: kernel %dx%d", d->KH, d->KW);
     MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: stride %d", d->stride);
@@ -702,7 +713,7 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         hipLaunchKernelGGL(conv_wgrad_1x1_bf16, dim3(base, 1, g.nsplit), dim3(256), 0, st, g);
         return masic_launch_status("conv2d_wgrad");
     }
-    if (masic_zero_async(workspace, wbytes, st) != hipSuccess) {
+    if (!workspace_clean && masic_zero_async(workspace, wbytes, st) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
@@ -725,7 +736,7 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
         const size_t total5 = (size_t)Tt * a.CA * a.CQ;
         int tb5 = (int)((total5 + 255) / 256);
         if (tb5 > 4096) tb5 = 4096;
-        hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb5), dim3(256), 0, st, (const float*)workspace, dw, Tt, a.CA * a.CQ);
+        hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb5), dim3(256), 0, st, (float*)workspace, dw, Tt, a.CA * a.CQ, workspace_clean);
         return masic_launch_status("conv2d_wgrad");
     }
     if (a.CQ <= 8 && Tt > 1 && ncol_tiles <= 8) {          // few fine-side channels: (tap, q) pairs packed into the 32 MFMA columns
@@ -762,6 +773,6 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
     const size_t total = (size_t)T * AQ;
     int tb = (int)((total + 255) / 256);
     if (tb > 4096) tb = 4096;
-    hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb), dim3(256), 0, st, (const float*)workspace, dw, T, AQ);
+    hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, T, AQ, workspace_clean);
     return masic_launch_status("conv2d_wgrad");
 }

@@ -211,11 +211,12 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
 }
 
 // ws [9][CA][CQ] -> dw [CA][CQ][9]
-__global__ __launch_bounds__(256) void wgrad3_transpose_kernel(const float* __restrict__ ws, float* __restrict__ dw, int AQ) {
+__global__ __launch_bounds__(256) void wgrad3_transpose_kernel(float* __restrict__ ws, float* __restrict__ dw, int AQ, int rezero) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)9 * AQ; i += (size_t)gridDim.x * 256) {
         const int t = (int)(i / AQ);
         const size_t aq = i - (size_t)t * AQ;
         dw[aq * 9 + t] = ws[i];
+        if (rezero) ws[i] = 0.0f;          // a persistent workspace is clean again (masic_conv3x3_wgrad_f16k_ws)
     }
 }
 
@@ -239,12 +240,18 @@ extern "C" size_t masic_conv3x3_wgrad_f16k_workspace_bytes(int Cin, int Cout) { 
 // dW [Cout][Cin][3][3] (float32) of Conv2d(Cin -> Cout, k3, s1, p1) from x and dy in F16K (Cin, Cout multiples of 32).
 extern "C" int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
                                         int B, int Cin, int Cout, int H, int W, void* stream) {
+    return masic_conv3x3_wgrad_f16k_ws(x_f16k, dy_f16k, dw, workspace, B, Cin, Cout, H, W, 0, stream);
+}
+
+// workspace_clean: as masic_conv2d_wgrad_ws -- zeros on entry, zeros again on exit, no fill launch
+extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                                           int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream) {
     MASIC_REQUIRE(x_f16k && dy_f16k && dw && workspace, MASIC_ERR_ARG, "conv3x3_wgrad_f16k: null pointer");
     MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED,
                   "conv3x3_wgrad_f16k: needs Cin, Cout multiples of 32");
     MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv3x3_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (masic_zero_async(workspace, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+    if (!workspace_clean && masic_zero_async(workspace, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
         masic_set_error("conv3x3_wgrad_f16k: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
@@ -270,6 +277,6 @@ extern "C" int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k,
     const int AQ = Cin * Cout;
     int tb = (9 * AQ + 255) / 256;
     if (tb > 2048) tb = 2048;
-    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (const float*)workspace, dw, AQ);
+    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, workspace_clean);
     return masic_launch_status("conv3x3_wgrad_f16k");
 }

@@ -581,9 +581,31 @@ def conv2d_wgrad(x, dy, desc, weight_shape):
     nbytes = lib.masic_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
     if nbytes != dw.numel() * 4:
         raise RuntimeError("masic_amd.conv2d_wgrad: weight shape does not match the descriptor")
-    ws = torch.empty(dw.numel(), dtype=torch.float32, device=x.device)
-    check(lib.masic_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), _stream()), "conv2d_wgrad")
+    ws = _clean_workspace(x.device, dw.numel())
+    try:
+        check(lib.masic_conv2d_wgrad_ws(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), 1, _stream()), "conv2d_wgrad")
+    except Exception:
+        _drop_workspace(x.device, dw.numel())          # an error part-way may have left it dirty
+        raise
     return dw
+
+
+_CLEAN_WS = {}
+
+
+def _clean_workspace(device, numel):
+    """Persistent float32 workspace of the weight-gradient kernels, zeroed ONCE: the kernels accumulate into it with float atomics and
+    their last pass puts the zeros back (masic_conv2d_wgrad_ws), so a step's ~80 weight gradients need no fill launch each.  One buffer
+    per (device, stream, size): launches on one stream are ordered, two streams never share a buffer."""
+    key = (device, int(_stream().value or 0), int(numel))
+    ws = _CLEAN_WS.get(key)
+    if ws is None:
+        ws = _CLEAN_WS[key] = zeros(numel, torch.float32, device)
+    return ws
+
+
+def _drop_workspace(device, numel):
+    _CLEAN_WS.pop((device, int(_stream().value or 0), int(numel)), None)
 
 
 def gmm_likelihood_bwd(y_hat, sigma, mu, wts, g_lik, g_yhat, K, weights_are_logits, scale_bound=SCALE_BOUND, lik_bound=LIK_BOUND):
@@ -1188,6 +1210,11 @@ def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:
         raise RuntimeError("masic_amd.conv3x3_wgrad_f16k: F16K buffer sizes do not match (B, C, H, W)")
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x16.device)
-    ws = torch.empty(lib.masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout) // 4, dtype=torch.float32, device=x16.device)
-    check(lib.masic_conv3x3_wgrad_f16k(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, _stream()), "conv3x3_wgrad_f16k")
+    n = lib.masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout) // 4
+    ws = _clean_workspace(x16.device, n)
+    try:
+        check(lib.masic_conv3x3_wgrad_f16k_ws(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, 1, _stream()), "conv3x3_wgrad_f16k")
+    except Exception:
+        _drop_workspace(x16.device, n)
+        raise
     return dw
