@@ -227,6 +227,11 @@ int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw,
                              int B, int Cin, int Cout, int H, int W, void* stream);
 int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
                              int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream);
+/* Weight gradient of the 1x1 layers (the entropy-parameter stacks, reference MASIC.py:330-468) from F16K operands:
+ * dw[a][q] = sum over batch and pixels of rows[b][a][p] * cols[b][q][p]; rows / cols: F16K [B][C/16][HW][16] bf16 with CA / CQ
+ * channels (multiples of 16); dw float32 [CA][CQ].  Conv2d weight [Cout][Cin]: rows = dy, cols = x; ConvTranspose2d(k1) weight
+ * [Cin][Cout]: rows = x, cols = dy. */
+int masic_gemm_wgrad_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int B, int CA, int CQ, int HW, void* stream);
 /* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
  * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */

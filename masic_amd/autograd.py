@@ -45,10 +45,13 @@ class ConvFn(Function):
             # bf16-operand mode, 1x1 layers of the entropy-parameter stacks: the DMA-staged GEMM of the inference path (conv_f16k.hip:
             # gemm_f16k, 4x the rate of the NCHW implicit-GEMM kernel at these shapes); x is converted once to F16K
             B, _, H, W = x.shape
-            y = ops.gemm_f16k(ops.nchw_to_f16k(x), mod.packed_gemm_dma_weight(), None if bias is None else bias.detach(), B, mod.in_channels,
+            x16 = ops.nchw_to_f16k(x)
+            y = ops.gemm_f16k(x16, mod.packed_gemm_dma_weight(), None if bias is None else bias.detach(), B, mod.in_channels,
                               mod.out_channels, H, W, act, want_nchw=True)
+            ctx.x16 = x16 if _WGRAD1_F16K else None          # kept for the weight gradient (masic_gemm_wgrad_f16k)
         else:
             y = mod.run(x, act=act)
+            ctx.x16 = None
         ctx.mod, ctx.act = mod, act
         ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
         ctx.has_bias = bias is not None
@@ -58,11 +61,13 @@ class ConvFn(Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         gx, gw, gb = conv_backward(ctx.mod, x, weight, y, g, ctx.act, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                   ctx.has_bias and ctx.needs_input_grad[2])
+                                   ctx.has_bias and ctx.needs_input_grad[2], x16=ctx.x16)
+        ctx.x16 = None
         return gx, gw, gb, None, None
 
 
 _PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
+_WGRAD1_F16K = os.environ.get("MASIC_WGRAD1_F16K", "1") != "0"     # 0: 1x1 weight gradients on the float32 NCHW kernel (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
 
@@ -125,7 +130,11 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     def parameter_gradients():
         gw = None
         gb_ = gb if act == ops.ACT_NONE else None
-        if dw_f16k:
+        if need_gw and _WGRAD1_F16K and dx_gemm and x16 is not None and g16 is not None and x.shape[1] == Cin:
+            # 1x1 layers: both operands are in F16K already (the forward GEMM's input, the input-gradient GEMM's dy)
+            gw = (ops.gemm_wgrad_f16k(x16, g16, B, Cin, Cout, Hi * Wi) if mod.transposed_conv
+                  else ops.gemm_wgrad_f16k(g16, x16, B, Cout, Cin, Hi * Wi)).view(tuple(weight.shape))
+        elif dw_f16k:
             gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
         elif need_gw:
             dw = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)

@@ -21,6 +21,8 @@
 // (mod 256) apart so that the two 16-lane groups of a half wave never share a bank.  Workgroups take a strided share of the
 // tiles and add their partial dW into a [tap][co][ci] workspace with float atomics (ci contiguous: full 128-byte segments);
 // a last pass transposes it into the weight layout.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -220,6 +222,119 @@ __global__ __launch_bounds__(256) void wgrad3_transpose_kernel(float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ 1x1 layers
+// dW[co][ci] = sum_{b,p} dy[b][co][p] x[b][ci][p] for the 1x1 layers of the entropy-parameter stacks (MASIC.py:330-468: 768 ... 1152
+// channels on both sides at 8 x 32 x 32 latents -- a 1152 x 768 x 8192 GEMM whose contraction index is the pixel).  The float32 NCHW
+// kernel (conv_wgrad.hip: conv_wgrad_1x1_bf16) re-reads its 128 x 64 float32 tiles 6 ... 9 times and is bound by that traffic
+// (77 us per layer, 0.19 PFLOP/s); the training step has both operands in F16K anyway (the forward GEMM's input, the input-gradient
+// GEMM's dy).  Workgroup = 4 waves, output tile 128 x 128 (wave = 64 co x 64 ci, 2 x 2 accumulators); k-tiles of 64 pixels of both
+// operands -- 16 planes of 64 records -- arrive by `buffer_load ... lds` DMA, two buffers (70 KiB: two workgroups per CU), 8 DMA
+// instructions per wave and tile with a counted vmcnt; fragments by `ds_read_b64_tr_b16` exactly as above (2 reads per MFMA).
+// Workgroups take a strided share of the (image, pixel tile) pairs and add their partial tile into dw with float atomics.
+constexpr int W1_PX = 64;                            // pixels per k-tile
+constexpr int W1_PLANE = W1_PX * 32 + 128;           // bytes per 16-channel plane (+128: bank offset between the planes of a 32-channel block)
+constexpr int W1_HALF = 8 * W1_PLANE;                // 128 channels of one operand
+constexpr int W1_BUF = 2 * W1_HALF;                  // dy planes | x planes
+
+struct Wg1Args {
+    const unsigned short* g16;    // rows (A): F16K [B][CA16][HW][16]
+    const unsigned short* x16;    // columns (B): F16K [B][CQ16][HW][16]
+    float* dw;                    // [CA][CQ] float32, zeroed by the caller
+    int B, HW, CA16, CQ16, CA, CQ;
+    int q_tiles, tpi, ntk, nsplit;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wq = wave >> 1;
+    const int a0 = (blockIdx.x / a.q_tiles) * 128, q0 = (blockIdx.x % a.q_tiles) * 128;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g16, 0, a.B * a.CA16 * a.HW * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, 0, a.B * a.CQ16 * a.HW * 32, 0x00020000);
+    // DMA instruction i = wave + 4 j, j < 8: operand i >> 4, plane (i >> 1) & 7, pixel half i & 1 (32 records of 32 bytes, 2 lanes each)
+    auto issue = [&](int kt, int buf) {
+        const bool real = kt < a.ntk;
+        const int kk = real ? kt : 0;
+        const int b = kk / a.tpi, p0 = (kk - b * a.tpi) * W1_PX;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = wave + 4 * j;
+            const int isx = i >> 4, pl = (i >> 1) & 7, half = i & 1;
+            const int px = p0 + half * 32 + (lane >> 1);
+            const int blk = ((isx ? q0 : a0) >> 4) + pl;
+            const bool ok = real && px < a.HW && blk < (isx ? a.CQ16 : a.CA16);
+            const int voff = ok ? px * 32 + (lane & 1) * 16 : 0x7ffffff0;
+            unsigned char* dst = lds + buf * W1_BUF + isx * W1_HALF + pl * W1_PLANE + half * 1024;
+            if (isx) dma16(rx, dst, voff, ((b * a.CQ16 + blk) * a.HW) * 32);
+            else dma16(rg, dst, voff, ((b * a.CA16 + blk) * a.HW) * 32);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][0][e] = 0.0f; acc[0][1][e] = 0.0f; acc[1][0][e] = 0.0f; acc[1][1][e] = 0.0f; }
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned lane_off = (g4 & 1) * W1_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
+    const unsigned la = ldsb + (4 * wa) * W1_PLANE + lane_off;                    // + m * 2 planes: this wave's 64 rows = 4 planes
+    const unsigned lb = ldsb + W1_HALF + (4 * wq) * W1_PLANE + lane_off;
+
+    int kt = blockIdx.z, buf = 0;
+    issue(kt, 0);
+    for (; kt < a.ntk; kt += a.nsplit, buf ^= 1) {
+        issue(kt + a.nsplit, buf ^ 1);           // past the end: out-of-range reads (zeros), the count per wave stays 8
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // this tile has landed, the next one may still fly
+        __builtin_amdgcn_s_barrier();                               // ... for every wave
+        const unsigned ba = la + buf * W1_BUF, bb = lb + buf * W1_BUF;
+        v2u af[2][2][2], bfr[2][2][2];
+        auto request = [&](auto kc, auto pc) {
+            constexpr int ks = decltype(kc)::value, pb = decltype(pc)::value;
+            sfor<0, 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                tr_read<m * 2 * W1_PLANE + ks * 16 * 32>(af[pb][m][0], ba);
+                tr_read<m * 2 * W1_PLANE + ks * 16 * 32 + 128>(af[pb][m][1], ba);
+                tr_read<m * 2 * W1_PLANE + ks * 16 * 32>(bfr[pb][m][0], bb);
+                tr_read<m * 2 * W1_PLANE + ks * 16 * 32 + 128>(bfr[pb][m][1], bb);
+            });
+        };
+        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        sfor<0, W1_PX / 16>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value, pb = ks & 1;
+            if constexpr (ks + 1 < W1_PX / 16) request(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (ks + 1) & 1>{});
+            constexpr int pending = ks + 1 < W1_PX / 16 ? 8 : 0;
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
+            sfor<0, 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                depend(af[pb][m][0], af[pb][m][1]);
+                depend(bfr[pb][m][0], bfr[pb][m][1]);
+            });
+            sfor<0, 2>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                const bf16x8 bq = frag(bfr[pb][n][0], bfr[pb][n][1]);
+                sfor<0, 2>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), bq, acc[m][n], 0, 0, 0);
+                });
+            });
+        });
+        __builtin_amdgcn_s_barrier();            // everyone is done reading this buffer before the next iteration's DMA overwrites it
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int ci = q0 + 64 * wq + 32 * n + j;
+            if (ci >= a.CQ) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = a0 + 64 * wa + 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+                if (co < a.CA) atomicAdd(a.dw + (size_t)co * a.CQ + ci, acc[m][n][e]);
+            }
+        }
+}
+
 template <int MA, int NQ>
 void launch(const Wg3Args& a, int grid, hipStream_t st) {
     auto kfn = wgrad3x3_f16k<MA, NQ>;
@@ -279,4 +394,35 @@ extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
     if (tb > 2048) tb = 2048;
     hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, workspace_clean);
     return masic_launch_status("conv3x3_wgrad_f16k");
+}
+
+// dw [CA][CQ] (float32) = sum over batch and pixels of rows[b][a][p] * cols[b][q][p], both operands F16K ([B][C/16][HW][16] bf16),
+// CA, CQ multiples of 16.  For a Conv2d(Cin -> Cout, k1) weight [Cout][Cin]: rows = dy, cols = x; for the ConvTranspose2d(k1) form
+// [Cin][Cout] (reference MASIC.py:338-376): rows = x, cols = dy.
+extern "C" int masic_gemm_wgrad_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int B, int CA, int CQ, int HW, void* stream) {
+    MASIC_REQUIRE(rows_f16k && cols_f16k && dw, MASIC_ERR_ARG, "gemm_wgrad_f16k: null pointer");
+    MASIC_REQUIRE(B > 0 && HW > 0 && CA > 0 && CQ > 0 && CA % 16 == 0 && CQ % 16 == 0, MASIC_ERR_UNSUPPORTED, "gemm_wgrad_f16k: channel counts must be multiples of 16");
+    MASIC_REQUIRE((long)B * (CA > CQ ? CA : CQ) * HW * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_wgrad_f16k: tensor too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (masic_zero_async(dw, (size_t)CA * CQ * sizeof(float), st) != hipSuccess) {
+        masic_set_error("gemm_wgrad_f16k: zero fill failed");
+        return MASIC_ERR_LAUNCH;
+    }
+    Wg1Args a{(const unsigned short*)rows_f16k, (const unsigned short*)cols_f16k, dw, B, HW, CA / 16, CQ / 16, CA, CQ, ceil_div(CQ, 128), ceil_div(HW, W1_PX), 0, 0};
+    a.ntk = a.B * a.tpi;
+    const int base = ceil_div(CA, 128) * a.q_tiles;
+    // pixel splits: as many as keep the grid within ONE round of the 256 CUs -- every split adds a full output tile of float atomics
+    // (64 KiB per workgroup, ~13 us at the chip's atomic rate), which outweighs a second co-resident workgroup: 55 us per layer at
+    // 540 workgroups, 40 at 216 (1152 x 768 x 8192; MASIC_WGRAD1_WGS overrides the 256 for A/B timing)
+    static const int target = getenv("MASIC_WGRAD1_WGS") ? atoi(getenv("MASIC_WGRAD1_WGS")) : 256;
+    int nsplit = target / base;
+    if (nsplit > a.ntk) nsplit = a.ntk;
+    a.nsplit = nsplit < 1 ? 1 : nsplit;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad1x1_f16k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad1x1_f16k, dim3(base, 1, a.nsplit), dim3(256), 2 * W1_BUF, st, a);
+    return masic_launch_status("gemm_wgrad_f16k");
 }

@@ -1205,6 +1205,16 @@ def deconv_s2_as_conv_weight_dev(weight, bias=None):
     return w, b
 
 
+def gemm_wgrad_f16k(rows16, cols16, B, CA, CQ, HW):
+    """dw [CA, CQ] = sum_{b,p} rows[b, a, p] * cols[b, q, p] from F16K operands (masic_gemm_wgrad_f16k): the weight gradient of a 1x1
+    layer -- Conv2d: (dy, x) -> [Cout, Cin]; ConvTranspose2d(k=1): (x, dy) -> [Cin, Cout]."""
+    if rows16.dtype != torch.int16 or cols16.dtype != torch.int16 or rows16.numel() != B * CA * HW or cols16.numel() != B * CQ * HW:
+        raise RuntimeError("masic_amd.gemm_wgrad_f16k: F16K buffer sizes do not match (B, C, HW)")
+    dw = torch.empty((CA, CQ), dtype=torch.float32, device=rows16.device)
+    check(lib.masic_gemm_wgrad_f16k(_p(rows16), _p(cols16), _p(dw), B, CA, CQ, HW, _stream()), "gemm_wgrad_f16k")
+    return dw
+
+
 def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     """dW [Cout, Cin, 3, 3] (float32) of Conv2d(k3, s1, p1) from x and dy in F16K (bf16 operands, float32 accumulate)."""
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:

@@ -250,6 +250,46 @@ def test_gdn_backward_fused_f16k_operands(B, H, W, inverse):
         ops.gdn_bwd_fused_ex(x16, g16, shape, beta, gamma, want_nchw=False, want_f16k=False)
 
 
+@pytest.mark.parametrize("B,Cout,Cin,H,W", [(2, 1152, 768, 16, 24), (3, 96, 160, 7, 9), (1, 768, 960, 32, 32), (2, 32, 48, 5, 3)])
+def test_gemm_wgrad_f16k_1x1_layers(B, Cout, Cin, H, W):
+    """masic_gemm_wgrad_f16k -- the weight gradient of the 1x1 layers of the entropy-parameter stacks (reference MASIC.py:330-468) from
+    F16K operands -- against a float64 contraction of the bf16-rounded operands the kernel sees (ragged pixel counts: partial 64-pixel
+    tiles; channel counts that are not multiples of 128: partial output tiles), for the Conv2d orientation [Cout, Cin] and the
+    ConvTranspose2d(k=1) orientation [Cin, Cout]; and through ConvFn in the bf16 mode against the float32 NCHW kernel's result."""
+    from compressai.models.utils import conv, deconv
+    from masic_amd import autograd as ag, nn as mnn, ops
+    x = _rand(B, Cin, H, W, seed=1, scale=1.5)
+    dy = _rand(B, Cout, H, W, seed=2)
+    q = lambda t: t.bfloat16().double()
+    want = torch.einsum("bohw,bchw->oc", q(dy), q(x))
+    x16, g16 = ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV))
+    got = ops.gemm_wgrad_f16k(g16, x16, B, Cout, Cin, H * W).cpu().double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), "Conv2d orientation"
+    got_t = ops.gemm_wgrad_f16k(x16, g16, B, Cin, Cout, H * W).cpu().double()
+    assert float((got_t - want.t()).abs().max()) <= 2e-5 * float(want.abs().max()), "ConvTranspose2d orientation"
+    if Cin % 32 == 0 and Cout % 32 == 0:
+        mnn.set_precision("bf16")
+        try:
+            for mod, shape in ((conv(Cin, Cout, kernel_size=1, stride=1), (Cout, Cin, 1, 1)), (deconv(Cin, Cout, kernel_size=1, stride=1), (Cin, Cout, 1, 1))):
+                mod = mod.to(DEV)
+                xd = x.to(DEV).requires_grad_(True)
+                y = ag.conv(mod, xd, ops.ACT_LEAKY)
+                y.backward(dy.to(DEV))
+                new = mod.weight.grad.clone()
+                mod.weight.grad = None
+                xd2 = x.to(DEV).requires_grad_(True)
+                old_flag, ag._WGRAD1_F16K = ag._WGRAD1_F16K, False
+                try:
+                    ag.conv(mod, xd2, ops.ACT_LEAKY).backward(dy.to(DEV))
+                finally:
+                    ag._WGRAD1_F16K = old_flag
+                assert tuple(new.shape) == shape
+                assert_close(new, mod.weight.grad.cpu(), f"1x1 weight gradient through ConvFn {shape}", 2e-5)
+                assert torch.equal(xd.grad, xd2.grad)
+        finally:
+            mnn.set_precision("f32")
+
+
 def test_picture_end_input_gradients_f16k_forms():
     """bf16 mode, input gradients of the two picture-end layers (reference MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128, k5, s2), :550
     g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)) on the F16K kernels -- the depth-to-space transposed convolution and the
