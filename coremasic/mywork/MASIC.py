@@ -334,6 +334,8 @@ class _GmmHeads(nn.Module):
             for t in outs[1:] + [xf]:
                 _keep_until(t, cur)
             return tuple(outs)
+        if torch.is_grad_enabled() and _ag.gmm_heads_supported(self, x):
+            return _ag.gmm_heads(self, x)             # bf16-mode training: the nine layers as one autograd node on F16K
         sigma = self._branch(self.gmm_sigma, x, (_RELU, _RELU, _RELU))
         means = self._branch(self.gmm_means, x, (_LEAKY, _LEAKY, _NONE))
         logits = self._branch(self.gmm_weights, x, (_LEAKY, _LEAKY, _NONE))

@@ -562,6 +562,116 @@ def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True):
                                 want_f16k=want_f16k, want_sum=True)
 
 
+class GmmHeadsFn(Function):
+    """The entropy-parameter head of one view -- three stacks (sigma, means, mixture-weight logits) of three 1x1 layers on one input,
+    reference MASIC.py:330-468 -- as ONE autograd node of the bf16-mode training step, everything between its input and its three
+    outputs in F16K:
+      forward   x -> F16K once (read by the three stacks); layer i of the three stacks is one grouped GEMM launch (ops.gemm_f16k_group);
+                the last layer writes float32 NCHW.  Saved: x and the six intermediate activations in F16K, the three outputs.
+      backward  per level, last to first: act' mask (float32 elementwise on the outputs' gradients, F16K masks below), bias gradient
+                (channel sums), weight gradient from the two F16K operands (masic_gemm_wgrad_f16k), input gradients of the three stacks as
+                one grouped GEMM on the transposed weights; the three stacks' input gradients are summed at the end.
+    Against one ConvFn per layer: 4 forward launches instead of 36, no float32 NCHW round trip between layers, 3 conversions of a
+    gradient instead of 18.  Gradients travel between the layers in bf16, as the operands of the per-layer GEMMs do anyway."""
+
+    @staticmethod
+    def forward(ctx, x, head, *params):
+        x = _c(x)
+        B, _, H, W = x.shape
+        x16 = ops.nchw_to_f16k(x)
+        t, inter = [x16, x16, x16], []
+        for i in range(3):
+            layers = []
+            for k, (name, _, acts) in enumerate(head._STACKS):
+                layer = getattr(head, name)[2 * i]
+                layers.append(dict(x=t[k], wp=layer.packed_gemm_dma_weight(), bias=None if layer.bias is None else layer.bias.detach(),
+                                   Cin=layer.in_channels, Cout=layer.out_channels, act=acts[i], out="nchw" if i == 2 else "f16k"))
+            t = ops.gemm_f16k_group(layers, B, H, W)
+            if i < 2:
+                inter += t
+        ctx.head, ctx.shape = head, (B, H, W)
+        ctx.save_for_backward(*params, x16, *inter, *t)
+        return tuple(t)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        head = ctx.head
+        B, H, W = ctx.shape
+        HW = H * W
+        params, rest = ctx.saved_tensors[:18], ctx.saved_tensors[18:]
+        x16, t0, t1, ys = rest[0], rest[1:4], rest[4:7], rest[7:10]
+        stacks = head._STACKS
+        mods = [[getattr(head, name)[2 * i] for i in range(3)] for name, _, _ in stacks]
+        slope = lambda act: 0.01 if act == ops.ACT_LEAKY else 0.0
+        grads = [None] * 18
+
+        def wgrad(mod, a16, g16):                  # dW in the module's weight layout
+            Cin, Cout = mod.in_channels, mod.out_channels
+            dw = ops.gemm_wgrad_f16k(a16, g16, B, Cin, Cout, HW) if mod.transposed_conv else ops.gemm_wgrad_f16k(g16, a16, B, Cout, Cin, HW)
+            return dw.view(tuple(mod.weight.shape))
+
+        def dgrad(level, g16s, out):               # the three stacks' input gradients of one level: one grouped GEMM on W^T
+            layers = []
+            for k in range(3):
+                mod = mods[k][level]
+                wt = ops.pack_gemm_f16k_weight(params[6 * k + 2 * level].detach().contiguous(), mod.out_channels, mod.in_channels, not mod.transposed_conv)
+                layers.append(dict(x=g16s[k], wp=wt, bias=None, Cin=mod.out_channels, Cout=mod.in_channels, act=ops.ACT_NONE, out=out))
+            return ops.gemm_f16k_group(layers, B, H, W)
+
+        # level 2: the outputs' gradients arrive in float32 NCHW
+        g16 = []
+        for k, (_, _, acts) in enumerate(stacks):
+            g = gouts[k]
+            g = ops.zeros(ys[k].shape, torch.float32, ys[k].device) if g is None else _c(g)
+            if acts[2] != ops.ACT_NONE:
+                g = ops.elementwise(ops.EW_ACT_BWD, g, ys[k], s0=acts[2])
+            if mods[k][2].bias is not None:
+                grads[6 * k + 5] = ops.channel_sum(g)
+            g16.append(ops.nchw_to_f16k(g))
+            grads[6 * k + 4] = wgrad(mods[k][2], t1[k], g16[k])
+        for level, saved in ((1, t1), (0, t0)):
+            gin = dgrad(level + 1, g16, "f16k")
+            g16 = []
+            for k, (_, _, acts) in enumerate(stacks):
+                gm = gin[k] if acts[level] == ops.ACT_NONE else ops.f16k_act_bwd(gin[k], saved[k], slope(acts[level]))
+                g16.append(gm)
+                mod = mods[k][level]
+                if mod.bias is not None:
+                    grads[6 * k + 2 * level + 1] = ops.f16k_channel_sum(gm, B, mod.out_channels, HW)
+                grads[6 * k + 2 * level] = wgrad(mod, x16 if level == 0 else t0[k], gm)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            parts = dgrad(0, g16, "nchw")
+            gx = parts[0].add_(parts[1]).add_(parts[2])
+        return (gx, None) + tuple(grads)
+
+
+def gmm_heads_supported(head, x):
+    """bf16 mode (not fp8), every layer of the three stacks a biased 1x1 layer on the DMA-staged GEMM (channels multiples of 32)."""
+    from . import nn as _mnn
+    if _mnn._PRECISION != PREC_BF16 or _mnn._FP8 or not _GMM_HEADS_FN or x.dim() != 4:
+        return False
+    for name, _, _ in head._STACKS:
+        seq = getattr(head, name)
+        for i in (0, 2, 4):
+            m = seq[i]
+            if not (_gemm_1x1(m) and m.bias is not None):
+                return False
+    return True
+
+
+def gmm_heads(head, x):
+    params = []
+    for name, _, _ in head._STACKS:
+        seq = getattr(head, name)
+        for i in (0, 2, 4):
+            params += [seq[i].weight, seq[i].bias]
+    return GmmHeadsFn.apply(x, head, *params)
+
+
+_GMM_HEADS_FN = os.environ.get("MASIC_GMM_HEADS_FN", "1") != "0"     # 0: one ConvFn per head layer (A/B timing)
+
+
 class AnalysisFn(Function):
     """conv(3->128)+GDN, conv+GDN, conv+GDN, conv(128->M) of Encoder1 / Encoder2 (reference MASIC.py:510-531): x float32 NCHW -> y float32 NCHW."""
 

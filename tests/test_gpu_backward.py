@@ -290,6 +290,49 @@ def test_gemm_wgrad_f16k_1x1_layers(B, Cout, Cin, H, W):
             mnn.set_precision("f32")
 
 
+@pytest.mark.parametrize("which", ["y1", "y2"])
+def test_gmm_heads_fused_node_vs_per_layer_nodes(which, monkeypatch):
+    """bf16-mode training: the entropy-parameter head (reference MASIC.py:330-468, nine 1x1 layers) as ONE autograd node on F16K
+    (masic_amd.autograd.GmmHeadsFn: grouped GEMMs forward and for the input gradients, F16K weight gradients) against one ConvFn per
+    layer: identical forward results (same GEMM kernel, same roundings), gradients of all 18 parameters and of the input within the
+    bf16 operand noise of the two orders of rounding (relative L2 error <= 1 %, cosine >= 0.9999)."""
+    import MASIC
+    from masic_amd import autograd as ag, nn as mnn, synth
+    N, M, K = 32, 32, 5
+    cls = MASIC.gmm_hyper_y1_same_resolution if which == "y1" else MASIC.gmm_hyper_y2_same_resolution
+    head = cls(N, M, K)
+    head.load_state_dict(synth.synth_state_dict(head.state_dict(), seed=8))
+    head = head.to(DEV).train()
+    B, H, W = 2, 12, 20
+    x0 = torch.randn(B, (4 if which == "y1" else 5) * M, H, W, generator=torch.Generator().manual_seed(4)).to(DEV)
+    gs = [torch.randn(B, M * K, H, W, generator=torch.Generator().manual_seed(10 + i)).to(DEV) for i in range(3)]
+    mnn.set_precision("bf16")
+    res = {}
+    try:
+        for fused in (False, True):
+            monkeypatch.setattr(ag, "_GMM_HEADS_FN", fused)
+            head.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            assert ag.gmm_heads_supported(head, x) == fused
+            outs = head.heads(x)
+            torch.autograd.backward(outs, gs)
+            res[fused] = ([o.detach().clone() for o in outs], x.grad.clone(), {n: p.grad.clone() for n, p in head.named_parameters()})
+    finally:
+        mnn.set_precision("f32")
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b), "forward: the same GEMM kernel on the same operands"
+
+    def check(name, a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert rel <= 1e-2 and cos >= 0.9999, (name, rel, cos)
+    check("input gradient", res[True][1], res[False][1])
+    assert len(res[True][2]) == 18
+    for n in res[False][2]:
+        check(n, res[True][2][n], res[False][2][n])
+
+
 def test_picture_end_input_gradients_f16k_forms():
     """bf16 mode, input gradients of the two picture-end layers (reference MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128, k5, s2), :550
     g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)) on the F16K kernels -- the depth-to-space transposed convolution and the
