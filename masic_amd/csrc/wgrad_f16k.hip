@@ -42,8 +42,10 @@ struct Wg3Args {
     const unsigned short* x16;    // x   F16K [B][CQ16][H*W][16]
     float* ws;                    // [9][CA][CQ] float32, zeroed by the caller
     int B, H, W, CA16, CQ16, CA, CQ;
-    int a0, q0;                   // first output / input channel of this launch's channel group
+    int a0, q0;                   // first output / input channel of this launch's first channel group
     int tiles_w, tiles_h, ntiles;
+    int gq;                       // channel groups of this launch: blockIdx.y = ga * gq + gq_i, group (a0 + 96 ga, q0 + 64 gq_i) -- equally
+                                  //   shaped groups share a launch (a 192 -> 192 layer: 6 groups, at latent resolution 64 workgroups each)
 };
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_wave_base, int voffset, int soffset) {
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qb = wave / 3, kh = wave - 3 * qb;
     const int HW = a.H * a.W;
+    const int ga0 = a.a0 + 96 * ((int)blockIdx.y / a.gq), gq0 = a.q0 + 64 * ((int)blockIdx.y % a.gq);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g16, 0, a.B * a.CA16 * HW * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, 0, a.B * a.CQ16 * HW * 32, 0x00020000);
 
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
             if (!real || i >= NI) {
                 dma16(rg, lds + NBUF * BUF, 0x7ffffff0, 0);
             } else if (d_isx[j]) {
-                if (d_live[j]) dma16(rx, lds + buf * BUF + d_lds[j], voff, ((b * a.CQ16 + (a.q0 >> 4) + d_blk[j]) * HW) * 32);
+                if (d_live[j]) dma16(rx, lds + buf * BUF + d_lds[j], voff, ((b * a.CQ16 + (gq0 >> 4) + d_blk[j]) * HW) * 32);
             } else {
-                dma16(rg, lds + buf * BUF + d_lds[j], voff, ((b * a.CA16 + (a.a0 >> 4) + d_blk[j]) * HW) * 32);
+                dma16(rg, lds + buf * BUF + d_lds[j], voff, ((b * a.CA16 + (ga0 >> 4) + d_blk[j]) * HW) * 32);
             }
         }
     };
@@ -196,16 +199,16 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
 
     // ---- reduce into ws[tap][co][ci]: accumulator row (co) = 8 (e >> 2) + 4 h + (e & 3), column (ci) = lane & 31
     const int j = lane & 31, h = lane >> 5;
-    const int ci = a.q0 + qb * 32 + j;
+    const int ci = gq0 + qb * 32 + j;
     if (ci < a.CQ) {
 #pragma unroll
         for (int m = 0; m < MA; ++m)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                float* wp = a.ws + ((size_t)(kh * 3 + kw) * a.CA + a.a0 + m * 32 + 4 * h) * a.CQ + ci;
+                float* wp = a.ws + ((size_t)(kh * 3 + kw) * a.CA + ga0 + m * 32 + 4 * h) * a.CQ + ci;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int co = a.a0 + m * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+                    const int co = ga0 + m * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
                     if (co < a.CA) atomicAdd(wp + (size_t)((e & 3) + 8 * (e >> 2)) * a.CQ, acc[m][kw][e]);
                 }
             }
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
 }
 
 template <int MA, int NQ>
-void launch(const Wg3Args& a, int grid, hipStream_t st) {
+void launch(const Wg3Args& a, int grid, int groups, hipStream_t st) {
     auto kfn = wgrad3x3_f16k<MA, NQ>;
     static bool attr_set = false;
     constexpr size_t lds = 3 * (size_t)(2 * MA * GP + 2 * NQ * XP) + 1024;
@@ -345,7 +348,7 @@ void launch(const Wg3Args& a, int grid, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NQ * 3 * 64), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid, groups), dim3(NQ * 3 * 64), lds, st, a);
 }
 
 }  // namespace
@@ -374,21 +377,26 @@ extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
               ceil_div(W, TC), ceil_div(H, TR), 0};
     a.ntiles = a.tiles_w * a.tiles_h * B;
     // channel groups of up to 96 output x 64 input channels (6 waves: at most two per SIMD, so the 9 accumulator tiles of a wave
-    // fit its register budget); each group: one workgroup per CU taking a strided share of the pixel tiles
-    for (int a0 = 0; a0 < Cout; a0 += 96)
-        for (int q0 = 0; q0 < Cin; q0 += 64) {
-            a.a0 = a0; a.q0 = q0;
-            const int ma = (Cout - a0 >= 96 ? 96 : Cout - a0) / 32, nq = (Cin - q0 >= 64 ? 64 : Cin - q0) / 32;
-            const int grid = a.ntiles < 256 ? a.ntiles : 256;
-            switch (ma * 4 + nq) {
-                case 1 * 4 + 1: launch<1, 1>(a, grid, st); break;
-                case 1 * 4 + 2: launch<1, 2>(a, grid, st); break;
-                case 2 * 4 + 1: launch<2, 1>(a, grid, st); break;
-                case 2 * 4 + 2: launch<2, 2>(a, grid, st); break;
-                case 3 * 4 + 1: launch<3, 1>(a, grid, st); break;
-                default: launch<3, 2>(a, grid, st); break;
-            }
+    // fit its register budget); each group: one workgroup per CU taking a strided share of the pixel tiles.  Equally shaped groups
+    // -- (full, full), (remainder, full), (full, remainder), (remainder, remainder) -- go out as ONE launch each (blockIdx.y).
+    const int na = Cout / 96, ra = (Cout % 96) / 32, nqf = Cin / 64, rq = (Cin % 64) / 32;
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    auto go = [&](int a0, int q0, int ma, int nq, int ga, int gq) {
+        if (ga <= 0 || gq <= 0 || ma <= 0 || nq <= 0) return;
+        a.a0 = a0; a.q0 = q0; a.gq = gq;
+        switch (ma * 4 + nq) {
+            case 1 * 4 + 1: launch<1, 1>(a, grid, ga * gq, st); break;
+            case 1 * 4 + 2: launch<1, 2>(a, grid, ga * gq, st); break;
+            case 2 * 4 + 1: launch<2, 1>(a, grid, ga * gq, st); break;
+            case 2 * 4 + 2: launch<2, 2>(a, grid, ga * gq, st); break;
+            case 3 * 4 + 1: launch<3, 1>(a, grid, ga * gq, st); break;
+            default: launch<3, 2>(a, grid, ga * gq, st); break;
         }
+    };
+    go(0, 0, 3, 2, na, nqf);
+    go(96 * na, 0, ra, 2, 1, nqf);
+    go(0, 64 * nqf, 3, rq, na, 1);
+    go(96 * na, 64 * nqf, ra, rq, 1, 1);
     const int AQ = Cin * Cout;
     int tb = (9 * AQ + 255) / 256;
     if (tb > 2048) tb = 2048;
