@@ -280,6 +280,7 @@ int masic_f16k_gate(const void* src, const float* gate, const float* minv, void*
                     int dst_ctot, int dst_coff, int gate_ctot, int gate_c, void* stream);
 int masic_nchw_to_f16k_view(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, void* stream);
 int masic_f16k_to_nchw(const void* x, float* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream);
+int masic_f16k_to_nchw_bf16(const void* x, void* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream);   /* y: bf16 NCHW */
 
 size_t masic_conv_a_packed_bytes(void);
 int masic_conv_a_pack_weight(const float* w, void* w_packed, void* stream);
@@ -406,6 +407,12 @@ int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspa
  * last pass of the call re-zeroes what it reads), so a training step's ~80 weight gradients need no fill launch each. */
 int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, void* workspace, const masic_conv_desc_t* d, int workspace_clean,
                           void* stream);
+/* The 5x5 stride-2 layers of the bf16 mode with bf16 NCHW operands (x: [B][in_ctot][Hi][Wi], dy: [B][Cout][Ho][Wo], both bf16): the
+ * GDN backward writes dx that way (masic_gdn_bwd_fused_ex2) and the saved F16K activations are converted that way
+ * (masic_f16k_to_nchw_bf16) -- half the bytes of the float32 tensors on every side of the kernel. */
+int masic_conv2d_wgrad_bf16in_supported(const masic_conv_desc_t* d);
+int masic_conv2d_wgrad_bf16in(const void* x_bf16, const void* dy_bf16, float* dw, void* workspace, const masic_conv_desc_t* d,
+                              int workspace_clean, void* stream);
 
 /* y = op(a, b) elementwise over n floats; ops (s0,s1 scalars):
  *   0 act_bwd (a=grad, b=activation output, s0=MASIC_ACT_*)   1 abs_bwd (a=grad, b=x)   2 square   3 abs
@@ -443,6 +450,10 @@ int masic_gdn_bwd_fused(const float* x, const float* g, const float* beta, const
 int masic_gdn_bwd_fused_ex(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
                            float* gx, void* gx_f16k, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
                            int B, int C, int H, int W, int inverse, double beta_min, void* stream);
+/* ... with one more output: gx_bf16 (or NULL) = dx as bf16 NCHW [B][128][H][W], the operand of masic_conv2d_wgrad_bf16in. */
+int masic_gdn_bwd_fused_ex2(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
+                            float* gx, void* gx_f16k, void* gx_bf16, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
+                            int B, int C, int H, int W, int inverse, double beta_min, void* stream);
 /* GaussianMixtureConditional_gf backward (entropy_models.py:808-858 + both LowerBound rules, bound_ops.py:40-42).
  * y_hat as returned by the forward; g_yhat may be NULL; weights_are_logits as in the forward. */
 int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,

@@ -103,6 +103,7 @@ SIGNATURES = {
     "masic_f16k_gate": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "masic_nchw_to_f16k_view": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "masic_f16k_to_nchw": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
+    "masic_f16k_to_nchw_bf16": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     # fp8 operand path
     "masic_f8k_bytes": (c_size_t, [c_int, c_int, c_int]),
     "masic_nchw_to_f8k": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -138,6 +139,8 @@ SIGNATURES = {
     "masic_conv2d_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "masic_conv2d_wgrad": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv2d_wgrad_ws": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), c_int, _P]),
+    "masic_conv2d_wgrad_bf16in_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "masic_conv2d_wgrad_bf16in": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), c_int, _P]),
     "masic_elementwise": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, c_float, _P]),
     "masic_channel_sum_workspace_bytes": (c_size_t, [c_int]),
     "masic_channel_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -149,6 +152,7 @@ SIGNATURES = {
     "masic_gdn_bwd_fused_workspace_bytes": (c_size_t, []),
     "masic_gdn_bwd_fused": (c_int, [_P] * 8 + [c_int] * 5 + [c_double, _P]),
     "masic_gdn_bwd_fused_ex": (c_int, [_P] * 12 + [c_int] * 5 + [c_double, _P]),
+    "masic_gdn_bwd_fused_ex2": (c_int, [_P] * 13 + [c_int] * 5 + [c_double, _P]),
     "masic_gmm_likelihood_bwd": (c_int, [_P] * 10 + [c_int] * 6 + [c_float, c_float, _P]),
     "masic_entropy_bottleneck_bwd": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
     "masic_eb_table_split": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int), c_int, _P]),

@@ -125,7 +125,7 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
         if dx_f16k:
             return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=not (gx_f16k and Cin % 16 == 0))
-        return ops.conv2d(g, ops.pack_conv_weight(weight.detach(), d), None, d)
+        return ops.conv2d(g if g.dtype == torch.float32 else g.float(), ops.pack_conv_weight(weight.detach(), d), None, d)
 
     def parameter_gradients():
         gw = None
@@ -138,7 +138,7 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
         elif need_gw:
             dw = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
-            gw = ops.conv2d_wgrad(x, g, dw, tuple(weight.shape))
+            gw = ops.conv2d_wgrad(x, g, dw, tuple(weight.shape))        # (x and g both bf16 NCHW: the bf16-input kernel)
         if need_gb and gb_ is None:
             gb_ = ops.channel_sum(g)
         return gw, gb_ if need_gb else None
@@ -548,18 +548,28 @@ class RateDistortionFn(Function):
 # needs it (weight gradient: the layer's input; GDN backward: the GDN's input).  Gradients are those of the same function evaluated
 # on bf16-rounded activations; the float32 mode keeps the per-layer nodes (the parity path).
 _GDN_BWD_F16K = os.environ.get("MASIC_GDN_BWD_F16K", "1") != "0"
+_WGRAD_B16 = os.environ.get("MASIC_WGRAD_B16", "1") != "0" and _GDN_BWD_F16K     # 0: float32 NCHW operands for the 5x5 stride-2 weight gradients (A/B timing)
 
 
-def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True):
-    """GDN backward inside the fused transforms: (dx float32 NCHW, dx F16K | None, channel sums of dx | None, d beta, d gamma); u16: the
-    GDN's saved input (F16K), g: float32 NCHW or F16K."""
+def _wgrad_b16(mod, B, hw_in):
+    """True if the weight gradient of `mod` on an input of B x C x hw_in takes bf16 NCHW operands (ops.conv2d_wgrad_b16_supported)."""
+    if not _WGRAD_B16:
+        return False
+    kh, kw, s, p = mod._geometry()
+    return ops.conv2d_wgrad_b16_supported(ops.make_conv_desc(B, mod.in_channels, hw_in[0], hw_in[1], mod.out_channels, kh, kw, s, p,
+                                                             transposed=mod.transposed_conv, prec=PREC_BF16))
+
+
+def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True, want_b16=False):
+    """GDN backward inside the fused transforms: (dx NCHW -- float32, or bf16 with want_b16 --, dx F16K | None, channel sums of dx | None,
+    d beta, d gamma); u16: the GDN's saved input (F16K), g: float32 NCHW or F16K."""
     if not _GDN_BWD_F16K:
         B, C, H, W = shape
         g32 = g if g.dtype == torch.float32 else ops.f16k_to_nchw_dev(g, B, C, H, W)
         gx, gb, gg = gdn_backward(ops.f16k_to_nchw_dev(u16, B, C, H, W), g32, gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min)
         return gx, None, None, gb, gg
     return ops.gdn_bwd_fused_ex(u16, _c(g), shape, gdn.beta.detach(), gdn.gamma.detach(), gdn.inverse, gdn.beta_min, want_nchw=True,
-                                want_f16k=want_f16k, want_sum=True)
+                                want_f16k=want_f16k, want_sum=True, want_b16=want_b16 and _WGRAD_B16)
 
 
 class GmmHeadsFn(Function):
@@ -699,15 +709,16 @@ class AnalysisFn(Function):
         convs = (enc.g_a_conv1, enc.g_a_conv2, enc.g_a_conv3, enc.g_a_conv4)
         gdns = (enc.g_a_gdn1, enc.g_a_gdn2, enc.g_a_gdn3)
         B = x.shape[0]
-        nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
+        nchw = lambda t16, hw, bf16=False: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1], bf16=bf16)
         grads = {}
         # The GDN backward reads its saved input (and the gradient, when an F16K kernel produced it) as F16K and writes dx twice --
         # float32 NCHW for the weight-gradient kernel, F16K for the input-gradient convolution -- plus dx's channel sums (the bias
         # gradient): no F16K -> NCHW pass on u, no NCHW -> F16K pass and no reduction pass on dx.  MASIC_GDN_BWD_F16K=0: the separate passes.
         gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE, gx_f16k=_GDN_BWD_F16K)
         for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
-            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i])
-            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE,
+            b16 = _wgrad_b16(convs[i], B, hw_in)       # the weight gradient's two operands as bf16 NCHW: half the bytes on every side of it
+            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i], want_b16=b16)
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in, b16), convs[i].weight, None, gu, ops.ACT_NONE,
                                                                                 g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
         gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0], want_f16k=ctx.needs_input_grad[0])
         gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], g16=gu16, gb=gsum)
@@ -769,12 +780,13 @@ class SynthesisFn(Function):
         convs = (dec.g_s_conv1, dec.g_s_conv2, dec.g_s_conv3, dec.g_s_conv4)
         gdns = (dec.g_s_gdn1, dec.g_s_gdn2, dec.g_s_gdn3)
         B = y_hat.shape[0]
-        nchw = lambda t16, hw: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1])
+        nchw = lambda t16, hw, bf16=False: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1], bf16=bf16)
         grads = {}
         gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE, gx_f16k=_GDN_BWD_F16K)
         for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
-            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i])
-            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in), convs[i].weight, None, gu, ops.ACT_NONE,
+            b16 = _wgrad_b16(convs[i], B, hw_in)       # the weight gradient's two operands as bf16 NCHW: half the bytes on every side of it
+            gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i], want_b16=b16)
+            gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in, b16), convs[i].weight, None, gu, ops.ACT_NONE,
                                                                                 g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
         gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0])
         gy, grads["w1"], grads["b1"] = conv_backward(convs[0], y_hat, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0],

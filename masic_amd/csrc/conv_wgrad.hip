@@ -503,6 +503,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_1x1_bf16(const Wgrad1x1Args a)
 constexpr int W5_PP = 144, W5_QP = 1360, W5_ROW = 192, W5_PLANE = 96;
 constexpr int W5_LDS = 64 * W5_PP + 32 * W5_QP;
 
+// IN16: P and Q are bf16 NCHW tensors (masic_conv2d_wgrad_bf16in: the GDN backward writes dx that way, the saved F16K activation is
+// converted that way) -- 8-byte loads of 4 pixels instead of 16-byte ones, no conversion on the way into LDS, half the L2 -> CU stream
+// that bounds this kernel
+template <bool IN16>
 __global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[W5_LDS];
     unsigned char* const pl = lds;
@@ -526,7 +530,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
     const bool q_thread = tid < 504;
     unsigned char* const p_dst = pl + p_ch * W5_PP + p_rr * 64 + p_run * 8;
     unsigned char* const q_dst = ql + q_grp * W5_QP + q_rr * W5_ROW + (2 * q_i + 6) * 2;       // plane entry e + 7, e = 2i - 1
-    float4 rp[2], rq[8];
+    typedef typename std::conditional<IN16, uint2, float4>::type ld_t;      // 4 consecutive pixels of one channel row
+    typedef typename std::conditional<IN16, unsigned short, float>::type el_t;
+    const el_t* const Pp = reinterpret_cast<const el_t*>(a.P);
+    const el_t* const Qp = reinterpret_cast<const el_t*>(a.Q);
+    ld_t rp[2], rq[8];
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
@@ -534,37 +542,49 @@ __global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
         {
             const int r = r0 + p_rr, c = c0 + 4 * p_run;
             const bool ok = r < a.Hc && c < a.Wc;
-            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff + a0 + p_ch) * cplane + (ok ? (size_t)r * a.Wc + c : 0);
+            const el_t* pb = Pp + ((size_t)b * a.p_ctot + a.p_coff + a0 + p_ch) * cplane + (ok ? (size_t)r * a.Wc + c : 0);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                rp[k] = (ok && a0 + p_ch + 32 * k < a.CA) ? *reinterpret_cast<const float4*>(pb + (size_t)(32 * k) * cplane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rp[k] = (ok && a0 + p_ch + 32 * k < a.CA) ? *reinterpret_cast<const ld_t*>(pb + (size_t)(32 * k) * cplane) : ld_t{};
         }
         {
             const int fh = 2 * r0 - 2 + q_rr, fw = 2 * c0 - 4 + 4 * q_i;
             const bool ok = q_thread && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
-            const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff + q0 + q_grp) * fplane + (ok ? (size_t)fh * a.Wf + fw : 0);
+            const el_t* qb = Qp + ((size_t)b * a.q_ctot + a.q_coff + q0 + q_grp) * fplane + (ok ? (size_t)fh * a.Wf + fw : 0);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                rq[k] = (ok && q0 + q_grp + 4 * k < a.CQ) ? *reinterpret_cast<const float4*>(qb + (size_t)(4 * k) * fplane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rq[k] = (ok && q0 + q_grp + 4 * k < a.CQ) ? *reinterpret_cast<const ld_t*>(qb + (size_t)(4 * k) * fplane) : ld_t{};
         }
     };
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
     auto stash = [&]() {
+        if constexpr (IN16) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            bf16x4_t v;
-            v[0] = (__bf16)rp[k].x; v[1] = (__bf16)rp[k].y; v[2] = (__bf16)rp[k].z; v[3] = (__bf16)rp[k].w;
-            *reinterpret_cast<bf16x4_t*>(p_dst + 32 * k * W5_PP) = v;
-        }
-        if (q_thread) {
+            for (int k = 0; k < 2; ++k) *reinterpret_cast<uint2*>(p_dst + 32 * k * W5_PP) = rp[k];
+            if (q_thread) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bf16x2_t ev, od;                                           // columns 2c0-4+4i .. +3 = even, odd, even, odd
-                ev[0] = (__bf16)rq[k].x; ev[1] = (__bf16)rq[k].z;
-                od[0] = (__bf16)rq[k].y; od[1] = (__bf16)rq[k].w;
-                *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP) = ev;
-                *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP + W5_PLANE) = od;
+                for (int k = 0; k < 8; ++k) {                              // (x, y) = pixels (0, 1), (2, 3): even plane 0, 2; odd plane 1, 3
+                    *reinterpret_cast<unsigned*>(q_dst + 4 * k * W5_QP) = (rq[k].x & 0xffffu) | (rq[k].y << 16);
+                    *reinterpret_cast<unsigned*>(q_dst + 4 * k * W5_QP + W5_PLANE) = (rq[k].x >> 16) | (rq[k].y & 0xffff0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                bf16x4_t v;
+                v[0] = (__bf16)rp[k].x; v[1] = (__bf16)rp[k].y; v[2] = (__bf16)rp[k].z; v[3] = (__bf16)rp[k].w;
+                *reinterpret_cast<bf16x4_t*>(p_dst + 32 * k * W5_PP) = v;
+            }
+            if (q_thread) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bf16x2_t ev, od;                                           // columns 2c0-4+4i .. +3 = even, odd, even, odd
+                    ev[0] = (__bf16)rq[k].x; ev[1] = (__bf16)rq[k].z;
+                    od[0] = (__bf16)rq[k].y; od[1] = (__bf16)rq[k].w;
+                    *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP) = ev;
+                    *reinterpret_cast<bf16x2_t*>(q_dst + 4 * k * W5_QP + W5_PLANE) = od;
+                }
             }
         }
     };
@@ -668,8 +688,32 @@ extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, vo
 // workspace_clean != 0: `workspace` holds zeros on entry (a persistent buffer: zeroed once by its owner) and holds zeros again when the
 // call's last kernel has run -- no fill launch per weight gradient (a training step computes ~80 of them; a launch costs the device
 // ~10 us whatever it does).  0: contents unknown, zeroed here, left dirty (the behaviour of masic_conv2d_wgrad).
+namespace { int wgrad_launch(const void* x, const void* dy, float* dw, void* workspace, const masic_conv_desc_t* d, int workspace_clean, int in16, void* stream); }
 extern "C" int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, void* workspace,
                                      const masic_conv_desc_t* d, int workspace_clean, void* stream) {
+    return wgrad_launch(x, dy, dw, workspace, d, workspace_clean, 0, stream);
+}
+
+// 1 if masic_conv2d_wgrad_bf16in takes this layer: the 5x5 stride-2 layers of the analysis / synthesis / hyper transforms in bf16 mode
+extern "C" int masic_conv2d_wgrad_bf16in_supported(const masic_conv_desc_t* d) {
+    if (d == nullptr || d->prec != MASIC_PREC_BF16 || d->KH != 5 || d->KW != 5 || d->stride != 2 || d->pad != 2) return 0;
+    const int CQ = d->transposed ? d->Cout : d->Cin, Hf = d->transposed ? d->Ho : d->Hi, Wf = d->transposed ? d->Wo : d->Wi;
+    const int Hc = d->transposed ? d->Hi : d->Ho, Wc = d->transposed ? d->Wi : d->Wo;
+    return CQ > 8 && Wf % 8 == 0 && Wf == 2 * Wc && Hf == 2 * Hc;
+}
+
+// x, dy: bf16 NCHW tensors (x: [B][in_ctot][Hi][Wi] with the channel view of d, dy: [B][Cout][Ho][Wo]); only layers for which
+// masic_conv2d_wgrad_bf16in_supported(d); workspace as masic_conv2d_wgrad_ws.
+extern "C" int masic_conv2d_wgrad_bf16in(const void* x_bf16, const void* dy_bf16, float* dw, void* workspace,
+                                         const masic_conv_desc_t* d, int workspace_clean, void* stream) {
+    MASIC_REQUIRE(masic_conv2d_wgrad_bf16in_supported(d), MASIC_ERR_UNSUPPORTED, "conv2d_wgrad_bf16in: not a 5x5 stride-2 layer of the bf16 mode");
+    return wgrad_launch(x_bf16, dy_bf16, dw, workspace, d, workspace_clean, 1, stream);
+}
+
+namespace {
+int wgrad_launch(const void* xv, const void* dyv, float* dw, void* workspace, const masic_conv_desc_t* d, int workspace_clean, int in16, void* stream) {
+    const float* x = (const float*)xv;
+    const float* dy = (const float*)dyv;
     MASIC_REQUIRE(x && dy && dw && workspace && d, MASIC_ERR_ARG, "conv2d_wgrad: null pointer");
     MASIC_REQUIRE(d->KH * d->KW == 1 || d->KH * d->KW <= 28, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: kernel %dx%d", d->KH, d->KW);
     MASIC_REQUIRE(d->stride == 1 || d->stride == 2, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad: stride %d", d->stride);
@@ -732,13 +776,15 @@ extern "C" int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw,
             if (best < 0 || cost < best) { best = cost; nsplit = ns; }
         }
         a.nsplit = nsplit;
-        hipLaunchKernelGGL(conv_wgrad_k5s2_bf16, dim3(ncombo * nsplit), dim3(512), 0, st, a);
+        if (in16) hipLaunchKernelGGL(conv_wgrad_k5s2_bf16<true>, dim3(ncombo * nsplit), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_k5s2_bf16<false>, dim3(ncombo * nsplit), dim3(512), 0, st, a);
         const size_t total5 = (size_t)Tt * a.CA * a.CQ;
         int tb5 = (int)((total5 + 255) / 256);
         if (tb5 > 4096) tb5 = 4096;
         hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb5), dim3(256), 0, st, (float*)workspace, dw, Tt, a.CA * a.CQ, workspace_clean);
         return masic_launch_status("conv2d_wgrad");
     }
+    MASIC_REQUIRE(!in16, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad_bf16in: layer shape without a bf16-input kernel");
     if (a.CQ <= 8 && Tt > 1 && ncol_tiles <= 8) {          // few fine-side channels: (tap, q) pairs packed into the 32 MFMA columns
         a.q_tiles = 1;
         int nsplit = ceil_div(512, a_tiles);
@@ -776,3 +822,4 @@ extern "C" int masic_conv2d_wgrad_ws(const float* x, const float* dy, float* dw,
     hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, T, AQ, workspace_clean);
     return masic_launch_status("conv2d_wgrad");
 }
+}  // namespace

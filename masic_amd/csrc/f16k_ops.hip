@@ -96,18 +96,30 @@ __global__ __launch_bounds__(256) void nchw_to_f16k_view_kernel(const float* __r
     reinterpret_cast<uint4*>(y + (((size_t)b * (dst_ctot >> 4) + (dc8 >> 1)) * HW) * 16)[2 * (size_t)p + (dc8 & 1)] = q;
 }
 
-__global__ __launch_bounds__(256) void f16k_to_nchw_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int C, int HW,
+// OUT16: the result stays bf16 (NCHW): what the bf16-input form of the 5x5 stride-2 weight-gradient kernel reads (conv_wgrad.hip) --
+// half the bytes written here and read there
+template <bool OUT16>
+__global__ __launch_bounds__(256) void f16k_to_nchw_kernel(const unsigned short* __restrict__ x, void* __restrict__ yv, int C, int HW,
                                                            int src_ctot, int src_coff, int ctot, int coff) {
     const int b = blockIdx.z, c8 = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const int sc8 = (src_coff >> 3) + c8;
     const uint4 q = reinterpret_cast<const uint4*>(x + (((size_t)b * (src_ctot >> 4) + (sc8 >> 1)) * HW) * 16)[2 * (size_t)p + (sc8 & 1)];
-    const float v[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
-    float* yb = y + ((size_t)b * ctot + coff) * HW + p;
+    if constexpr (OUT16) {
+        const unsigned short v[8] = {(unsigned short)(q.x & 0xffff), (unsigned short)(q.x >> 16), (unsigned short)(q.y & 0xffff), (unsigned short)(q.y >> 16),
+                                     (unsigned short)(q.z & 0xffff), (unsigned short)(q.z >> 16), (unsigned short)(q.w & 0xffff), (unsigned short)(q.w >> 16)};
+        unsigned short* yb = (unsigned short*)yv + ((size_t)b * ctot + coff) * HW + p;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (c8 * 8 + i < C) yb[(size_t)(c8 * 8 + i) * HW] = v[i];
+        for (int i = 0; i < 8; ++i)
+            if (c8 * 8 + i < C) yb[(size_t)(c8 * 8 + i) * HW] = v[i];
+    } else {
+        const float v[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
+        float* yb = (float*)yv + ((size_t)b * ctot + coff) * HW + p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (c8 * 8 + i < C) yb[(size_t)(c8 * 8 + i) * HW] = v[i];
+    }
 }
 
 // g' = g * act'(y) on F16K buffers (y = the forward activation's output: its sign is the pre-activation's)
@@ -213,7 +225,17 @@ extern "C" int masic_f16k_to_nchw(const void* x, float* y, int B, int C, int HW,
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "f16k_to_nchw: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot && src_ctot % 16 == 0 && src_coff % 8 == 0 && src_coff >= 0 && src_coff + C <= src_ctot,
                   MASIC_ERR_SHAPE, "f16k_to_nchw: view out of range");
-    hipLaunchKernelGGL(f16k_to_nchw_kernel, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(f16k_to_nchw_kernel<false>, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)x, y, C, HW, src_ctot, src_coff, ctot, coff);
     return masic_launch_status("f16k_to_nchw");
+}
+
+// the same with a bf16 NCHW result (y: [B][ctot][HW] bf16)
+extern "C" int masic_f16k_to_nchw_bf16(const void* x, void* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream) {
+    MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "f16k_to_nchw_bf16: null pointer");
+    MASIC_REQUIRE(coff >= 0 && coff + C <= ctot && src_ctot % 16 == 0 && src_coff % 8 == 0 && src_coff >= 0 && src_coff + C <= src_ctot,
+                  MASIC_ERR_SHAPE, "f16k_to_nchw_bf16: view out of range");
+    hipLaunchKernelGGL(f16k_to_nchw_kernel<true>, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, y, C, HW, src_ctot, src_coff, ctot, coff);
+    return masic_launch_status("f16k_to_nchw_bf16");
 }

@@ -69,6 +69,7 @@ struct GdnBwdArgs {
     const unsigned short* x16;   // X16: x as F16K [B][8][HW][16] bf16 (then x is unused)
     const unsigned short* g16;   // G16: g as F16K
     unsigned short* gx16;        // dx as F16K too, or null (gx may then be null)
+    unsigned short* gxb;         // dx as bf16 NCHW (what the bf16-input 5x5 stride-2 weight-gradient kernel reads), or null
     const uint4* img;            // two fragment images + beta^
     float* part;                 // [GB_NBLK][GB_SLOT]
     long long npix;              // B * HW
@@ -221,6 +222,16 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) op[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = uv[m][e];
         }
+        if (ok && a.gxb != nullptr) {
+            unsigned short* ob = a.gxb + base;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const __bf16 bv = (__bf16)uv[m][e];
+                    ob[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = __builtin_bit_cast(unsigned short, bv);
+                }
+        }
         if (a.gx16 != nullptr) {
             // as conv_f16k.hip: store_f16k_tile -- the two halves of the wave swap their middle quarters so that lane (j, h) writes
             // the 8 consecutive channels 8h .. 8h+7 of each 16-channel record with one 16-byte store (every lane takes part in
@@ -319,8 +330,15 @@ extern "C" size_t masic_gdn_bwd_fused_workspace_bytes(void) {
 extern "C" int masic_gdn_bwd_fused_ex(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
                                       float* gx, void* gx_f16k, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
                                       int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
-    MASIC_REQUIRE(((x != nullptr) != (x_f16k != nullptr)) && ((g != nullptr) != (g_f16k != nullptr)) && (gx || gx_f16k), MASIC_ERR_ARG,
-                  "gdn_bwd_fused: exactly one of x / x_f16k and of g / g_f16k, at least one of gx / gx_f16k");
+    return masic_gdn_bwd_fused_ex2(x, x_f16k, g, g_f16k, beta, gamma, gx, gx_f16k, nullptr, g_sum, g_beta, g_gamma, workspace, B, C, H, W, inverse, beta_min, stream);
+}
+
+// ... and gx_bf16: dx as bf16 NCHW [B][128][H][W] (or NULL): the operand of masic_conv2d_wgrad_bf16in, half the bytes of gx
+extern "C" int masic_gdn_bwd_fused_ex2(const float* x, const void* x_f16k, const float* g, const void* g_f16k, const float* beta, const float* gamma,
+                                       float* gx, void* gx_f16k, void* gx_bf16, float* g_sum, float* g_beta, float* g_gamma, void* workspace,
+                                       int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    MASIC_REQUIRE(((x != nullptr) != (x_f16k != nullptr)) && ((g != nullptr) != (g_f16k != nullptr)) && (gx || gx_f16k || gx_bf16), MASIC_ERR_ARG,
+                  "gdn_bwd_fused: exactly one of x / x_f16k and of g / g_f16k, at least one of gx / gx_f16k / gx_bf16");
     MASIC_REQUIRE(beta && gamma && g_beta && g_gamma && workspace, MASIC_ERR_ARG, "gdn_bwd_fused: null pointer");
     MASIC_REQUIRE(C == 128, MASIC_ERR_UNSUPPORTED, "gdn_bwd_fused: C=%d (128 only; other widths use the unfused pieces)", C);
     MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W * 128 < (1ll << 31), MASIC_ERR_SHAPE, "gdn_bwd_fused: shape");
@@ -332,7 +350,7 @@ extern "C" int masic_gdn_bwd_fused_ex(const float* x, const void* x_f16k, const 
     hipLaunchKernelGGL(gdn_bwd_pack_kernel, dim3(16), dim3(256), 0, st, beta, gamma, img, beta_bound, gamma_bound, pedestal);
     GdnBwdArgs a{};
     a.x = x; a.g = g; a.gx = gx; a.img = img; a.part = part;
-    a.x16 = (const unsigned short*)x_f16k; a.g16 = (const unsigned short*)g_f16k; a.gx16 = (unsigned short*)gx_f16k;
+    a.x16 = (const unsigned short*)x_f16k; a.g16 = (const unsigned short*)g_f16k; a.gx16 = (unsigned short*)gx_f16k; a.gxb = (unsigned short*)gx_bf16;
     a.HW = H * W; a.npix = (long long)B * H * W; a.inverse = inverse; a.want_sum = g_sum != nullptr;
     a.ntiles = (int)((a.npix + 127) / 128);
     const int nblk = a.ntiles < GB_NBLK ? a.ntiles : GB_NBLK;

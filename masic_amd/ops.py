@@ -541,9 +541,10 @@ def gdn_bwd_fused(x, g, beta, gamma, inverse=False, beta_min=1e-6):
     return gx, g_beta, g_gamma
 
 
-def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, want_nchw=True, want_f16k=False, want_sum=True):
-    """gdn_bwd_fused with F16K operands (masic_gdn_bwd_fused_ex): x and g are float32 NCHW tensors or F16K int16 buffers of
-    shape = (B, 128, H, W); returns (dx float32 NCHW | None, dx F16K | None, channel sums of dx [128] | None, d beta, d gamma)."""
+def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, want_nchw=True, want_f16k=False, want_sum=True, want_b16=False):
+    """gdn_bwd_fused with F16K operands (masic_gdn_bwd_fused_ex2): x and g are float32 NCHW tensors or F16K int16 buffers of
+    shape = (B, 128, H, W); returns (dx float32 NCHW | None, dx F16K | None, channel sums of dx [128] | None, d beta, d gamma).
+    want_b16: the NCHW result is bf16 (torch.bfloat16, returned in the first slot) -- the operand of conv2d_wgrad_b16."""
     B, C, H, W = shape
     for t, name in ((x, "x"), (g, "g")):
         if not t.is_cuda or not t.is_contiguous():
@@ -553,26 +554,40 @@ def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, wan
                 raise RuntimeError(f"masic_amd.gdn_bwd_fused_ex: F16K buffer {name} does not hold {shape}")
         elif t.dtype != torch.float32 or tuple(t.shape) != tuple(shape):
             raise RuntimeError(f"masic_amd.gdn_bwd_fused_ex: {name} must be float32 {shape} or an F16K int16 buffer")
-    if not (want_nchw or want_f16k):
+    if not (want_nchw or want_f16k or want_b16):
         raise RuntimeError("masic_amd.gdn_bwd_fused_ex: no output requested")
     dev = x.device
     ws = _GDN_BWD_WS.get(dev)
     if ws is None:
         ws = _GDN_BWD_WS[dev] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
-    gx = torch.empty(shape, dtype=torch.float32, device=dev) if want_nchw else None
+    gx = torch.empty(shape, dtype=torch.float32, device=dev) if (want_nchw and not want_b16) else None
+    gxb = torch.empty(shape, dtype=torch.bfloat16, device=dev) if want_b16 else None
     gx16 = torch.empty(B * C * H * W, dtype=torch.int16, device=dev) if want_f16k else None
     g_sum = torch.empty(C, dtype=torch.float32, device=dev) if want_sum else None
     g_beta = torch.empty(C, dtype=torch.float32, device=dev)
     g_gamma = torch.empty(C, C, dtype=torch.float32, device=dev)
     x16, g16 = x.dtype == torch.int16, g.dtype == torch.int16
-    check(lib.masic_gdn_bwd_fused_ex(_p(None if x16 else x), _p(x if x16 else None), _p(None if g16 else g), _p(g if g16 else None),
-                                     _p(_dev(beta.contiguous())), _p(_dev(gamma.contiguous())), _p(gx), _p(gx16), _p(g_sum), _p(g_beta), _p(g_gamma),
-                                     _p(ws), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_bwd_fused_ex")
-    return gx, gx16, g_sum, g_beta, g_gamma
+    check(lib.masic_gdn_bwd_fused_ex2(_p(None if x16 else x), _p(x if x16 else None), _p(None if g16 else g), _p(g if g16 else None),
+                                      _p(_dev(beta.contiguous())), _p(_dev(gamma.contiguous())), _p(gx), _p(gx16), _p(gxb), _p(g_sum), _p(g_beta), _p(g_gamma),
+                                      _p(ws), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_bwd_fused_ex")
+    return (gxb if want_b16 else gx), gx16, g_sum, g_beta, g_gamma
+
+
+def conv2d_wgrad_b16_supported(desc):
+    """True if conv2d_wgrad takes bf16 NCHW operands for this layer (the 5x5 stride-2 layers of the bf16 mode)."""
+    return bool(lib.masic_conv2d_wgrad_bf16in_supported(ctypes.byref(desc)))
 
 
 def conv2d_wgrad(x, dy, desc, weight_shape):
-    _dev(x, "x"); _dev(dy, "dy")
+    """dW of the layer `desc` describes; x, dy float32 NCHW -- or BOTH torch.bfloat16 NCHW where conv2d_wgrad_b16_supported(desc)."""
+    b16 = isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16
+    if b16:
+        if not (x.is_cuda and x.is_contiguous() and isinstance(dy, torch.Tensor) and dy.is_cuda and dy.is_contiguous()):
+            raise RuntimeError("masic_amd.conv2d_wgrad: contiguous device tensors only")
+    else:
+        _dev(x, "x"); _dev(dy, "dy")
+    if b16 != (dy.dtype == torch.bfloat16) or (b16 and not conv2d_wgrad_b16_supported(desc)):
+        raise RuntimeError("masic_amd.conv2d_wgrad: bf16 operands need both tensors in bf16 and a layer conv2d_wgrad_b16_supported")
     if tuple(dy.shape) != (desc.B, desc.Cout, desc.Ho, desc.Wo):
         raise RuntimeError(f"masic_amd.conv2d_wgrad: dy {tuple(dy.shape)} does not match the descriptor")
     if tuple(x.shape) != (desc.B, desc.in_ctot, desc.Hi, desc.Wi):
@@ -583,7 +598,8 @@ def conv2d_wgrad(x, dy, desc, weight_shape):
         raise RuntimeError("masic_amd.conv2d_wgrad: weight shape does not match the descriptor")
     ws = _clean_workspace(x.device, dw.numel())
     try:
-        check(lib.masic_conv2d_wgrad_ws(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), 1, _stream()), "conv2d_wgrad")
+        fn = lib.masic_conv2d_wgrad_bf16in if b16 else lib.masic_conv2d_wgrad_ws
+        check(fn(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), 1, _stream()), "conv2d_wgrad")
     except Exception:
         _drop_workspace(x.device, dw.numel())          # an error part-way may have left it dirty
         raise
@@ -1029,13 +1045,15 @@ def nchw_to_f16k_view(x, dst16, dst_ctot, dst_coff, C=None, coff=0):
     return dst16
 
 
-def f16k_to_nchw_dev(x16, B, C, H, W, src_ctot=None, src_coff=0):
-    """F16K channel slice -> float32 NCHW (HIP kernel; `f16k_to_nchw` above is the torch-op form the tests use as a checker)."""
+def f16k_to_nchw_dev(x16, B, C, H, W, src_ctot=None, src_coff=0, bf16=False):
+    """F16K channel slice -> float32 NCHW, or bf16 NCHW (bf16=True: exact, no rounding -- F16K holds bf16) (HIP kernel; `f16k_to_nchw`
+    above is the torch-op form the tests use as a checker)."""
     src_ctot = C if src_ctot is None else src_ctot
     if x16.dtype != torch.int16 or x16.numel() != B * src_ctot * H * W:
         raise RuntimeError("masic_amd.f16k_to_nchw_dev: source buffer size mismatch")
-    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x16.device)
-    check(lib.masic_f16k_to_nchw(_p(x16), _p(y), B, C, H * W, src_ctot, src_coff, C, 0, _stream()), "f16k_to_nchw")
+    y = torch.empty((B, C, H, W), dtype=torch.bfloat16 if bf16 else torch.float32, device=x16.device)
+    fn = lib.masic_f16k_to_nchw_bf16 if bf16 else lib.masic_f16k_to_nchw
+    check(fn(_p(x16), _p(y), B, C, H * W, src_ctot, src_coff, C, 0, _stream()), "f16k_to_nchw")
     return y
 
 

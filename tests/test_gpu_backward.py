@@ -333,6 +333,36 @@ def test_gmm_heads_fused_node_vs_per_layer_nodes(which, monkeypatch):
         check(n, res[True][2][n], res[False][2][n])
 
 
+@pytest.mark.parametrize("transposed,B,Cin,Cout,H,W", [(False, 2, 128, 128, 32, 48), (True, 2, 128, 128, 16, 24), (False, 1, 128, 192, 64, 64), (True, 3, 192, 128, 8, 8)])
+def test_conv_wgrad_bf16_nchw_operands(transposed, B, Cin, Cout, H, W):
+    """masic_conv2d_wgrad_bf16in: the 5x5 stride-2 weight-gradient kernel reading bf16 NCHW operands (what masic_gdn_bwd_fused_ex2 and
+    masic_f16k_to_nchw_bf16 write) must equal the float32-operand call on the same bf16-representable values (the float32 form rounds to
+    bf16 on its way into LDS: identical operands, identical arithmetic) -- up to the order of the float atomics.  Plus the two producers:
+    f16k_to_nchw(bf16=True) is exact, gdn_bwd_fused_ex(want_b16=True) is the bf16 rounding of its float32 output."""
+    from masic_amd import ops, synth, _lib
+    x = _rand(B, Cin, H, W, seed=3).bfloat16()
+    d = ops.make_conv_desc(B, Cin, H, W, Cout, 5, 5, 2, 2, transposed=transposed, prec=_lib.PREC_BF16)
+    dy = _rand(B, Cout, d.Ho, d.Wo, seed=4).bfloat16()
+    assert ops.conv2d_wgrad_b16_supported(d)
+    shape = (Cin, Cout, 5, 5) if transposed else (Cout, Cin, 5, 5)
+    ref = ops.conv2d_wgrad(x.float().to(DEV), dy.float().to(DEV), d, shape)
+    got = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), d, shape)
+    assert_close(got, ref.cpu(), "bf16 NCHW operands vs float32 operands", 1e-5)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_wgrad(x.to(DEV), dy.float().to(DEV), d, shape)                       # mixed operand types
+    d3 = ops.make_conv_desc(B, Cin, H, W, Cout, 3, 3, 1, 1, prec=_lib.PREC_BF16)
+    assert not ops.conv2d_wgrad_b16_supported(d3)
+    if Cin == 128 and not transposed:
+        x16 = ops.nchw_to_f16k(x.float().to(DEV))
+        assert torch.equal(ops.f16k_to_nchw_dev(x16, B, Cin, H, W, bf16=True).cpu(), x)
+        rs = np.random.RandomState(5)
+        beta, gamma = synth.synth_tensor("g.beta", (128,), rs).to(DEV), synth.synth_tensor("g.gamma", (128, 128), rs).to(DEV)
+        g = _rand(B, 128, H, W, seed=6).to(DEV)
+        a = ops.gdn_bwd_fused_ex(x16, g, (B, 128, H, W), beta, gamma, want_nchw=True, want_f16k=False, want_sum=False)
+        b = ops.gdn_bwd_fused_ex(x16, g, (B, 128, H, W), beta, gamma, want_nchw=True, want_f16k=True, want_sum=True, want_b16=True)
+        assert b[0].dtype == torch.bfloat16 and torch.equal(b[0], a[0].bfloat16()) and torch.equal(b[3], a[3]) and torch.equal(b[4], a[4])
+
+
 def test_picture_end_input_gradients_f16k_forms():
     """bf16 mode, input gradients of the two picture-end layers (reference MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128, k5, s2), :550
     g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)) on the F16K kernels -- the depth-to-space transposed convolution and the
