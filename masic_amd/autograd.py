@@ -30,6 +30,18 @@ def _gemm_1x1(mod, act=0):
             and mod.in_channels % 32 == 0 and mod.out_channels % 32 == 0 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY))
 
 
+_FWD_F16K = os.environ.get("MASIC_TRAIN_FWD_F16K", "1") != "0"      # 0: training-mode forward of the hyper / context layers on the NCHW kernel (A/B timing)
+
+
+def _fwd_f16k(mod, x, act):
+    from . import nn as _mnn
+    if not _FWD_F16K or _mnn._PRECISION == PREC_F32 or _mnn._FP8 or x.dim() != 4 or x.shape[1] != mod.in_channels:
+        return False
+    kh, kw, _, _ = mod._geometry()
+    return (kh * kw > 1 and mod.in_channels % 16 == 0 and mod.out_channels % 32 == 0 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY)
+            and mod.f16k_supported(x.shape[0], x.shape[2], x.shape[3]))
+
+
 _GEMM_1X1 = os.environ.get("MASIC_TRAIN_GEMM_1X1", "1") != "0"      # 0: 1x1 layers of the training step on the implicit-GEMM kernel (A/B timing)
 
 
@@ -49,6 +61,14 @@ class ConvFn(Function):
             y = ops.gemm_f16k(x16, mod.packed_gemm_dma_weight(), None if bias is None else bias.detach(), B, mod.in_channels,
                               mod.out_channels, H, W, act, want_nchw=True)
             ctx.x16 = x16 if _WGRAD1_F16K else None          # kept for the weight gradient (masic_gemm_wgrad_f16k)
+        elif _fwd_f16k(mod, x, act):
+            # bf16 mode, the hyper transforms and context models (3x3 / 5x5, 128 ... 384 channels at latent resolution): the DMA-staged
+            # F16K kernel of inference (x converted once; the 3x3 weight gradient reads the same F16K copy) instead of the NCHW
+            # implicit-GEMM kernel -- 38 against 54 ... 70 us per layer at 8 x 32 x 32
+            B, _, H, W = x.shape
+            x16 = ops.nchw_to_f16k(x)
+            y = mod.run_f16k(x16, B, H, W, act=act, want_nchw=True)[0]
+            ctx.x16 = x16
         else:
             y = mod.run(x, act=act)
             ctx.x16 = None
