@@ -108,6 +108,8 @@ int masic_gemm1x1_bf16_fwd(const void* x_f16k, const void* w_packed, const float
  * Cout % 32 == 0; own weight pack (per 128-channel block, 64-channel chunks in LDS-image order). */
 size_t masic_gemm_f16k_packed_bytes(int Cin, int Cout);
 int masic_gemm_f16k_pack_weight(const float* w, void* wp, int Cin, int Cout, int transposed, void* stream);
+/* n (<= 18) such packs in one launch: the nine layers of an entropy-parameter head, forward and transposed (training step) */
+int masic_gemm_f16k_pack_weights(const float* const* w, void* const* wp, const int* Cin, const int* Cout, const int* transposed, int n, void* stream);
 int masic_gemm_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, void* y_f16k, float* y_nchw,
                         int B, int Cin, int Cout, int HW, int out_ctot, int out_coff, int act, void* stream);
 /* Up to three such layers over the same B x HW pixels in ONE launch: layer i of the sigma / means / weights stacks of a GMM head

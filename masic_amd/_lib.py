@@ -50,6 +50,7 @@ SIGNATURES = {
     "masic_nchw_to_f16k_op": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_gemm_f16k_packed_bytes": (c_size_t, [c_int, c_int]),
     "masic_gemm_f16k_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "masic_gemm_f16k_pack_weights": (c_int, [ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, _P]),
     "masic_gemm_f16k_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "masic_gemm_f16k_group_fwd": (c_int, [ctypes.POINTER(GemmGroup), c_int, c_int, c_int, _P]),
     "masic_conv_f16k_supported": (c_int, [_P]),

@@ -609,12 +609,19 @@ class GmmHeadsFn(Function):
         x = _c(x)
         B, _, H, W = x.shape
         x16 = ops.nchw_to_f16k(x)
+        # all 18 weight packs of the node -- every layer for its forward GEMM and, transposed, for its input-gradient GEMM -- in one launch
+        mods = [getattr(head, name)[2 * i] for name, _, _ in head._STACKS for i in range(3)]
+        wds = [params[2 * n].detach().contiguous() for n in range(9)]
+        jobs = ([(w, m.in_channels, m.out_channels, m.transposed_conv) for w, m in zip(wds, mods)] +
+                [(w, m.out_channels, m.in_channels, not m.transposed_conv) for w, m in zip(wds, mods)])
+        packs = ops.pack_gemm_f16k_weights(jobs) if _HEADS_MULTIPACK else [ops.pack_gemm_f16k_weight(*j) for j in jobs]
+        ctx.wt_packs = packs[9:]
         t, inter = [x16, x16, x16], []
         for i in range(3):
             layers = []
             for k, (name, _, acts) in enumerate(head._STACKS):
                 layer = getattr(head, name)[2 * i]
-                layers.append(dict(x=t[k], wp=layer.packed_gemm_dma_weight(), bias=None if layer.bias is None else layer.bias.detach(),
+                layers.append(dict(x=t[k], wp=packs[3 * k + i], bias=None if layer.bias is None else layer.bias.detach(),
                                    Cin=layer.in_channels, Cout=layer.out_channels, act=acts[i], out="nchw" if i == 2 else "f16k"))
             t = ops.gemm_f16k_group(layers, B, H, W)
             if i < 2:
@@ -644,8 +651,7 @@ class GmmHeadsFn(Function):
             layers = []
             for k in range(3):
                 mod = mods[k][level]
-                wt = ops.pack_gemm_f16k_weight(params[6 * k + 2 * level].detach().contiguous(), mod.out_channels, mod.in_channels, not mod.transposed_conv)
-                layers.append(dict(x=g16s[k], wp=wt, bias=None, Cin=mod.out_channels, Cout=mod.in_channels, act=ops.ACT_NONE, out=out))
+                layers.append(dict(x=g16s[k], wp=ctx.wt_packs[3 * k + level], bias=None, Cin=mod.out_channels, Cout=mod.in_channels, act=ops.ACT_NONE, out=out))
             return ops.gemm_f16k_group(layers, B, H, W)
 
         # level 2: the outputs' gradients arrive in float32 NCHW
@@ -699,6 +705,7 @@ def gmm_heads(head, x):
     return GmmHeadsFn.apply(x, head, *params)
 
 
+_HEADS_MULTIPACK = os.environ.get("MASIC_HEADS_MULTIPACK", "1") != "0"     # 0: one pack launch per weight and orientation (A/B timing)
 _GMM_HEADS_FN = os.environ.get("MASIC_GMM_HEADS_FN", "1") != "0"     # 0: one ConvFn per head layer (A/B timing)
 
 

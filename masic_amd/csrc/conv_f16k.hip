@@ -1713,6 +1713,56 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmGrou
 
 }  // namespace
 
+// Up to 18 weight packs in one launch (blockIdx.y = job): the nine 1x1 layers of an entropy-parameter head, each for the forward GEMM
+// and -- transposed -- for the input-gradient GEMM of the training step, whose weights change with every optimizer step (one launch per
+// pack was 36 launches of ~5 us per head pair and step).
+namespace {
+constexpr int GEMM_PACK_MAXJ = 18;
+struct GemmPackJobs {
+    const float* w[GEMM_PACK_MAXJ];
+    unsigned short* wp[GEMM_PACK_MAXJ];
+    int Cin[GEMM_PACK_MAXJ], Cout[GEMM_PACK_MAXJ], transposed[GEMM_PACK_MAXJ];
+};
+__global__ void pack_gemm_f16k_multi_kernel(const GemmPackJobs J) {
+    const int jb = blockIdx.y;
+    const float* __restrict__ w = J.w[jb];
+    unsigned short* __restrict__ wp = J.wp[jb];
+    const int Cin = J.Cin[jb], Cout = J.Cout[jb], transposed = J.transposed[jb];
+    const int nk16 = ((Cin + 15) / 16 + 3) / 4 * 4, ncb = (Cout + 127) / 128;
+    const size_t total = (size_t)ncb * nk16 * 2048;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = (int)(r & 7); r >>= 3;
+        const int co = (int)(r & 127); r >>= 7;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int k16 = (int)(r % nk16);
+        const int cb = (int)(r / nk16);
+        const int ci = k16 * 16 + hh * 8 + e, cog = cb * 128 + co;
+        float v = 0.0f;
+        if (ci < Cin && cog < Cout) v = transposed ? w[(size_t)ci * Cout + cog] : w[(size_t)cog * Cin + ci];
+        const __bf16 bv = (__bf16)v;
+        wp[i] = __builtin_bit_cast(unsigned short, bv);
+    }
+}
+}  // namespace
+
+// jobs: n (<= 18) packs as masic_gemm_f16k_pack_weight would make them, one launch: w[i] / wp[i] / Cin[i] / Cout[i] / transposed[i]
+extern "C" int masic_gemm_f16k_pack_weights(const float* const* w, void* const* wp, const int* Cin, const int* Cout, const int* transposed, int n, void* stream) {
+    MASIC_REQUIRE(w && wp && Cin && Cout && transposed && n >= 1 && n <= GEMM_PACK_MAXJ, MASIC_ERR_ARG, "gemm_f16k_pack_weights: 1 ... %d jobs", GEMM_PACK_MAXJ);
+    GemmPackJobs J{};
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        MASIC_REQUIRE(w[i] && wp[i] && Cin[i] > 0 && Cout[i] > 0, MASIC_ERR_ARG, "gemm_f16k_pack_weights: bad job %d", i);
+        J.w[i] = w[i]; J.wp[i] = (unsigned short*)wp[i]; J.Cin[i] = Cin[i]; J.Cout[i] = Cout[i]; J.transposed[i] = transposed[i];
+        const size_t total = (size_t)ceil_div(Cout[i], 128) * round_up(ceil_div(Cin[i], 16), 4) * 2048;
+        most = most > total ? most : total;
+    }
+    int nb = (int)((most + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pack_gemm_f16k_multi_kernel, dim3(nb, n), dim3(256), 0, (hipStream_t)stream, J);
+    return masic_launch_status("gemm_f16k_pack_weights");
+}
+
 extern "C" size_t masic_gemm_f16k_packed_bytes(int Cin, int Cout) {
     return (size_t)ceil_div(Cout, 128) * round_up(ceil_div(Cin, 16), 4) * 4096;
 }

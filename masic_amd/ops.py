@@ -829,6 +829,19 @@ def conv5s1_pair(xa, xb, packed, bias, gdn_in=None, gdn_out=None, beta_min=1e-6)
     return y
 
 
+def pack_gemm_f16k_weights(jobs):
+    """jobs: [(weight, Cin, Cout, transposed), ...] (<= 18) -> the packs pack_gemm_f16k_weight would make, in ONE launch."""
+    n = len(jobs)
+    outs = [torch.empty(lib.masic_gemm_f16k_packed_bytes(ci, co) // 2, dtype=torch.int16, device=w.device) for w, ci, co, _ in jobs]
+    for w, _, _, _ in jobs:
+        _dev(w, "weight")
+    W = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _, _ in jobs])
+    P = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    I = lambda k: (ctypes.c_int * n)(*[int(j[k]) for j in jobs])
+    check(lib.masic_gemm_f16k_pack_weights(W, P, I(1), I(2), I(3), n, _stream()), "gemm_f16k_pack_weights")
+    return outs
+
+
 def pack_gemm_f16k_weight(weight, Cin, Cout, transposed):
     _dev(weight, "weight")
     wp = torch.empty(lib.masic_gemm_f16k_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
