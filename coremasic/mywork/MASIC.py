@@ -34,6 +34,7 @@ from masic_amd.streams import ForkJoin as _ForkJoin
 from masic_amd import fp8 as _fp8
 
 _RELU, _LEAKY, _NONE = _hip.ACT_RELU, _hip.ACT_LEAKY, _hip.ACT_NONE
+_CAT_F16K = os.environ.get("MASIC_CAT_F16K", "1") != "0"               # 0: float32 concat buffers in front of the heads (A/B timing)
 _HEADS_GROUPED = os.environ.get("MASIC_HEADS_GROUPED", "1") != "0"     # layer i of a head's three stacks in one launch (0: A/B timing)
 
 
@@ -121,6 +122,12 @@ def _keep_until(t, stream):
     """Tensor.record_stream for a tensor used on another stream than the one it was allocated on.  Skipped inside a HIP-graph
     capture: there every cross-stream tensor of the forward lives until all streams have joined the capturing one (and
     record_stream with a non-capturing-origin stream ends torch's capture with a fault on this ROCm)."""
+    if isinstance(t, (tuple, list)):              # (F16K buffer, channels) pairs
+        for e in t:
+            _keep_until(e, stream)
+        return
+    if not torch.is_tensor(t):
+        return
     if not torch.cuda.is_current_stream_capturing():
         t.record_stream(stream)
 
@@ -133,10 +140,11 @@ def _bf16_inference(*tensors):
     return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
 
 
-def _f16k_chain(convs, acts, x, in_op=0, out=None, out_coff=0, gate=None, gate_c=0):
+def _f16k_chain(convs, acts, x, in_op=0, out=None, out_coff=0, gate=None, gate_c=0, out16=None):
     """A chain of convolutions on the float32 NCHW tensor `x` with the activations between them in F16K bf16
     (conv_f16k.hip); |x| / round(x) is applied while converting the input. The last layer writes float32 NCHW (a channel
-    view of `out`, optionally gated). None if a layer shape has no F16K configuration."""
+    view of `out`, optionally gated) -- or, with out16 = (F16K buffer, its channel count), the same view of an F16K concat buffer.
+    None if a layer shape has no F16K configuration."""
     B, C, H, W = x.shape
     sizes = [(H, W)]
     for cv in convs:
@@ -148,6 +156,8 @@ def _f16k_chain(convs, acts, x, in_op=0, out=None, out_coff=0, gate=None, gate_c
     last = len(convs) - 1
     for i, (cv, act) in enumerate(zip(convs, acts)):
         if i == last:
+            if out16 is not None:
+                return cv.run_f16k(t, B, *sizes[i], act=act, out_coff=out_coff, gate=gate, gate_c=gate_c, out16=out16[0], out16_ctot=out16[1])[0]
             return cv.run_f16k(t, B, *sizes[i], act=act, want_nchw=out is None, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)[0]
         t = cv.run_f16k(t, B, *sizes[i], act=act)[0]
 
@@ -286,11 +296,14 @@ class _GmmHeads(nn.Module):
         return all(seq[i].in_channels % 32 == 0 and seq[i].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights) for i in (0, 2)) \
             and all(seq[4].in_channels % 16 == 0 and seq[4].out_channels % 32 == 0 for seq in (self.gmm_sigma, self.gmm_means, self.gmm_weights))
 
-    def heads(self, x, parallel=True):
+    def heads(self, x, parallel=True, x16=None):
         """parallel: the means / weights stacks on two side streams forked from the current one.  Callers that are themselves on
         a side stream pass False: a side stream that forks further streams (or a stream waiting for its own event) ends a
         HIP-graph capture on this ROCm with a fault in hipStreamEndCapture (measured; torch 2.10 / ROCm 7)."""
         from masic_amd import nn as _mnn
+        if x16 is not None:                # the input as an F16K buffer (x = its shape): HSIC's bf16 eval forward builds the concat there
+            B, _, H, W = x
+            return self._heads_grouped(x16, None, B, H, W)
         if _mnn.reduced_precision() and not (torch.is_grad_enabled() and (x.requires_grad or self.gmm_sigma[0].weight.requires_grad)):
             B, _, H, W = x.shape
             sc = _fp8.scales(self)
@@ -627,26 +640,37 @@ class HSIC(CompressionModel):
     def _standardized_cumulative(self, inputs):
         return self.gaussian1._standardized_cumulative(inputs)
 
-    def _hyper_up(self, seq, z_hat, out, out_coff, gate=None, gate_c=0):
+    @staticmethod
+    def _into_f16k(y32, out16, out_coff):
+        """fallback of the F16K concat buffers: a float32 result converted into its slice (a layer without an F16K configuration)"""
+        _hip.nchw_to_f16k_view(y32, out16[0], out16[1], out_coff)
+        return out16[0]
+
+    def _hyper_up(self, seq, z_hat, out, out_coff, gate=None, gate_c=0, out16=None):
+        """out16 = (F16K buffer, channels): the result goes into that concat buffer instead of the float32 one (`out` is None then)."""
         if _bf16_inference(z_hat, seq[0].weight):
             # the two small transposed layers (8^2 -> 16^2 -> 32^2: a few dozen workgroups) are quicker on the register-streamed
             # NCHW kernel; the 3x3 288 -> 384 layer at 32^2 on the F16K one (measured: 21 + 58 + 46 us against 47 + 92 + 46)
             t = seq[2].run(seq[0].run(z_hat, act=_LEAKY), act=_LEAKY)
-            r = _f16k_chain((seq[4],), (_NONE,), t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+            r = _f16k_chain((seq[4],), (_NONE,), t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c, out16=out16)
             if r is not None:
                 return r
+            if out16 is not None:
+                return self._into_f16k(seq[4].run(t, gate=gate, gate_c=gate_c), out16, out_coff)
             return seq[4].run(t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
         t = seq[0].run(z_hat, act=_LEAKY)
         t = seq[2].run(t, act=_LEAKY)
         return seq[4].run(t, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
 
-    def _context(self, ctx, y, out, out_coff, gate=None, gate_c=0):
+    def _context(self, ctx, y, out, out_coff, gate=None, gate_c=0, out16=None):
         """Eval-mode context model: masked conv of round(y) into a slice of the concat buffer (optionally gated)."""
         if _bf16_inference(y, ctx.weight):
             ctx.zero_masked_taps()
-            r = _f16k_chain((ctx,), (_NONE,), y, in_op=_hip.INOP_ROUND, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
+            r = _f16k_chain((ctx,), (_NONE,), y, in_op=_hip.INOP_ROUND, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c, out16=out16)
             if r is not None:
                 return r
+        if out16 is not None:
+            return self._into_f16k(ctx.run(y, in_op=_hip.INOP_ROUND, gate=gate, gate_c=gate_c), out16, out_coff)
         return ctx.run(y, in_op=_hip.INOP_ROUND, out=out, out_coff=out_coff, gate=gate, gate_c=gate_c)
 
     def _needs_graph(self):
@@ -786,26 +810,44 @@ class HSIC(CompressionModel):
         z2 = self._h_a2(y2)
         z2_hat, z2_lik = self.entropy_bottleneck2(z2)
         h, w = y2.shape[-2:]
-        cat2 = torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)       # params2*g0 | ctx2*g1 | y1_warp_hat*g2
+        cat16 = self._cat_f16k(self._h_s2_same_resolution, y2, 5 * M)
+        cat2 = None if cat16 is not None else torch.empty((B, 5 * M, h, w), dtype=x1.dtype, device=x1.device)       # params2*g0 | ctx2*g1 | y1_warp_hat*g2
         # masks and gates: a chain of tiny kernels first needed here; at the head of the forward it would only delay the
         # analysis transform
         x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
         x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
         gates = self.mask2weights_unit(x1_mask_R)                                    # [B,3,h,w]
-        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
-        self._context(self.context_prediction2, y2, cat2, 2 * M, gates, 1)
-        return {"y2": y2, "z2_hat": z2_hat, "z2_lik": z2_lik, "cat2": cat2, "gates": gates, "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L}
+        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0, out16=cat16)
+        self._context(self.context_prediction2, y2, cat2, 2 * M, gates, 1, out16=cat16)
+        return {"y2": y2, "z2_hat": z2_hat, "z2_lik": z2_lik, "cat2": cat2, "cat16": cat16, "gates": gates, "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L}
+
+    def _cat_f16k(self, head, y, C):
+        """(F16K buffer, C) for the concat in front of an entropy-parameter head when the bf16 eval forward can keep it in F16K: the
+        producers (last hyper-synthesis layer, context model, the rounded warped latent) then write their gated slices as bf16 records
+        and the head's grouped GEMMs read them directly -- no float32 concat, no conversion pass of the whole buffer on the entropy
+        chain (same values bit for bit: the gate multiplies in float32 before the one rounding to bf16 either way).  None otherwise
+        (float32 / fp8 operands, fp8 calibration, head widths without the grouped GEMM form; MASIC_CAT_F16K=0)."""
+        from masic_amd import nn as _mnn
+        if not (_CAT_F16K and _HEADS_GROUPED and _bf16_inference(y) and not _mnn._FP8 and not _fp8.recording() and C % 16 == 0
+                and _fp8.scales(head) is None and head._grouped_heads_ok()):
+            return None
+        B, _, h, w = y.shape
+        return (_hip.f16k_empty(B, C, h, w, y.device), C)
 
     def _eval_left_entropy(self, y1):
         """On the current (side) stream: everything of the left view that only feeds likelihoods."""
         M = self.M
         B = y1.shape[0]
-        cat1 = torch.empty((B, 4 * M) + tuple(y1.shape[-2:]), dtype=y1.dtype, device=y1.device)   # params1 | ctx_params1
-        self._context(self.context_prediction1, y1, cat1, 2 * M)
+        cat16 = self._cat_f16k(self._h_s1_same_resolution, y1, 4 * M)
+        cat1 = None if cat16 is not None else torch.empty((B, 4 * M) + tuple(y1.shape[-2:]), dtype=y1.dtype, device=y1.device)   # params1 | ctx_params1
+        self._context(self.context_prediction1, y1, cat1, 2 * M, out16=cat16)
         z1 = self._h_a1(y1)
         z1_hat, z1_lik = self.entropy_bottleneck1(z1)
-        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0)
-        s1, m1, l1 = self._h_s1_same_resolution.heads(cat1, parallel=False)
+        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0, out16=cat16)
+        if cat16 is not None:
+            s1, m1, l1 = self._h_s1_same_resolution.heads((B, 4 * M) + tuple(y1.shape[-2:]), x16=cat16[0])
+        else:
+            s1, m1, l1 = self._h_s1_same_resolution.heads(cat1, parallel=False)
         _, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)
         return {"z1_hat": z1_hat, "z1_lik": z1_lik, "y1_lik": y1_lik}
 
@@ -814,9 +856,13 @@ class HSIC(CompressionModel):
         (the one left -> right dependency of the entropy model), then the right view's heads and likelihood."""
         M = self.M
         y1_warp = self.encoder1.latent(x1_hat_warp)
-        cat2, gates, y2 = right["cat2"], right["gates"], right["y2"]
-        _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
-        s2, m2, l2 = self._h_s2_same_resolution.heads(cat2, parallel=False)
+        cat2, cat16, gates, y2 = right["cat2"], right["cat16"], right["gates"], right["y2"]
+        if cat16 is not None:             # round(y1_warp) * gate straight into its F16K slice
+            _hip.nchw_to_f16k_view(y1_warp, cat16[0], cat16[1], 4 * M, in_op=_hip.INOP_ROUND, gate=gates, gate_c=2)
+            s2, m2, l2 = self._h_s2_same_resolution.heads((y2.shape[0], 5 * M) + tuple(y2.shape[-2:]), x16=cat16[0])
+        else:
+            _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+            s2, m2, l2 = self._h_s2_same_resolution.heads(cat2, parallel=False)
         _, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)
         return y2_lik
 

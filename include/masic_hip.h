@@ -281,6 +281,10 @@ int masic_conv_f16k_few_fwd(const void* x_f16k, const void* w_packed, const floa
 int masic_f16k_gate(const void* src, const float* gate, const float* minv, void* dst, int B, int C, int H, int W,
                     int dst_ctot, int dst_coff, int gate_ctot, int gate_c, void* stream);
 int masic_nchw_to_f16k_view(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, void* stream);
+/* ... with |x| / round(x) (in_op) applied and an optional gate[b][gate_c][pixel] (float32 [B][gate_ctot][HW]) multiplied in before the
+ * rounding to bf16: round(y) * gate into its slice of an F16K concat buffer (the gated concat of MASIC.py:827). */
+int masic_nchw_to_f16k_view_op(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, int in_op,
+                               const float* gate, int gate_ctot, int gate_c, void* stream);
 int masic_f16k_to_nchw(const void* x, float* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream);
 int masic_f16k_to_nchw_bf16(const void* x, void* y, int B, int C, int HW, int src_ctot, int src_coff, int ctot, int coff, void* stream);   /* y: bf16 NCHW */
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "masic_conv_f16k_few_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.POINTER(ConvDesc), _P]),
     "masic_f16k_gate": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "masic_nchw_to_f16k_view": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
+    "masic_nchw_to_f16k_view_op": (c_int, [_P, _P] + [c_int] * 8 + [_P, c_int, c_int, _P]),
     "masic_f16k_to_nchw": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "masic_f16k_to_nchw_bf16": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     # fp8 operand path

@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
             }
         } else {
             float gv = 1.0f;
-            if (a.y32 != nullptr && a.gate != nullptr) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];
+            if (a.gate != nullptr && pok) gv = a.gate[((size_t)b * a.gate_ctot + a.gate_c) * oplane + opix];      // (float32 NCHW or F16K output)
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -1323,8 +1323,8 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
     MASIC_REQUIRE(d->in_ctot % cblk == 0 && d->in_coff % cblk == 0, MASIC_ERR_SHAPE, "conv_f16k: input channel view must be 16-aligned (32 for fp8)");
-    MASIC_REQUIRE(y_f16k == nullptr || (d->out_ctot % 16 == 0 && d->out_coff % 16 == 0 && d->Cout % 4 == 0 && gate == nullptr),
-                  MASIC_ERR_SHAPE, "conv_f16k: F16K output needs a 16-aligned channel view, Cout % 4 == 0 and no gate");
+    MASIC_REQUIRE(y_f16k == nullptr || (d->out_ctot % 16 == 0 && d->out_coff % 16 == 0 && d->Cout % 4 == 0 && (gate == nullptr || gdn_packed == nullptr)),
+                  MASIC_ERR_SHAPE, "conv_f16k: F16K output needs a 16-aligned channel view and Cout % 4 == 0 (a gate only without the fused GDN)");
     MASIC_REQUIRE(gdn_packed == nullptr || (d->Cout == 128 && d->act == MASIC_ACT_NONE && gate == nullptr), MASIC_ERR_UNSUPPORTED,
                   "conv_f16k: the fused GDN needs Cout = 128, no activation and no gate");
     if (g[0].Hp <= 0 || g[0].Wp <= 0) return MASIC_OK;

@@ -78,17 +78,22 @@ __global__ __launch_bounds__(256) void f16k_gate_kernel(const unsigned short* __
     reinterpret_cast<uint4*>(dst + (((size_t)b * (dst_ctot >> 4) + (dc8 >> 1)) * HW) * 16)[2 * (size_t)pix + (dc8 & 1)] = o;
 }
 
+// in_op: |x| / round(x) on the way; gate: multiply by gate[b][gate_c][pixel] (float32 [B][gate_ctot][HW]) before the rounding to bf16 --
+// round(y) * gate written straight into its slice of an F16K concat buffer is what `quantize(..., out=cat, gate=...)` + a conversion
+// of the whole buffer computed in two passes (MASIC.py:827: the gated concat in front of the right view's entropy-parameter heads)
 __global__ __launch_bounds__(256) void nchw_to_f16k_view_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int C, int HW,
-                                                                int ctot, int coff, int dst_ctot, int dst_coff) {
+                                                                int ctot, int coff, int dst_ctot, int dst_coff, int in_op,
+                                                                const float* __restrict__ gate, int gate_ctot, int gate_c) {
     const int b = blockIdx.z, c8 = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const float* xb = x + ((size_t)b * ctot + coff) * HW + p;
+    const float gv = gate != nullptr ? gate[((size_t)b * gate_ctot + gate_c) * HW + p] : 1.0f;
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = c8 * 8 + i;
-        v[i] = c < C ? xb[(size_t)c * HW] : 0.0f;
+        v[i] = c < C ? apply_inop(xb[(size_t)c * HW], in_op) * gv : 0.0f;
     }
     uint4 q;
     q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
@@ -213,11 +218,18 @@ extern "C" int masic_f16k_gate(const void* src, const float* gate, const float* 
 }
 
 extern "C" int masic_nchw_to_f16k_view(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, void* stream) {
+    return masic_nchw_to_f16k_view_op(x, y, B, C, HW, ctot, coff, dst_ctot, dst_coff, MASIC_INOP_NONE, nullptr, 0, 0, stream);
+}
+
+// ... with |x| / round(x) applied and an optional per-pixel gate (see the kernel)
+extern "C" int masic_nchw_to_f16k_view_op(const float* x, void* y, int B, int C, int HW, int ctot, int coff, int dst_ctot, int dst_coff, int in_op,
+                                          const float* gate, int gate_ctot, int gate_c, void* stream) {
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "nchw_to_f16k_view: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot && dst_ctot % 16 == 0 && dst_coff % 8 == 0 && dst_coff >= 0 && dst_coff + round_up(C, 8) <= dst_ctot,
                   MASIC_ERR_SHAPE, "nchw_to_f16k_view: view out of range");
+    MASIC_REQUIRE(gate == nullptr || (gate_c >= 0 && gate_c < gate_ctot), MASIC_ERR_SHAPE, "nchw_to_f16k_view: gate channel out of range");
     hipLaunchKernelGGL(nchw_to_f16k_view_kernel, dim3(ceil_div(HW, 256), ceil_div(C, 8), B), dim3(256), 0, (hipStream_t)stream,
-                       x, (unsigned short*)y, C, HW, ctot, coff, dst_ctot, dst_coff);
+                       x, (unsigned short*)y, C, HW, ctot, coff, dst_ctot, dst_coff, in_op, gate, gate_ctot, gate_c);
     return masic_launch_status("nchw_to_f16k_view");
 }
 

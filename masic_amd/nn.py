@@ -226,11 +226,14 @@ class _PackedWeightMixin:
         return (self.transposed_conv and self._geometry() == (5, 5, 2, 2) and self.out_channels <= 8 and self.in_channels % 32 == 0
                 and ops.conv_f16k_supported(ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, 3, 3, 1, 1, prec=PREC_BF16)))
 
-    def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0, gdn=None):
+    def run_f16k(self, x16, B, Hi, Wi, act=ops.ACT_NONE, want_nchw=False, out=None, out_coff=0, gate=None, gate_c=0, gdn=None, out16=None, out16_ctot=0):
         """Inference-only: y = act(conv(x) + bias) on an F16K input buffer. Returns (y, Ho, Wo) with y an F16K buffer of
         ceil16(Cout) channels, or float32 NCHW when `want_nchw` / `out` (channel view of a concat buffer, optional gate).
         `gdn`: a 128-channel compressai GDN module applied to the result inside the kernel's epilogue."""
-        if out is not None:
+        if out16 is not None:             # channels out_coff.. of an F16K concat buffer of out16_ctot channels (optionally gated)
+            desc = self._desc_f16k(B, Hi, Wi, out_ctot=out16_ctot, out_coff=out_coff, act=act,
+                                   gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
+        elif out is not None:
             desc = self._desc_f16k(B, Hi, Wi, out_ctot=out.shape[1], out_coff=out_coff, act=act,
                                    gate_ctot=0 if gate is None else gate.shape[1], gate_c=gate_c)
         elif want_nchw:
@@ -239,7 +242,7 @@ class _PackedWeightMixin:
             desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 15) // 16 * 16, act=act)
         bias = None if self.bias is None else self.bias.detach()
         y = ops.conv2d_f16k(x16, self.packed_f16k_weight(desc), bias, desc, out_nchw=out, want_nchw=want_nchw, gate=gate,
-                            gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse))
+                            gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse), out16=out16)
         return y, desc.Ho, desc.Wo
 
     def run_f16k_dual(self, x16, B, Hi, Wi, gdn, products=3):

@@ -726,9 +726,10 @@ def pack_gdn_f16k(beta, gamma, beta_min=1e-6):
     return packed
 
 
-def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=None, gdn=None):
+def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=None, gdn=None, out16=None):
     """Conv on an F16K input [B][in_ctot/16][Hi*Wi][16]; returns float32 NCHW (want_nchw / out_nchw) or an F16K buffer of
-    desc.out_ctot channels (a fresh one holds exactly ceil16(Cout) channels)."""
+    desc.out_ctot channels (a fresh one holds exactly ceil16(Cout) channels; `out16`: an existing buffer of desc.out_ctot channels,
+    written at desc.out_coff -- a slice of a concat buffer, optionally gated)."""
     if x16.dtype != torch.int16 or not x16.is_cuda:
         raise RuntimeError("masic_amd.conv2d_f16k: input must be an F16K int16 CUDA buffer")
     if x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
@@ -741,10 +742,14 @@ def conv2d_f16k(x16, packed, bias, desc, out_nchw=None, want_nchw=False, gate=No
         y32 = out_nchw if out_nchw is not None else torch.empty((desc.B, desc.out_ctot, desc.Ho, desc.Wo), dtype=torch.float32, device=x16.device)
         if tuple(y32.shape) != (desc.B, desc.out_ctot, desc.Ho, desc.Wo):
             raise RuntimeError(f"masic_amd.conv2d_f16k: output buffer {tuple(y32.shape)} does not match descriptor")
-        if gate is not None and tuple(gate.shape) != (desc.B, desc.gate_ctot, desc.Ho, desc.Wo):
-            raise RuntimeError("masic_amd.conv2d_f16k: gate does not match descriptor")
+    elif out16 is not None:
+        if out16.dtype != torch.int16 or out16.numel() != desc.B * desc.out_ctot * desc.Ho * desc.Wo:
+            raise RuntimeError("masic_amd.conv2d_f16k: out16 does not match the descriptor's output view")
+        y16 = out16
     else:
         y16 = torch.empty(desc.B * desc.out_ctot * desc.Ho * desc.Wo, dtype=torch.int16, device=x16.device)
+    if gate is not None and tuple(gate.shape) != (desc.B, desc.gate_ctot, desc.Ho, desc.Wo):
+        raise RuntimeError("masic_amd.conv2d_f16k: gate does not match descriptor")
     timed = None
     if _timer is not None:
         buf = ctypes.create_string_buffer(96)
@@ -1048,13 +1053,18 @@ def f16k_gate(src16, B, C, H, W, dst16, dst_ctot, dst_coff, gate=None, gate_c=0,
     return dst16
 
 
-def nchw_to_f16k_view(x, dst16, dst_ctot, dst_coff, C=None, coff=0):
+def nchw_to_f16k_view(x, dst16, dst_ctot, dst_coff, C=None, coff=0, in_op=INOP_NONE, gate=None, gate_c=0):
+    """float32 NCHW (channel view) -> channels dst_coff.. of the F16K buffer dst16 (dst_ctot channels); in_op: |x| / round(x) on the
+    way, gate: multiply by gate[:, gate_c] before the rounding to bf16."""
     _dev(x, "x")
     B, ctot, H, W = x.shape
     C = ctot if C is None else C
     if dst16.dtype != torch.int16 or dst16.numel() != B * dst_ctot * H * W:
         raise RuntimeError("masic_amd.nchw_to_f16k_view: destination buffer size mismatch")
-    check(lib.masic_nchw_to_f16k_view(_p(x), _p(dst16), B, C, H * W, ctot, coff, dst_ctot, dst_coff, _stream()), "nchw_to_f16k_view")
+    if gate is not None and (_dev(gate, "gate").dim() != 4 or gate.shape[0] != B or tuple(gate.shape[2:]) != (H, W)):
+        raise RuntimeError("masic_amd.nchw_to_f16k_view: gate does not match the tensor")
+    check(lib.masic_nchw_to_f16k_view_op(_p(x), _p(dst16), B, C, H * W, ctot, coff, dst_ctot, dst_coff, int(in_op), _p(gate),
+                                         0 if gate is None else gate.shape[1], gate_c, _stream()), "nchw_to_f16k_view")
     return dst16
 
 

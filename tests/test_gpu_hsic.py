@@ -349,6 +349,38 @@ def test_bf16_operand_path_config1_accuracy_streams_and_graph():
     assert bad <= 0.06 * total
 
 
+def test_f16k_concat_buffers_equal_float32_concat(monkeypatch):
+    """bf16 eval forward: the concat buffers in front of the entropy-parameter heads (reference MASIC.py:765, :827) kept in F16K --
+    gated slices written by their producers, round(y1_warp) * gate converted straight into its slice -- against the float32 concat +
+    one conversion of the whole buffer: every output bit for bit (the gate multiplies in float32 before the single rounding to bf16
+    in both forms), eagerly and through a graph replay."""
+    import MASIC
+    from masic_amd import nn as mnn, synth
+    from masic_amd.graph import GraphedHSIC
+    N, M, K = 32, 32, 5
+    net = MASIC.HSIC(N, M, K)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=21))
+    net = net.to(DEV).eval()
+    x1, x2, hm = (t.to(DEV) for t in synth.synth_inputs(2, 128, 192, seed=21))
+    mnn.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            monkeypatch.setattr(MASIC, "_CAT_F16K", False)
+            want = net(x1, x2, hm)
+            monkeypatch.setattr(MASIC, "_CAT_F16K", True)
+            assert net._cat_f16k(net._h_s2_same_resolution, want["y1_hat"], 5 * M) is not None
+            got = net(x1, x2, hm)
+            rep = GraphedHSIC(net, x1, x2, hm)(x1, x2, hm)
+            torch.cuda.synchronize()
+    finally:
+        mnn.set_precision("f32")
+    for out in (got, rep):
+        for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat", "x1_mask_R", "x1_mask_L"):
+            assert torch.equal(out[k], want[k]), k
+        for k in want["likelihoods"]:
+            assert torch.equal(out["likelihoods"][k], want["likelihoods"][k]), k
+
+
 def test_graphed_forward_homography_lookahead():
     """GraphedHSIC(..., next_h_matrix=): the next call's homography staged under the current replay.  Results must equal the plain
     calls bit for bit -- also when the announced homography is NOT the one the next call brings (the staged matrices are dropped),
