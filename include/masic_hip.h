@@ -441,6 +441,12 @@ int masic_softmax_k_bwd(const float* g, const float* y, float* gx, int B, int M,
  *   post: dx = s + 2 x u,  u = gamma^T t */
 int masic_gdn_bwd_pre(const float* x, const float* nrm, const float* g, float* s, float* t, size_t n, int inverse, void* stream);
 int masic_gdn_bwd_post(const float* x, const float* s, const float* u, float* dx, size_t n, void* stream);
+/* The same backward for C <= 4 (MASIC.py:560 pre_gdn, :575 after_gdn: GDN(3) on full-resolution pictures) in one pass: float32
+ * per-pixel algebra in registers, parameter sums reduced in float64 in a fixed order.  beta [C], gamma [C][C]: the STORED tensors;
+ * g_beta, g_gamma: gradients with respect to them (reparametrisation rules included, as masic_gdn_bwd_fused). */
+size_t masic_gdn_bwd_small_workspace_bytes(void);
+int masic_gdn_bwd_small(const float* x, const float* g, const float* beta, const float* gamma, float* gx, float* g_beta,
+                        float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse, double beta_min, void* stream);
 /* The whole GDN / inverse-GDN backward (gdn.py:77-92 under autograd, C = 128) in one pass over x and g = dL/dy, bf16
  * operands on the matrix cores with float32 accumulation -- the training step of the bf16-operand mode; the pieces above
  * remain the float32 parity path.  beta, gamma: the STORED tensors; g_beta [128], g_gamma [128][128]: gradients with

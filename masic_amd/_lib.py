@@ -151,6 +151,8 @@ SIGNATURES = {
     "masic_softmax_k_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "masic_gdn_bwd_pre": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "masic_gdn_bwd_post": (c_int, [_P, _P, _P, _P, c_size_t, _P]),
+    "masic_gdn_bwd_small_workspace_bytes": (c_size_t, []),
+    "masic_gdn_bwd_small": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, _P]),
     "masic_gdn_bwd_fused_workspace_bytes": (c_size_t, []),
     "masic_gdn_bwd_fused": (c_int, [_P] * 8 + [c_int] * 5 + [c_double, _P]),
     "masic_gdn_bwd_fused_ex": (c_int, [_P] * 12 + [c_int] * 5 + [c_double, _P]),

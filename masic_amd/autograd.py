@@ -87,6 +87,7 @@ class ConvFn(Function):
 
 
 _PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
+_GDN_BWD_SMALL = os.environ.get("MASIC_GDN_BWD_SMALL", "1") != "0"   # 0: GDN(3) backward as the nine-launch generic chain (A/B timing)
 _WGRAD1_F16K = os.environ.get("MASIC_WGRAD1_F16K", "1") != "0"     # 0: 1x1 weight gradients on the float32 NCHW kernel (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
@@ -199,6 +200,8 @@ def gdn_backward(x, g, beta, gamma, inverse, beta_min, need_gx=True):
     from . import nn as _mnn
     if C == 128 and _mnn._PRECISION != PREC_F32:       # bf16-operand mode: the whole backward in one kernel
         return ops.gdn_bwd_fused(x, g, beta.detach(), gamma.detach(), inverse, beta_min)
+    if C <= 4 and _GDN_BWD_SMALL:                      # pre_gdn / after_gdn (GDN(3) on pictures): one pass, float32 in every mode
+        return ops.gdn_bwd_small(x, g, beta.detach(), gamma.detach(), inverse, beta_min)
     b_bound = float(torch.tensor((beta_min + PEDESTAL) ** 0.5, dtype=torch.float32))
     g_bound = float(torch.tensor(PEDESTAL ** 0.5, dtype=torch.float32))
     ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))

@@ -176,6 +176,106 @@ __global__ __launch_bounds__(256) void gdn_bwd_post_kernel(const float* __restri
         dx[i] = fmaf(2.0f * x[i], u[i], s[i]);
 }
 
+// ---------------------------------------------------------------------------- (inverse) GDN backward, C <= 4, one pass
+// encoder2.pre_gdn / decoder2.after_gdn (MASIC.py:560, :575: GDN(3) on full-resolution pictures).  The generic path above runs
+// two 3-channel 1x1 convolutions, two elementwise passes and a 1x1 weight gradient (nine launches over 2 M pixels, ~200 us at
+// 8 x 512 x 512); here a thread does the whole per-pixel algebra in registers and keeps the C + C^2 parameter sums, a block
+// writes one partial per sum, and the finishing block adds the partials in float64 in a fixed order and applies the
+// reparametrisation rules (parametrizers.py:61-64, bound_ops.py:40-42).  Float32 arithmetic in every precision mode.
+template <int C>
+__global__ __launch_bounds__(256) void gdn_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                            float* __restrict__ gx, float* __restrict__ part, int B, int HW, int inverse,
+                                                            float b_bound, float g_bound, float ped) {
+    float gam[C][C], bet[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float bv = fmaxf(beta[i], b_bound);
+        bet[i] = bv * bv - ped;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float gv = fmaxf(gamma[i * C + j], g_bound);
+            gam[i][j] = gv * gv - ped;
+        }
+    }
+    float sb[C], sg[C][C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        sb[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) sg[i][j] = 0.0f;
+    }
+    const size_t total = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW, p = i - b * HW;
+        const size_t base = b * C * (size_t)HW + p;
+        float xv[C], gv[C], x2[C], sv[C], tv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { xv[c] = x[base + (size_t)c * HW]; gv[c] = g[base + (size_t)c * HW]; x2[c] = xv[c] * xv[c]; }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float n = bet[c];
+#pragma unroll
+            for (int j = 0; j < C; ++j) n = fmaf(gam[c][j], x2[j], n);
+            const float r = sqrtf(n);
+            if (inverse) { sv[c] = gv[c] * r; tv[c] = 0.5f * gv[c] * xv[c] / r; }
+            else { sv[c] = gv[c] / r; tv[c] = -0.5f * gv[c] * xv[c] / (n * r); }
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float u = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) u = fmaf(gam[c][j], tv[c], u);
+            gx[base + (size_t)j * HW] = fmaf(2.0f * xv[j], u, sv[j]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            sb[c] += tv[c];
+#pragma unroll
+            for (int j = 0; j < C; ++j) sg[c][j] = fmaf(tv[c], x2[j], sg[c][j]);
+        }
+    }
+    __shared__ float red[4][C + C * C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < C + C * C; ++k) {
+        float v = k < C ? sb[k < C ? k : 0] : sg[(k >= C ? k - C : 0) / C][(k >= C ? k - C : 0) % C];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C + C * C)
+        part[(size_t)blockIdx.x * (C + C * C) + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one block: sums [nblocks][C + C*C] partials per parameter in float64 (fixed order: wave k % 4 takes sum k, lanes stride over the
+// blocks, butterfly) and applies the reparametrisation backward
+__global__ __launch_bounds__(256) void gdn_bwd_small_finish(const float* __restrict__ part, int nblocks, int n, const float* __restrict__ beta,
+                                                            const float* __restrict__ gamma, float* __restrict__ g_beta,
+                                                            float* __restrict__ g_gamma, int C, float b_bound, float g_bound) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < n; k += 4) {
+        double s = 0.0;
+        for (int i0 = lane; i0 < nblocks; i0 += 512) {      // eight loads in flight per lane (a dependent load per add is a latency each)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = i0 + 64 * j < nblocks ? part[(size_t)(i0 + 64 * j) * n + k] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const float d = (float)s;
+            const float pv = k < C ? beta[k] : gamma[k - C], bound = k < C ? b_bound : g_bound;
+            const float gg = d * 2.0f * fmaxf(pv, bound);
+            const float r = (pv >= bound || gg < 0.0f) ? gg : 0.0f;
+            if (k < C) g_beta[k] = r; else g_gamma[k - C] = r;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- Gaussian mixture backward
 __device__ __forceinline__ float norm_pdf(float t) { return 0.3989422804014327f * expf(-0.5f * t * t); }
 
@@ -544,6 +644,32 @@ extern "C" int masic_gdn_bwd_post(const float* x, const float* s, const float* u
     MASIC_REQUIRE(x && s && u && dx, MASIC_ERR_ARG, "gdn_bwd_post: null pointer");
     hipLaunchKernelGGL(gdn_bwd_post_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, s, u, dx, n);
     return masic_launch_status("gdn_bwd_post");
+}
+
+extern "C" size_t masic_gdn_bwd_small_workspace_bytes() { return (size_t)2048 * 20 * sizeof(float); }
+
+// x, g: float32 NCHW [B][C][H][W], C <= 4; beta [C], gamma [C][C]: the STORED tensors; gx: dL/dx; g_beta, g_gamma: gradients with
+// respect to the stored tensors; workspace: masic_gdn_bwd_small_workspace_bytes() of device memory
+extern "C" int masic_gdn_bwd_small(const float* x, const float* g, const float* beta, const float* gamma, float* gx, float* g_beta,
+                                   float* g_gamma, void* workspace, int B, int C, int H, int W, int inverse, double beta_min, void* stream) {
+    MASIC_REQUIRE(x && g && beta && gamma && gx && g_beta && g_gamma && workspace, MASIC_ERR_ARG, "gdn_bwd_small: null pointer");
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0, MASIC_ERR_SHAPE, "gdn_bwd_small: non-positive dimension");
+    MASIC_REQUIRE(C >= 1 && C <= 4, MASIC_ERR_UNSUPPORTED, "gdn_bwd_small: C=%d (1..4)", C);
+    const double ped = 0x1p-36;
+    const float b_bound = (float)__builtin_sqrt(beta_min + ped), g_bound = (float)__builtin_sqrt(ped);
+    const size_t total = (size_t)B * H * W;
+    const int nb = grid_for(total, 2048);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+#define GDNS_CASE(CC)                                                                                                              \
+    case CC:                                                                                                                       \
+        hipLaunchKernelGGL(gdn_bwd_small_kernel<CC>, dim3(nb), dim3(256), 0, st, x, g, beta, gamma, gx, part, B, H * W, inverse,   \
+                           b_bound, g_bound, (float)ped);                                                                          \
+        break;
+    switch (C) { GDNS_CASE(1) GDNS_CASE(2) GDNS_CASE(3) GDNS_CASE(4) }
+#undef GDNS_CASE
+    hipLaunchKernelGGL(gdn_bwd_small_finish, dim3(1), dim3(256), 0, st, part, nb, C + C * C, beta, gamma, g_beta, g_gamma, C, b_bound, g_bound);
+    return masic_launch_status("gdn_bwd_small");
 }
 
 extern "C" int masic_gmm_likelihood_bwd(const float* y_hat, const float* sigma, const float* mu, const float* wts,

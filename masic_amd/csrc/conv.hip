@@ -52,9 +52,9 @@ ConvCfg choose_cfg(const masic_conv_desc_t& d, const ConvGeom* g, int nphase) {
         c.direct = 2; c.Cin_pad = round_up(d.Cin, 8); c.Cout_pad = 4;      // packed [ci][5][5][4]
         return c;
     }
-    if (d.Cout <= 4 && d.Cin <= 8 && d.stride == 1 && d.KH == 5 && d.KW == 5 && d.pad == 2 && !d.masked &&
+    if (d.Cout <= 8 && d.Cin <= 8 && d.stride == 1 && d.KH == 5 && d.KW == 5 && d.pad == 2 && !d.masked &&
         d.in_op == MASIC_INOP_NONE && d.act != MASIC_ACT_SOFTMAX_C) {
-        c.direct = 3; c.Cin_pad = d.Cin; c.Cout_pad = 4;                   // packed [ci][5][5][4]
+        c.direct = 3; c.Cin_pad = d.Cin; c.Cout_pad = d.Cout <= 4 ? 4 : 8;  // packed [ci][5][5][4 or 8]
         return c;
     }
     if (d.Cout <= 8) {
@@ -800,8 +800,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const IgemmArgs a, con
 
 
 // ------------------------------------------------------------------------------------------ 5x5 stride-1, few channels
-// Conv2d / ConvTranspose2d(k=5, s=1, p=2) with Cin <= 8 and Cout <= 4: encoder2.pre_conv (6->3) and
-// decoder2.after_conv (6->3, transposed; MASIC.py:559,600).  Full-resolution, HBM-bound (reads Cin, writes Cout
+// Conv2d / ConvTranspose2d(k=5, s=1, p=2) with Cin <= 8 and Cout <= CO (4 or 8): encoder2.pre_conv (6->3) and
+// decoder2.after_conv (6->3, transposed; MASIC.py:559,600), and with CO = 8 the input gradient of after_conv (3->6).  Full-resolution, HBM-bound (reads Cin, writes Cout
 // planes): a 16x16 output tile per workgroup, the (16+4)^2 input tile of every channel staged by DMA, weights packed
 // [ci][kh][kw][4] (flipped for the transposed layer, so the kernel is always a correlation) as scalar operands.
 struct Conv5s1Args {
@@ -838,6 +838,7 @@ __device__ __forceinline__ void gdn3(float (&v)[3], const float* beta, const flo
     for (int i = 0; i < 3; ++i) v[i] = o[i];
 }
 
+template <int CO>
 __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const float* __restrict__ wpk) {
     constexpr int T = 16, LW = T + 4, PLANE = LW * LW, PSZ = 448;       // 400 floats per channel -> 7 DMA groups
     __shared__ __attribute__((aligned(16))) float lds[8 * PSZ];
@@ -872,10 +873,12 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
         }
         __syncthreads();
     }
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.0f;
     const float* base = lds + ty * LW + tx;
     for (int ci = 0; ci < a.Cin; ++ci) {
-        const float* w = wpk + ci * 100;
+        const float* w = wpk + ci * 25 * CO;
         const float* pl = base + ci * PSZ;
 #pragma unroll
         for (int kh = 0; kh < 5; ++kh)
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
             for (int kw = 0; kw < 5; ++kw) {
                 const float xv = pl[kh * LW + kw];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fmaf(xv, w[(kh * 5 + kw) * 4 + o], acc[o]);
+                for (int o = 0; o < CO; ++o) acc[o] = fmaf(xv, w[(kh * 5 + kw) * CO + o], acc[o]);
             }
     }
     if (oy >= a.H || ox >= a.W) return;
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
         return;
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < CO; ++o) {
         if (o >= a.Cout) break;
         float v = apply_act(acc[o] + (a.bias ? a.bias[o] : 0.0f), a.act) * gv;
         if (a.res1) v += a.res1[((size_t)b * a.Cout + o) * plane + opix];
@@ -905,11 +908,11 @@ __global__ __launch_bounds__(256) void conv5s1_small(const Conv5s1Args a, const 
     }
 }
 
-// [ci][kh][kw][4]; the transposed layer's taps are flipped so that the kernel correlates
-__global__ void pack_conv5s1_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int transposed) {
+// [ci][kh][kw][CO]; the transposed layer's taps are flipped so that the kernel correlates
+__global__ void pack_conv5s1_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int transposed, int CO) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Cin * 100) return;
-    const int ci = i / 100, rem = i - ci * 100, tap = rem >> 2, o = rem & 3;
+    if (i >= Cin * 25 * CO) return;
+    const int ci = i / (25 * CO), rem = i - ci * 25 * CO, tap = rem / CO, o = rem - tap * CO;
     float v = 0.0f;
     if (o < Cout) v = transposed ? w[((size_t)ci * Cout + o) * 25 + (24 - tap)] : w[((size_t)o * Cin + ci) * 25 + tap];
     wp[i] = v;
@@ -925,7 +928,8 @@ extern "C" size_t masic_conv_packed_bytes(const masic_conv_desc_t* d) {
     const ConvCfg c = choose_cfg(*d, g, np);
     int taps = 0;
     for (int p = 0; p < np; ++p) taps += g[p].ntaps;
-    if (c.direct == 2 || c.direct == 3) return (size_t)c.Cin_pad * 100 * sizeof(float);
+    if (c.direct == 2) return (size_t)c.Cin_pad * 100 * sizeof(float);
+    if (c.direct == 3) return (size_t)c.Cin_pad * 25 * c.Cout_pad * sizeof(float);
     if (c.bf16) return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(unsigned short);
     return (size_t)taps * c.Cin_pad * c.Cout_pad * sizeof(float);
 }
@@ -974,8 +978,8 @@ extern "C" int masic_conv_pack_weight(const float* w, void* w_packed, const masi
         return masic_launch_status("conv_pack_weight");
     }
     if (c.direct == 3) {
-        hipLaunchKernelGGL(pack_conv5s1_kernel, dim3(ceil_div(d->Cin * 100, 256)), dim3(256), 0, (hipStream_t)stream,
-                           w, (float*)w_packed, d->Cin, d->Cout, d->transposed);
+        hipLaunchKernelGGL(pack_conv5s1_kernel, dim3(ceil_div(d->Cin * 25 * c.Cout_pad, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, (float*)w_packed, d->Cin, d->Cout, d->transposed, c.Cout_pad);
         return masic_launch_status("conv_pack_weight");
     }
     PackArgs a{w, (float*)w_packed, d->Cin, d->Cout, d->KH, d->KW, c.Cin_pad, c.Cout_pad, d->transposed, {}};
@@ -1025,8 +1029,10 @@ extern "C" int masic_conv2d_fwd_ex(const float* x, const void* w_packed, const f
         MASIC_REQUIRE(res2 == nullptr, MASIC_ERR_UNSUPPORTED, "conv2d_fwd: two residuals on the small 5x5 path");
         Conv5s1Args a{x, bias, gate, res1, y, d->Cin, d->Hi, d->Wi, d->in_ctot, d->in_coff, d->Cout, d->out_ctot, d->out_coff,
                       d->act, ceil_div(d->Wi, 16), d->gate_ctot, d->gate_c, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0.0f, 0.0f, 0.0f};
-        hipLaunchKernelGGL(conv5s1_small, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
-                           (const float*)w_packed);
+        if (c.Cout_pad == 4) hipLaunchKernelGGL(conv5s1_small<4>, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
+                                                (const float*)w_packed);
+        else hipLaunchKernelGGL(conv5s1_small<8>, dim3(ceil_div(d->Wi, 16) * ceil_div(d->Hi, 16), d->B), dim3(256), 0, st, a,
+                                (const float*)w_packed);
         return masic_launch_status("conv2d_fwd");
     }
     if (c.direct) {
@@ -1111,6 +1117,6 @@ extern "C" int masic_conv5s1_pair_fwd(const float* xa, const float* xb, const fl
     Conv5s1Args a{xa, bias, nullptr, nullptr, y, 6, H, W, 3, 0, 3, 3, 0, MASIC_ACT_NONE, ceil_div(W, 16), 0, 0,
                   xb, 3, gin_beta, gin_gamma, gin_inverse, gout_beta, gout_gamma, gout_inverse,
                   (float)__builtin_sqrt(beta_min + ped), (float)__builtin_sqrt(ped), (float)ped};
-    hipLaunchKernelGGL(conv5s1_small, dim3(ceil_div(W, 16) * ceil_div(H, 16), B), dim3(256), 0, (hipStream_t)stream, a, (const float*)w_packed);
+    hipLaunchKernelGGL(conv5s1_small<4>, dim3(ceil_div(W, 16) * ceil_div(H, 16), B), dim3(256), 0, (hipStream_t)stream, a, (const float*)w_packed);
     return masic_launch_status("conv5s1_pair_fwd");
 }

@@ -660,6 +660,135 @@ __global__ __launch_bounds__(512) void conv_wgrad_k5s2_bf16(const WgradArgs a) {
     else role(false_c{}, std::integral_constant<int, 1>{}, 4);
 }
 
+// ---------------------------------------------------------------------------- 5x5 stride-1 layers with a handful of channels
+// encoder2.pre_conv (Conv2d 6 -> 3) and decoder2.after_conv (ConvTranspose2d 6 -> 3; MASIC.py:559, :576) on full-resolution pictures:
+// 450 weights, 2 M pixels per batch of 8 x 512 x 512 -- 0.94 G multiply-adds and a few planes of traffic.  On the matrix-core
+// kernels above 3 (or 6) of the 64 tile rows are real and the tile staging dominates (211 / 260 us).  Here: plain float32 FMAs.
+// A workgroup takes NA a-channels x all CQ q-channels and walks 32 x 64 pixel tiles; lane = column, wave = 8 rows; the q tile (2-row
+// halo, columns c0-4 .. c0+67 so that every 16-byte DMA chunk is aligned and wholly inside or outside the picture) sits in LDS, a
+// thread slides a 5 x 5 register window down its 8 rows and feeds NA x CQ x 25 accumulators.  Each workgroup stores ONE partial per
+// weight and a finishing pass adds them in a fixed order (deterministic; float atomics from 500 workgroups on the same 15 cache
+// lines cost 56 us of a 220 us launch).  rnd: operands rounded to bf16 as they are staged (the bf16-operand mode: the same operand
+// values as the matrix-core kernels of that mode); products and sums are float32 either way.  Needs W % 4 == 0.
+__device__ __attribute__((aligned(16))) float g_zero16_wg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+__device__ __forceinline__ float wg_round(float v, int rnd) { return rnd ? (float)(__bf16)v : v; }
+__device__ __forceinline__ void dma16w(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NA, int CQ>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_small_s1(const WgradArgs a, float* __restrict__ part, int rnd) {
+    constexpr int TR = 32, TC = 64, LR = TR + 4, LC = TC + 8, R = 8, NV = NA * CQ * 25;
+    constexpr int NQ = CQ * LR * LC, NC16 = NQ / 4, NCH = (NC16 + 63) / 64;       // 16-byte chunks, wave instructions
+    __shared__ __attribute__((aligned(16))) float ql[NCH * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a_base = blockIdx.y * NA;
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    const int tiles_w = (a.Wc + TC - 1) / TC, tiles_h = (a.Hc + TR - 1) / TR;
+    const int tiles_per_img = tiles_w * tiles_h, ntiles = tiles_per_img * a.B;
+    float acc[NA][CQ][25];
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+#pragma unroll
+            for (int t = 0; t < 25; ++t) acc[n][q][t] = 0.0f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, trem = tile - b * tiles_per_img;
+        const int r0 = (trem / tiles_w) * TR, c0 = (trem % tiles_w) * TC;
+        __syncthreads();                                  // the previous tile has been read
+        // the q tile by global -> LDS DMA, 16 bytes per lane: every request of the tile is in flight before the first one is awaited
+        const float* qb = a.Q + ((size_t)b * a.q_ctot + a.q_coff) * plane;
+        for (int ch = wave; ch < NCH; ch += 4) {
+            const int e = ch * 64 + lane;                 // chunk index: (q, row, 18 chunks of 4 columns)
+            const int q = e / (LR * (LC / 4)), rem = e - q * (LR * (LC / 4));
+            const int rr = rem / (LC / 4), cc = rem - rr * (LC / 4);
+            const int fh = r0 - 2 + rr, fw = c0 - 4 + 4 * cc;
+            const bool ok = e < NC16 && fh >= 0 && fh < a.Hc && fw >= 0 && fw < a.Wc;
+            dma16w(ok ? qb + (size_t)q * plane + (size_t)fh * a.Wc + fw : g_zero16_wg, ql + ch * 256);
+        }
+        float p[NA][R];
+        {
+            const int c = c0 + lane;
+            const float* pb = a.P + ((size_t)b * a.p_ctot + a.p_coff + a_base) * plane;
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int r = r0 + wave * R + i;
+                    p[n][i] = (r < a.Hc && c < a.Wc && a_base + n < a.CA) ? wg_round(pb[(size_t)n * plane + (size_t)r * a.Wc + c], rnd) : 0.0f;
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rnd) {                                        // bf16-operand mode: the staged tile rounded in place
+            for (int e = tid; e < NQ; e += 256) ql[e] = (float)(__bf16)ql[e];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            const float* base = ql + q * (LR * LC) + (wave * R) * LC + lane + 2;
+            float win[5][5];                              // row (i + kh) of the halo tile lives in win[(i + kh) % 5]
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) win[kh][kw] = base[kh * LC + kw];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) win[(i + 4) % 5][kw] = base[(i + 4) * LC + kw];
+#pragma unroll
+                for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                        for (int n = 0; n < NA; ++n) acc[n][q][kh * 5 + kw] = fmaf(p[n][i], win[(i + kh) % 5][kw], acc[n][q][kh * 5 + kw]);
+            }
+        }
+    }
+    __syncthreads();
+    static_assert(4 * NV <= NCH * 256, "reduction scratch fits the tile");
+    float* red = ql;                                      // [4][NV]
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+#pragma unroll
+            for (int t = 0; t < 25; ++t) {
+                float v = acc[n][q][t];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) red[wave * NV + (n * CQ + q) * 25 + t] = v;
+            }
+    __syncthreads();
+    float* mine = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * NV;
+    for (int k = tid; k < NV; k += 256) mine[k] = (red[k] + red[NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
+}
+
+// dw[o] = sum over the gx workgroups of a column of partials, in index order; the partials are zeroed behind the read (the
+// persistent workspace protocol of masic_conv2d_wgrad_ws); one wave per weight
+__global__ __launch_bounds__(64) void wgrad_small_finish(float* __restrict__ part, float* __restrict__ dw, int gx, int gy, int NV, int total) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    const int y = o / NV, k = o - y * NV;
+    float s = 0.0f;
+    for (int x0 = 0; x0 < gx; x0 += 256) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + 64 * j + lane;
+            float* src = part + ((size_t)(x < gx ? x : 0) * gy + y) * NV + k;
+            v[j] = x < gx ? *src : 0.0f;
+            if (x < gx) *src = 0.0f;
+        }
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0 && o < total) dw[o] = s;
+}
+
 // ws [T][CA][CQ] -> dw [CA][CQ][T]
 // rezero: every workspace element is read by exactly one thread of this pass, which then puts the zero back -- a persistent workspace
 // is clean again for the next weight gradient and needs no fill launch of its own (masic_conv2d_wgrad_ws)
@@ -675,9 +804,22 @@ __global__ __launch_bounds__(256) void wgrad_transpose_kernel(float* __restrict_
 
 }  // namespace
 
+namespace {
+constexpr int SMALL_WGS = 512;       // workgroups of conv_wgrad_small_s1 (two per CU), each with one partial of 150 floats in the workspace
+// the 5x5 stride-1 layers with 3 / 6 channels on either side (pre_conv, after_conv) take conv_wgrad_small_s1
+bool small_path(const masic_conv_desc_t* d) {
+    static const bool on = [] { const char* e = getenv("MASIC_WGRAD_SMALL"); return e == nullptr || e[0] != '0'; }();
+    if (!on || d->stride != 1 || d->KH != 5 || d->KW != 5 || d->pad != 2 || d->Wi % 4 != 0 || d->Hi != d->Ho || d->Wi != d->Wo) return false;
+    const int CA = d->transposed ? d->Cin : d->Cout, CQ = d->transposed ? d->Cout : d->Cin;
+    return (CQ == 6 || CQ == 3) && CA <= 8;
+}
+}  // namespace
+
 extern "C" size_t masic_conv2d_wgrad_workspace_bytes(const masic_conv_desc_t* d) {
     if (!d) return 0;
-    return (size_t)d->Cin * d->Cout * d->KH * d->KW * sizeof(float);
+    const size_t w = (size_t)d->Cin * d->Cout * d->KH * d->KW * sizeof(float);
+    const size_t small = small_path(d) ? (size_t)SMALL_WGS * 150 * sizeof(float) : 0;
+    return w > small ? w : small;
 }
 
 extern "C" int masic_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace,
@@ -785,6 +927,17 @@ int wgrad_launch(const void* xv, const void* dyv, float* dw, void* workspace, co
         return masic_launch_status("conv2d_wgrad");
     }
     MASIC_REQUIRE(!in16, MASIC_ERR_UNSUPPORTED, "conv2d_wgrad_bf16in: layer shape without a bf16-input kernel");
+    if (small_path(d)) {
+        // pre_conv / after_conv: plain float32 FMAs, one partial per workgroup in the workspace, summed (and zeroed again) by the finishing pass
+        const int ntl = ceil_div(a.Wc, 64) * ceil_div(a.Hc, 32) * a.B;
+        const int NA = a.CQ == 6 ? 1 : 2, gy = ceil_div(a.CA, NA), NV = NA * a.CQ * 25;
+        int gx = SMALL_WGS / gy;
+        if (gx > ntl) gx = ntl;
+        if (a.CQ == 6) hipLaunchKernelGGL((conv_wgrad_small_s1<1, 6>), dim3(gx, gy), dim3(256), 0, st, a, (float*)workspace, (int)bf16);
+        else hipLaunchKernelGGL((conv_wgrad_small_s1<2, 3>), dim3(gx, gy), dim3(256), 0, st, a, (float*)workspace, (int)bf16);
+        hipLaunchKernelGGL(wgrad_small_finish, dim3(gy * NV), dim3(64), 0, st, (float*)workspace, dw, gx, gy, NV, a.CA * a.CQ * 25);
+        return masic_launch_status("conv2d_wgrad");
+    }
     if (a.CQ <= 8 && Tt > 1 && ncol_tiles <= 8) {          // few fine-side channels: (tap, q) pairs packed into the 32 MFMA columns
         a.q_tiles = 1;
         int nsplit = ceil_div(512, a_tiles);

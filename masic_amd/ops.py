@@ -524,6 +524,27 @@ def gdn_bwd_post(x, s, u):
 _GDN_BWD_WS = {}
 
 
+_GDN_BWD_SMALL_WS = {}
+
+
+def gdn_bwd_small(x, g, beta, gamma, inverse=False, beta_min=1e-6):
+    """(dx, d beta, d gamma) of GDN / inverse GDN with C <= 4 channels in one pass (float32; masic_gdn_bwd_small)."""
+    _dev(x, "x"); _dev(g, "g")
+    B, C, H, W = x.shape
+    if g.shape != x.shape or not (x.is_contiguous() and g.is_contiguous()):
+        raise RuntimeError("masic_amd.gdn_bwd_small: x and g must be contiguous and of one shape")
+    key = (x.device, int(_stream().value or 0))
+    ws = _GDN_BWD_SMALL_WS.get(key)
+    if ws is None:
+        ws = _GDN_BWD_SMALL_WS[key] = torch.empty(lib.masic_gdn_bwd_small_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    gx = torch.empty_like(x)
+    g_beta = torch.empty(C, dtype=torch.float32, device=x.device)
+    g_gamma = torch.empty(C, C, dtype=torch.float32, device=x.device)
+    check(lib.masic_gdn_bwd_small(_p(x), _p(g), _p(_dev(beta.contiguous())), _p(_dev(gamma.contiguous())), _p(gx), _p(g_beta),
+                                  _p(g_gamma), _p(ws), B, C, H, W, int(inverse), float(beta_min), _stream()), "gdn_bwd_small")
+    return gx, g_beta, g_gamma
+
+
 def gdn_bwd_fused(x, g, beta, gamma, inverse=False, beta_min=1e-6):
     """(dx, d beta, d gamma) of GDN / inverse GDN at C = 128 in one kernel (bf16 operands, float32 accumulate)."""
     _dev(x, "x"); _dev(g, "g")
@@ -594,14 +615,14 @@ def conv2d_wgrad(x, dy, desc, weight_shape):
         raise RuntimeError(f"masic_amd.conv2d_wgrad: x {tuple(x.shape)} does not match the descriptor")
     dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     nbytes = lib.masic_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
-    if nbytes != dw.numel() * 4:
+    if desc.Cin * desc.Cout * desc.KH * desc.KW != dw.numel() or nbytes < dw.numel() * 4:
         raise RuntimeError("masic_amd.conv2d_wgrad: weight shape does not match the descriptor")
-    ws = _clean_workspace(x.device, dw.numel())
+    ws = _clean_workspace(x.device, nbytes // 4)       # (>= the weight: the few-channel 5x5 kernel keeps per-workgroup partials in it)
     try:
         fn = lib.masic_conv2d_wgrad_bf16in if b16 else lib.masic_conv2d_wgrad_ws
         check(fn(_p(x), _p(dy), _p(dw), _p(ws), ctypes.byref(desc), 1, _stream()), "conv2d_wgrad")
     except Exception:
-        _drop_workspace(x.device, dw.numel())          # an error part-way may have left it dirty
+        _drop_workspace(x.device, nbytes // 4)         # an error part-way may have left it dirty
         raise
     return dw
 

@@ -32,6 +32,8 @@ CONV_BWD_CASES = [
     ("masked5",    2, 192, 16, 24, 384,  5, 1, False, True,  0),
     ("conv6to3",   2, 6,   32, 48, 3,    5, 1, False, False, 0),
     ("deconv6to3", 2, 6,   32, 48, 3,    5, 1, True,  False, 0),
+    ("conv6to3_big", 1, 6, 260, 1400, 3, 5, 1, False, False, 0),      # conv_wgrad_small_s1: ragged tiles, several tiles per workgroup
+    ("deconv6to3_big", 2, 6, 256, 704, 3, 5, 1, True, False, 0),
     ("m2w_3x3s2",  2, 3,   32, 48, 6,    3, 2, False, False, 1),
     ("ragged",     1, 20,  18, 36, 72,   5, 2, False, False, 2),
 ]
