@@ -229,6 +229,12 @@ int masic_conv3x3_wgrad_f16k(const void* x_f16k, const void* dy_f16k, float* dw,
                              int B, int Cin, int Cout, int H, int W, void* stream);
 int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
                              int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream);
+/* The same for Conv2d(Cin -> Cout, k5, s1, p2): encode_hyper's first layer and the context model at latent resolution
+ * (reference MASIC.py:170-187, :627; a MaskedConv2d gets the dense gradient -- the reference masks weight.data, not the gradient).
+ * dw: float32 [Cout][Cin][5][5]; workspace_clean as masic_conv2d_wgrad_ws. */
+size_t masic_conv5x5_wgrad_f16k_workspace_bytes(int Cin, int Cout);
+int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                                int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream);
 /* Weight gradient of the 1x1 layers (the entropy-parameter stacks, reference MASIC.py:330-468) from F16K operands:
  * dw[a][q] = sum over batch and pixels of rows[b][a][p] * cols[b][q][p]; rows / cols: F16K [B][C/16][HW][16] bf16 with CA / CQ
  * channels (multiples of 16); dw float32 [CA][CQ].  Conv2d weight [Cout][Cin]: rows = dy, cols = x; ConvTranspose2d(k1) weight

@@ -88,6 +88,7 @@ class ConvFn(Function):
 
 _PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
 _GDN_BWD_SMALL = os.environ.get("MASIC_GDN_BWD_SMALL", "1") != "0"   # 0: GDN(3) backward as the nine-launch generic chain (A/B timing)
+_WGRAD5_F16K = os.environ.get("MASIC_WGRAD5_F16K", "1") != "0"     # 0: 5x5 stride-1 weight gradients on the float32-tile kernel (A/B timing)
 _WGRAD1_F16K = os.environ.get("MASIC_WGRAD1_F16K", "1") != "0"     # 0: 1x1 weight gradients on the float32 NCHW kernel (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
@@ -121,8 +122,11 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     # 3x3 stride-1 layers (Independent_EN, hyper transforms): dW from both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
     dw_f16k = (need_gw and _WGRAD3_F16K and bf16 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
+    # 5x5 stride-1 layers at latent resolution (encode_hyper[0], the context model): the same kernel with five kernel-row waves
+    dw5_f16k = (need_gw and _WGRAD5_F16K and bf16 and not mod.transposed_conv and (kh, kw, s, p) == (5, 5, 1, 2)
+                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
     if g16 is None or act != ops.ACT_NONE:
-        g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k) else None  # dy in F16K, converted once for both gradients
+        g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k or dw5_f16k) else None  # dy in F16K, converted once for both gradients
 
     pic_end = _PIC_END_DGRAD and bf16 and need_gx and act == ops.ACT_NONE and (kh, kw, s, p) == (5, 5, 2, 2)
     # the two picture-end layers (MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128), :550 g_s_conv4 = ConvTranspose2d(128 -> 3)); without
@@ -157,6 +161,8 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
                   else ops.gemm_wgrad_f16k(g16, x16, B, Cout, Cin, Hi * Wi)).view(tuple(weight.shape))
         elif dw_f16k:
             gw = ops.conv3x3_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
+        elif dw5_f16k:
+            gw = ops.conv5x5_wgrad_f16k(x16 if x16 is not None else ops.nchw_to_f16k(x), g16, B, Cin, Cout, Hi, Wi)
         elif need_gw:
             dw = ops.make_conv_desc(B, Cin, Hi, Wi, Cout, kh, kw, s, p, transposed=mod.transposed_conv, prec=_mnn._PRECISION)
             gw = ops.conv2d_wgrad(x, g, dw, tuple(weight.shape))        # (x and g both bf16 NCHW: the bf16-input kernel)

@@ -33,9 +33,13 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int TR = 4, TC = 32;                       // tile: output rows x columns
 constexpr int GP = TR * TC * 32 + 128;               // bytes per 16-channel plane of the dy tile (+128: bank offset between planes)
-constexpr int XW = TC + 2, XR = TR + 2;              // patch columns / rows
-constexpr int XROW = XW * 32;                        // 1088 bytes per patch row
-constexpr int XP = XR * XROW;                        // 6528 bytes per 16-channel plane of the x patch (= 128 mod 256)
+template <int KS>                                    // x patch of a KS x KS layer: columns / rows with the halo
+struct XGeom {
+    static constexpr int XW = TC + KS - 1, XR = TR + KS - 1;
+    static constexpr int XROW = XW * 32;             // bytes per patch row (k3: 1088, k5: 1152)
+    static constexpr int XP0 = XR * XROW;
+    static constexpr int XP = XP0 + (XP0 % 256 == 128 ? 0 : 128);   // bytes per 16-channel plane, = 128 mod 256 (k3: 6528, k5: 9216 + 128)
+};
 
 struct Wg3Args {
     const unsigned short* g16;    // dy  F16K [B][CA16][H*W][16]
@@ -43,6 +47,7 @@ struct Wg3Args {
     float* ws;                    // [9][CA][CQ] float32, zeroed by the caller
     int B, H, W, CA16, CQ16, CA, CQ;
     int a0, q0;                   // first output / input channel of this launch's first channel group
+    int sa, sq;                   // channel strides between the groups of a launch (k3: 96 / 64, k5: 64 / 32)
     int tiles_w, tiles_h, ntiles;
     int gq;                       // channel groups of this launch: blockIdx.y = ga * gq + gq_i, group (a0 + 96 ga, q0 + 64 gq_i) -- equally
                                   //   shaped groups share a launch (a 192 -> 192 layer: 6 groups, at latent resolution 64 workgroups each)
@@ -71,9 +76,10 @@ __device__ __forceinline__ bf16x8 frag(const v2u& lo, const v2u& hi) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3));
 }
 
-template <int MA, int NQ>
-__global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
-    constexpr int NW = NQ * 3;
+template <int MA, int NQ, int KS>
+__global__ __launch_bounds__(NQ * KS * 64) void wgrad3x3_f16k(const Wg3Args a) {
+    constexpr int XR = XGeom<KS>::XR, XROW = XGeom<KS>::XROW, XP = XGeom<KS>::XP;
+    constexpr int NW = NQ * KS;
     constexpr int GBYTES = 2 * MA * GP, XBYTES = 2 * NQ * XP, BUF = GBYTES + XBYTES;
     constexpr int NBUF = 3;
     constexpr int NI_G = 2 * MA * TR, NI_X = 2 * NQ * XR * 2, NI = NI_G + NI_X, NPW = (NI + NW - 1) / NW;
@@ -81,9 +87,9 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
     const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = wave / 3, kh = wave - 3 * qb;
+    const int qb = wave / KS, kh = wave - KS * qb;
     const int HW = a.H * a.W;
-    const int ga0 = a.a0 + 96 * ((int)blockIdx.y / a.gq), gq0 = a.q0 + 64 * ((int)blockIdx.y % a.gq);
+    const int ga0 = a.a0 + a.sa * ((int)blockIdx.y / a.gq), gq0 = a.q0 + a.sq * ((int)blockIdx.y % a.gq);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g16, 0, a.B * a.CA16 * HW * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, 0, a.B * a.CQ16 * HW * 32, 0x00020000);
 
@@ -105,10 +111,10 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
         } else {
             const int k = i - NI_G, part = k & 1, br = k >> 1;
             d_blk[j] = br / XR;
-            d_row[j] = br - d_blk[j] * XR - 1;                       // image row relative to the tile's first row
-            d_col[j] = part * 32 + (lane >> 1) - 1;                  // image column relative to the tile's first column
-            d_lds[j] = GBYTES + d_blk[j] * XP + (d_row[j] + 1) * XROW + part * 1024;
-            if (part == 1 && lane >= 4) d_live[j] = false;
+            d_row[j] = br - d_blk[j] * XR - KS / 2;                  // image row relative to the tile's first row
+            d_col[j] = part * 32 + (lane >> 1) - KS / 2;             // image column relative to the tile's first column
+            d_lds[j] = GBYTES + d_blk[j] * XP + (d_row[j] + KS / 2) * XROW + part * 1024;
+            if (part == 1 && lane >= 2 * (KS - 1)) d_live[j] = false;
         }
     }
     // every wave issues exactly NPW DMA instructions per call (dead slots and calls past the last tile read out of range into
@@ -134,11 +140,11 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
         }
     };
 
-    f32x16 acc[MA][3];
+    f32x16 acc[MA][KS];
 #pragma unroll
     for (int m = 0; m < MA; ++m)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < KS; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.0f;
 
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
         __builtin_amdgcn_s_barrier();                                // ... for every wave, and everyone is done reading the buffer of the tile before
         issue(tile + 2 * gridDim.x, buf >= 1 ? buf - 1 : NBUF - 1);  // two tiles ahead, into that free buffer
         const unsigned ba = la + buf * BUF, bb = lb + buf * BUF;
-        v2u af[2][MA][2], bfr[2][3][2];
+        v2u af[2][MA][2], bfr[2][KS][2];
         auto request = [&](auto kc, auto pc) {
             constexpr int ks = decltype(kc)::value, pb = decltype(pc)::value;
             constexpr int rr = ks >> 1, ch = ks & 1;                 // k-step = 16 pixels: row rr of the tile, column half ch
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
                 tr_read<m * 2 * GP + (rr * TC + ch * 16) * 32>(af[pb][m][0], ba);
                 tr_read<m * 2 * GP + (rr * TC + ch * 16) * 32 + 128>(af[pb][m][1], ba);
             });
-            sfor<0, 3>([&](auto tc) {
+            sfor<0, KS>([&](auto tc) {
                 constexpr int kw = decltype(tc)::value;
                 tr_read<rr * XROW + (ch * 16 + kw) * 32>(bfr[pb][kw][0], bb);
                 tr_read<rr * XROW + (ch * 16 + kw) * 32 + 128>(bfr[pb][kw][1], bb);
@@ -175,17 +181,17 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
         sfor<0, TR * 2>([&](auto kc) {
             constexpr int ks = decltype(kc)::value, pb = ks & 1;
             if constexpr (ks + 1 < TR * 2) request(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (ks + 1) & 1>{});
-            constexpr int pending = ks + 1 < TR * 2 ? 2 * (MA + 3) : 0;     // LDS returns in order: the requests for ks+1 may stay out
+            constexpr int pending = ks + 1 < TR * 2 ? 2 * (MA + KS) : 0;     // LDS returns in order: the requests for ks+1 may stay out
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
             sfor<0, MA>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 depend(af[pb][m][0], af[pb][m][1]);
             });
-            sfor<0, 3>([&](auto tc) {
+            sfor<0, KS>([&](auto tc) {
                 constexpr int kw = decltype(tc)::value;
                 depend(bfr[pb][kw][0], bfr[pb][kw][1]);
             });
-            sfor<0, 3>([&](auto tc) {
+            sfor<0, KS>([&](auto tc) {
                 constexpr int kw = decltype(tc)::value;
                 const bf16x8 bq = frag(bfr[pb][kw][0], bfr[pb][kw][1]);
                 sfor<0, MA>([&](auto mc) {
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
 #pragma unroll
         for (int m = 0; m < MA; ++m)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                float* wp = a.ws + ((size_t)(kh * 3 + kw) * a.CA + ga0 + m * 32 + 4 * h) * a.CQ + ci;
+            for (int kw = 0; kw < KS; ++kw) {
+                float* wp = a.ws + ((size_t)(kh * KS + kw) * a.CA + ga0 + m * 32 + 4 * h) * a.CQ + ci;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = ga0 + m * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
@@ -215,12 +221,12 @@ __global__ __launch_bounds__(NQ * 3 * 64) void wgrad3x3_f16k(const Wg3Args a) {
     }
 }
 
-// ws [9][CA][CQ] -> dw [CA][CQ][9]
-__global__ __launch_bounds__(256) void wgrad3_transpose_kernel(float* __restrict__ ws, float* __restrict__ dw, int AQ, int rezero) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)9 * AQ; i += (size_t)gridDim.x * 256) {
+// ws [T][CA][CQ] -> dw [CA][CQ][T]
+__global__ __launch_bounds__(256) void wgrad3_transpose_kernel(float* __restrict__ ws, float* __restrict__ dw, int AQ, int T, int rezero) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)T * AQ; i += (size_t)gridDim.x * 256) {
         const int t = (int)(i / AQ);
         const size_t aq = i - (size_t)t * AQ;
-        dw[aq * 9 + t] = ws[i];
+        dw[aq * T + t] = ws[i];
         if (rezero) ws[i] = 0.0f;          // a persistent workspace is clean again (masic_conv3x3_wgrad_f16k_ws)
     }
 }
@@ -338,17 +344,17 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
         }
 }
 
-template <int MA, int NQ>
+template <int MA, int NQ, int KS = 3>
 void launch(const Wg3Args& a, int grid, int groups, hipStream_t st) {
-    auto kfn = wgrad3x3_f16k<MA, NQ>;
+    auto kfn = wgrad3x3_f16k<MA, NQ, KS>;
     static bool attr_set = false;
-    constexpr size_t lds = 3 * (size_t)(2 * MA * GP + 2 * NQ * XP) + 1024;
+    constexpr size_t lds = 3 * (size_t)(2 * MA * GP + 2 * NQ * XGeom<KS>::XP) + 1024;
     static_assert(lds <= 160 * 1024, "three tile buffers must fit the LDS");
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid, groups), dim3(NQ * 3 * 64), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid, groups), dim3(NQ * KS * 64), lds, st, a);
 }
 
 }  // namespace
@@ -373,17 +379,21 @@ extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
         masic_set_error("conv3x3_wgrad_f16k: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
-    Wg3Args a{(const unsigned short*)dy_f16k, (const unsigned short*)x_f16k, (float*)workspace, B, H, W, Cout / 16, Cin / 16, Cout, Cin, 0, 0,
+    Wg3Args a{(const unsigned short*)dy_f16k, (const unsigned short*)x_f16k, (float*)workspace, B, H, W, Cout / 16, Cin / 16, Cout, Cin, 0, 0, 96, 64,
               ceil_div(W, TC), ceil_div(H, TR), 0};
     a.ntiles = a.tiles_w * a.tiles_h * B;
     // channel groups of up to 96 output x 64 input channels (6 waves: at most two per SIMD, so the 9 accumulator tiles of a wave
     // fit its register budget); each group: one workgroup per CU taking a strided share of the pixel tiles.  Equally shaped groups
     // -- (full, full), (remainder, full), (full, remainder), (remainder, remainder) -- go out as ONE launch each (blockIdx.y).
     const int na = Cout / 96, ra = (Cout % 96) / 32, nqf = Cin / 64, rq = (Cin % 64) / 32;
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;
     auto go = [&](int a0, int q0, int ma, int nq, int ga, int gq) {
         if (ga <= 0 || gq <= 0 || ma <= 0 || nq <= 0) return;
         a.a0 = a0; a.q0 = q0; a.gq = gq;
+        // workgroups per channel group: 256 where the picture has that many tiles (Independent_EN); at latent resolution (64 tiles,
+        // up to 16 groups: the hyper transforms) one round of the CUs over ALL groups -- every workgroup ends with a full group tile
+        // of float atomics (55 296 of them), and 1024 single-tile workgroups spent 190 us of which ~150 were those atomics
+        int grid = a.ntiles < 256 ? a.ntiles : 256;
+        if (a.ntiles < 256 && grid * ga * gq > 256) grid = 256 / (ga * gq) > 0 ? 256 / (ga * gq) : 1;
         switch (ma * 4 + nq) {
             case 1 * 4 + 1: launch<1, 1>(a, grid, ga * gq, st); break;
             case 1 * 4 + 2: launch<1, 2>(a, grid, ga * gq, st); break;
@@ -400,8 +410,47 @@ extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
     const int AQ = Cin * Cout;
     int tb = (9 * AQ + 255) / 256;
     if (tb > 2048) tb = 2048;
-    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, workspace_clean);
+    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, 9, workspace_clean);
     return masic_launch_status("conv3x3_wgrad_f16k");
+}
+
+extern "C" size_t masic_conv5x5_wgrad_f16k_workspace_bytes(int Cin, int Cout) { return (size_t)25 * Cin * Cout * sizeof(float); }
+
+// dW [Cout][Cin][5][5] (float32) of Conv2d(Cin -> Cout, k5, s1, p2) from x and dy in F16K (Cin, Cout multiples of 32): the 5x5
+// stride-1 layers at latent resolution -- encode_hyper's first layer (MASIC.py:222) and the context model (MaskedConv2d, :627; its
+// masked taps get their dense gradient like everywhere else: the reference masks weight.data, not the gradient).  The 3x3 kernel
+// with five kernel-row waves per 32 input channels: workgroup = 64 output x 32 input channels x 25 taps (5 waves, 10 accumulator
+// tiles each).  workspace: masic_conv5x5_wgrad_f16k_workspace_bytes; workspace_clean as masic_conv3x3_wgrad_f16k_ws.
+extern "C" int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
+                                           int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream) {
+    MASIC_REQUIRE(x_f16k && dy_f16k && dw && workspace, MASIC_ERR_ARG, "conv5x5_wgrad_f16k: null pointer");
+    MASIC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, MASIC_ERR_UNSUPPORTED,
+                  "conv5x5_wgrad_f16k: needs Cin, Cout multiples of 32");
+    MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv5x5_wgrad_f16k: tensor too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (!workspace_clean && masic_zero_async(workspace, masic_conv5x5_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+        masic_set_error("conv5x5_wgrad_f16k: workspace memset failed");
+        return MASIC_ERR_LAUNCH;
+    }
+    Wg3Args a{(const unsigned short*)dy_f16k, (const unsigned short*)x_f16k, (float*)workspace, B, H, W, Cout / 16, Cin / 16, Cout, Cin, 0, 0, 64, 32,
+              ceil_div(W, TC), ceil_div(H, TR), 0};
+    a.ntiles = a.tiles_w * a.tiles_h * B;
+    const int na = Cout / 64, ra = (Cout % 64) / 32, nq = Cin / 32;
+    auto go = [&](int a0, int ma, int ga) {
+        if (ga <= 0 || ma <= 0) return;
+        a.a0 = a0; a.q0 = 0; a.gq = nq;
+        int grid = a.ntiles < 256 ? a.ntiles : 256;          // (one round of the CUs over all groups at latent resolution, as the 3x3 layers)
+        if (a.ntiles < 256 && grid * ga * nq > 256) grid = 256 / (ga * nq) > 0 ? 256 / (ga * nq) : 1;
+        if (ma == 2) launch<2, 1, 5>(a, grid, ga * nq, st);
+        else launch<1, 1, 5>(a, grid, ga * nq, st);
+    };
+    go(0, 2, na);
+    go(64 * na, ra, 1);
+    const int AQ = Cin * Cout;
+    int tb = (25 * AQ + 255) / 256;
+    if (tb > 2048) tb = 2048;
+    hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, 25, workspace_clean);
+    return masic_launch_status("conv5x5_wgrad_f16k");
 }
 
 // dw [CA][CQ] (float32) = sum over batch and pixels of rows[b][a][p] * cols[b][q][p], both operands F16K ([B][C/16][HW][16] bf16),

@@ -1277,6 +1277,21 @@ def gemm_wgrad_f16k(rows16, cols16, B, CA, CQ, HW):
     return dw
 
 
+def conv5x5_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
+    """dW [Cout, Cin, 5, 5] (float32) of Conv2d(k5, s1, p2) from x and dy in F16K (bf16 operands, float32 accumulate)."""
+    if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:
+        raise RuntimeError("masic_amd.conv5x5_wgrad_f16k: F16K buffer sizes do not match (B, C, H, W)")
+    dw = torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x16.device)
+    n = lib.masic_conv5x5_wgrad_f16k_workspace_bytes(Cin, Cout) // 4
+    ws = _clean_workspace(x16.device, n)
+    try:
+        check(lib.masic_conv5x5_wgrad_f16k_ws(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, 1, _stream()), "conv5x5_wgrad_f16k")
+    except Exception:
+        _drop_workspace(x16.device, n)
+        raise
+    return dw
+
+
 def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     """dW [Cout, Cin, 3, 3] (float32) of Conv2d(k3, s1, p1) from x and dy in F16K (bf16 operands, float32 accumulate)."""
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:

@@ -327,6 +327,28 @@ def test_conv3x3_wgrad_f16k_vs_torch(B, Cin, Cout, H, W):
     assert_close(got, ref, f"conv3x3_wgrad_f16k {Cin}->{Cout}", 1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 192, 384, 16, 24), (1, 32, 96, 7, 9), (8, 192, 128, 32, 32), (1, 64, 32, 20, 70), (3, 288, 384, 8, 8)])
+def test_conv5x5_wgrad_f16k_vs_torch(B, Cin, Cout, H, W):
+    """Weight gradient of the 5x5 stride-1 layers at latent resolution (encode_hyper[0], the context model: reference MASIC.py:170-187,
+    :627) from F16K operands -- the 3x3 kernel with five kernel-row waves; several tiles per workgroup, ragged tiles, a 32-channel
+    remainder group -- against torch's convolution weight gradient on the bf16-rounded operands.  (3, 288, 384, 8, 8): the 3x3
+    kernel's own workgroup cap at latent resolution, through conv3x3_wgrad_f16k."""
+    from masic_amd import ops
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(_bf(x), (Cout, Cin, 5, 5), _bf(dy), padding=2)
+    got = ops.conv5x5_wgrad_f16k(ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV)), B, Cin, Cout, H, W)
+    assert_close(got, ref, f"conv5x5_wgrad_f16k {Cin}->{Cout}", 1e-5)
+    if (H, W) == (8, 8):
+        ref3 = torch.nn.grad.conv2d_weight(_bf(x), (Cout, Cin, 3, 3), _bf(dy), padding=1)
+        got3 = ops.conv3x3_wgrad_f16k(ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV)), B, Cin, Cout, H, W)
+        assert_close(got3, ref3, f"conv3x3_wgrad_f16k {Cin}->{Cout} at latent resolution", 1e-5)
+    # the persistent workspace is clean again: a second call gives the same result
+    again = ops.conv5x5_wgrad_f16k(ops.nchw_to_f16k(x.to(DEV)), ops.nchw_to_f16k(dy.to(DEV)), B, Cin, Cout, H, W)
+    assert_close(again, ref, "second call on the same workspace", 1e-5)
+
+
 @pytest.mark.parametrize("C,H,W", [(32, 64, 96), (96, 40, 72)])
 def test_enhancement_block_fused_training_node_vs_float32_graph(C, H, W, monkeypatch):
     """bf16 mode trains Enhancement_Block (reference MASIC.py:149-164) as ONE node, forward and backward on F16K buffers
