@@ -232,6 +232,14 @@ int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* 
 /* The same for Conv2d(Cin -> Cout, k5, s1, p2): encode_hyper's first layer and the context model at latent resolution
  * (reference MASIC.py:170-187, :627; a MaskedConv2d gets the dense gradient -- the reference masks weight.data, not the gradient).
  * dw: float32 [Cout][Cin][5][5]; workspace_clean as masic_conv2d_wgrad_ws. */
+/* Weight gradient (float32, 128 x 3 x 5 x 5) of the two picture-end 5x5 stride-2 layers in the bf16 mode -- g_a_conv1 = Conv2d(3 -> 128)
+ * (MASIC.py:515) and g_s_conv4 = ConvTranspose2d(128 -> 3) (:550): p_f16k = the 128-channel tensor at Hc x Wc in F16K (dy of the
+ * former: dW = [Cout][Cin][5][5]; x of the latter: dW = [Cin][Cout][5][5]), q = the 3-channel tensor at 2 Hc x 2 Wc, float32 NCHW
+ * (channels q_coff .. q_coff + 2 of q_ctot).  Per-workgroup partials + a finishing pass: deterministic.  workspace:
+ * masic_pic_wgrad_f16k_workspace_bytes() bytes, contents irrelevant on entry and exit. */
+size_t masic_pic_wgrad_f16k_workspace_bytes(void);
+int masic_pic_wgrad_f16k(const void* p_f16k, const float* q, float* dw, void* workspace, int B, int Hc, int Wc,
+                         int q_ctot, int q_coff, void* stream);
 size_t masic_conv5x5_wgrad_f16k_workspace_bytes(int Cin, int Cout);
 int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* dw, void* workspace,
                                 int B, int Cin, int Cout, int H, int W, int workspace_clean, void* stream);

@@ -87,6 +87,8 @@ SIGNATURES = {
     "masic_conv3x3_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_gemm_wgrad_f16k": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "masic_conv3x3_wgrad_f16k_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_pic_wgrad_f16k_workspace_bytes": (c_size_t, []),
+    "masic_pic_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv5x5_wgrad_f16k_workspace_bytes": (c_size_t, [c_int, c_int]),
     "masic_conv5x5_wgrad_f16k_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv_f16k_set_stamps": (None, [_P]),

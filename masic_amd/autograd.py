@@ -89,22 +89,36 @@ class ConvFn(Function):
 _PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
 _GDN_BWD_SMALL = os.environ.get("MASIC_GDN_BWD_SMALL", "1") != "0"   # 0: GDN(3) backward as the nine-launch generic chain (A/B timing)
 _WGRAD5_F16K = os.environ.get("MASIC_WGRAD5_F16K", "1") != "0"     # 0: 5x5 stride-1 weight gradients on the float32-tile kernel (A/B timing)
+_PIC_WGRAD = os.environ.get("MASIC_PIC_WGRAD", "1") != "0"         # 0: weight gradients of g_a_conv1 / g_s_conv4 on the float32-tile kernel (A/B timing)
 _WGRAD1_F16K = os.environ.get("MASIC_WGRAD1_F16K", "1") != "0"     # 0: 1x1 weight gradients on the float32 NCHW kernel (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
 
 
-def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None, g16=None, gb=None, gx_f16k=False):
+def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb=True, x16=None, g16=None, gb=None, gx_f16k=False,
+                  x_shape=None, g_shape=None):
     """(dx, dW, db) of y = act(conv(x, W) + b) for the module's layer geometry; x, g float32 NCHW (x16: x in F16K if the caller has it).
     g16 / gb: dy in F16K and its channel sums when the caller's producer already wrote them (ops.gdn_bwd_fused_ex): no conversion and
     no reduction pass here.  gx_f16k: return dx as an F16K buffer (int16) when the F16K kernel computes it (the consumer is another
     F16K-operand kernel), float32 NCHW otherwise.
+    x = None / g = None with x_shape / g_shape: the caller has that tensor in F16K only (x16 / g16 + gb) -- the picture-end layers, whose
+    weight gradient reads the 128-channel operand in F16K (ops.pic_wgrad_f16k) and never needs its float32 NCHW form.
     (Issuing dW / db on a side stream next to dx was measured: 24.9 -> 25.2 ms per HSIC training step, i.e. nothing -- not kept.)"""
-    g = _c(g)
-    if act != ops.ACT_NONE:
-        g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=act)
+    if g is None:
+        if g16 is None or g_shape is None or act != ops.ACT_NONE or (need_gb and gb is None):
+            raise RuntimeError("masic_amd.conv_backward: g = None needs g16, g_shape, the bias gradient and no activation")
+    else:
+        g = _c(g)
+        g_shape = tuple(g.shape)
+        if act != ops.ACT_NONE:
+            g = ops.elementwise(ops.EW_ACT_BWD, g, y, s0=act)
+    if x is None:
+        if x16 is None or x_shape is None:
+            raise RuntimeError("masic_amd.conv_backward: x = None needs x16 and x_shape")
+    else:
+        x_shape = tuple(x.shape)
     kh, kw, s, p = mod._geometry()
-    B, Cin, Hi, Wi = x.shape
-    Cout, Ho, Wo = g.shape[1], g.shape[2], g.shape[3]
+    B, Cin, Hi, Wi = x_shape
+    Cout, Ho, Wo = g_shape[1], g_shape[2], g_shape[3]
     from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
     bf16 = _mnn._PRECISION != PREC_F32
     d = d16 = None
@@ -121,10 +135,10 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             dx_f16k = ops.conv_f16k_supported(d16)
     # 3x3 stride-1 layers (Independent_EN, hyper transforms): dW from both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
     dw_f16k = (need_gw and _WGRAD3_F16K and bf16 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
-               and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
+               and Cin % 32 == 0 and Cout % 32 == 0 and x_shape[1] == Cin)
     # 5x5 stride-1 layers at latent resolution (encode_hyper[0], the context model): the same kernel with five kernel-row waves
     dw5_f16k = (need_gw and _WGRAD5_F16K and bf16 and not mod.transposed_conv and (kh, kw, s, p) == (5, 5, 1, 2)
-                and Cin % 32 == 0 and Cout % 32 == 0 and x.shape[1] == Cin)
+                and Cin % 32 == 0 and Cout % 32 == 0 and x_shape[1] == Cin)
     if g16 is None or act != ops.ACT_NONE:
         g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k or dw5_f16k) else None  # dy in F16K, converted once for both gradients
 
@@ -133,6 +147,16 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     # these forms their input gradients run on the float32 NCHW kernels (266 / 170 us per launch at 8 x 512 x 512)
     dx_d2s = pic_end and not mod.transposed_conv and Cin <= 8 and Cout % 32 == 0 and g16 is not None
     dx_conv_a = pic_end and mod.transposed_conv and (Cin, Cout) == (128, 3) and gx_f16k
+
+    # ... and their weight gradients: the 128-channel operand in F16K (dy of g_a_conv1, x of g_s_conv4), the 3-channel one float32 NCHW
+    dw_pic = 0
+    if need_gw and _PIC_WGRAD and bf16 and act == ops.ACT_NONE and (kh, kw, s, p) == (5, 5, 2, 2):
+        if not mod.transposed_conv and (Cin, Cout) == (3, 128) and g16 is not None and x is not None and (Hi, Wi) == (2 * Ho, 2 * Wo):
+            dw_pic = 1
+        elif mod.transposed_conv and (Cin, Cout) == (128, 3) and x16 is not None and g is not None and (Ho, Wo) == (2 * Hi, 2 * Wi):
+            dw_pic = 2
+    if (x is None or g is None) and not dw_pic:
+        raise RuntimeError("masic_amd.conv_backward: x / g given in F16K only, but this layer's weight gradient needs the NCHW tensor")
 
     def input_gradient():
         if dx_d2s:
@@ -150,12 +174,15 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
         if dx_f16k:
             return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=not (gx_f16k and Cin % 16 == 0))
-        return ops.conv2d(g if g.dtype == torch.float32 else g.float(), ops.pack_conv_weight(weight.detach(), d), None, d)
+        g32 = ops.f16k_to_nchw_dev(g16, B, Cout, Ho, Wo) if g is None else (g if g.dtype == torch.float32 else g.float())
+        return ops.conv2d(g32, ops.pack_conv_weight(weight.detach(), d), None, d)
 
     def parameter_gradients():
         gw = None
         gb_ = gb if act == ops.ACT_NONE else None
-        if need_gw and _WGRAD1_F16K and dx_gemm and x16 is not None and g16 is not None and x.shape[1] == Cin:
+        if dw_pic:
+            gw = (ops.pic_wgrad_f16k(g16, x, B, Ho, Wo) if dw_pic == 1 else ops.pic_wgrad_f16k(x16, g, B, Hi, Wi)).view(tuple(weight.shape))
+        elif need_gw and _WGRAD1_F16K and dx_gemm and x16 is not None and g16 is not None and x_shape[1] == Cin:
             # 1x1 layers: both operands are in F16K already (the forward GEMM's input, the input-gradient GEMM's dy)
             gw = (ops.gemm_wgrad_f16k(x16, g16, B, Cin, Cout, Hi * Wi) if mod.transposed_conv
                   else ops.gemm_wgrad_f16k(g16, x16, B, Cout, Cin, Hi * Wi)).view(tuple(weight.shape))
@@ -589,7 +616,7 @@ def _wgrad_b16(mod, B, hw_in):
                                                              transposed=mod.transposed_conv, prec=PREC_BF16))
 
 
-def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True, want_b16=False):
+def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True, want_b16=False, want_nchw=True):
     """GDN backward inside the fused transforms: (dx NCHW -- float32, or bf16 with want_b16 --, dx F16K | None, channel sums of dx | None,
     d beta, d gamma); u16: the GDN's saved input (F16K), g: float32 NCHW or F16K."""
     if not _GDN_BWD_F16K:
@@ -597,7 +624,7 @@ def _gdn_backward_f16k(u16, g, shape, gdn, want_f16k=True, want_b16=False):
         g32 = g if g.dtype == torch.float32 else ops.f16k_to_nchw_dev(g, B, C, H, W)
         gx, gb, gg = gdn_backward(ops.f16k_to_nchw_dev(u16, B, C, H, W), g32, gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min)
         return gx, None, None, gb, gg
-    return ops.gdn_bwd_fused_ex(u16, _c(g), shape, gdn.beta.detach(), gdn.gamma.detach(), gdn.inverse, gdn.beta_min, want_nchw=True,
+    return ops.gdn_bwd_fused_ex(u16, _c(g), shape, gdn.beta.detach(), gdn.gamma.detach(), gdn.inverse, gdn.beta_min, want_nchw=want_nchw,
                                 want_f16k=want_f16k, want_sum=True, want_b16=want_b16 and _WGRAD_B16)
 
 
@@ -756,8 +783,12 @@ class AnalysisFn(Function):
             gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i], want_b16=b16)
             gx, grads["w%d" % (i + 1)], grads["b%d" % (i + 1)] = conv_backward(convs[i], nchw(a_in, hw_in, b16), convs[i].weight, None, gu, ops.ACT_NONE,
                                                                                 g16=gu16, gb=gsum, gx_f16k=_GDN_BWD_F16K)
-        gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0], want_f16k=ctx.needs_input_grad[0])
-        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], g16=gu16, gb=gsum)
+        # the first layer takes dy in F16K for both gradients (ops.pic_wgrad_f16k, the depth-to-space input gradient): no float32 NCHW dx here
+        f16k_only = _GDN_BWD_F16K and _PIC_WGRAD and _PIC_END_DGRAD and tuple(x.shape[2:]) == (2 * ctx.sizes[0][0], 2 * ctx.sizes[0][1])
+        gu, gu16, gsum, grads["beta1"], grads["gamma1"] = _gdn_backward_f16k(u1, gx, (B, 128) + tuple(ctx.sizes[0]), gdns[0],
+                                                                             want_f16k=ctx.needs_input_grad[0] or f16k_only, want_nchw=not f16k_only)
+        gimg, grads["w1"], grads["b1"] = conv_backward(convs[0], x, convs[0].weight, None, gu, ops.ACT_NONE, need_gx=ctx.needs_input_grad[0], g16=gu16, gb=gsum,
+                                                       g_shape=(B, 128) + tuple(ctx.sizes[0]))
         return (gimg, None, grads["w1"], grads["b1"], grads["beta1"], grads["gamma1"], grads["w2"], grads["b2"], grads["beta2"], grads["gamma2"],
                 grads["w3"], grads["b3"], grads["beta3"], grads["gamma3"], grads["w4"], grads["b4"])
 
@@ -818,7 +849,12 @@ class SynthesisFn(Function):
         B = y_hat.shape[0]
         nchw = lambda t16, hw, bf16=False: ops.f16k_to_nchw_dev(t16, B, 128, hw[0], hw[1], bf16=bf16)
         grads = {}
-        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], nchw(a3, ctx.sizes[2]), convs[3].weight, None, g, ops.ACT_NONE, gx_f16k=_GDN_BWD_F16K)
+        # the last layer's weight gradient reads its saved input where it is, in F16K (ops.pic_wgrad_f16k): no float32 NCHW copy of a3
+        hw3 = tuple(ctx.sizes[2])
+        f16k_only = (_GDN_BWD_F16K and _PIC_WGRAD and _PIC_END_DGRAD and tuple(convs[3].weight.shape[:2]) == (128, 3)
+                     and tuple(g.shape[2:]) == (2 * hw3[0], 2 * hw3[1]))
+        gx, grads["w4"], grads["b4"] = conv_backward(convs[3], None if f16k_only else nchw(a3, hw3), convs[3].weight, None, g, ops.ACT_NONE,
+                                                     gx_f16k=_GDN_BWD_F16K, x16=a3, x_shape=(B, 128) + hw3)
         for i, (u, a_in, hw, hw_in) in ((2, (u3, a2, ctx.sizes[2], ctx.sizes[1])), (1, (u2, a1, ctx.sizes[1], ctx.sizes[0]))):
             b16 = _wgrad_b16(convs[i], B, hw_in)       # the weight gradient's two operands as bf16 NCHW: half the bytes on every side of it
             gu, gu16, gsum, grads["beta%d" % (i + 1)], grads["gamma%d" % (i + 1)] = _gdn_backward_f16k(u, gx, (B, 128) + tuple(hw), gdns[i], want_b16=b16)

@@ -344,6 +344,159 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ picture-end layers
+// dW[a][q][kh][kw] = sum_{b,r,c} P[b][a][r][c] * Q[b][q][2r + kh - 2][2c + kw - 2]: the weight gradient of the two 5x5 stride-2 layers
+// at the picture -- g_a_conv1 = Conv2d(3 -> 128) (MASIC.py:515: P = dy, Q = x, dW [Cout][Cin][5][5]) and g_s_conv4 =
+// ConvTranspose2d(128 -> 3) (:550: P = x, Q = dy, dW [Cin][Cout][5][5]) -- five times per training step (three analysis passes, two
+// synthesis passes).  A 128 x 75 x (B Hc Wc) GEMM whose contraction index is the coarse pixel: 10 GFLOP, bound by reading P.  The
+// tap-packing float32-tile kernel (conv_wgrad.hip: conv_wgrad_packed_f32) reads P as float32 NCHW and gathers its fragments with
+// 4-byte LDS reads: 165 us.  Here P is read where it already lives in the bf16 mode, F16K (the GDN backward's dx / the saved input
+// of the last synthesis layer: 134 MB instead of 268, by DMA, fragments by transposed LDS reads as above), and the Q operand is
+// built in LDS as an im2col tile: lane = coarse pixel, wave = q channel, 15 coalesced 8-byte loads of its 5 x 6 fine window, rounded
+// to bf16 and stored as the two 16-"channel" records (taps 0..15, 16..24 + zeros) of that pixel -- the layout the transposed read
+// expects.  Workgroup = 4 waves, k-tiles of 64 coarse pixels, two buffers (61 KB: two workgroups per CU), wave w owns output
+// channels 32w .. 32w+31 x 3 q x 25 taps (three accumulators).  Each workgroup stores one partial of the 9 600 weights; a finishing
+// pass adds the partials in index order (deterministic, no atomics, nothing to zero).
+constexpr int WP_PLANE = 64 * 32 + 128;              // 64 records of 32 bytes + the bank offset between planes
+constexpr int WP_PBYTES = 8 * WP_PLANE, WP_QBYTES = 6 * WP_PLANE, WP_BUF = WP_PBYTES + WP_QBYTES;
+constexpr int WP_NOUT = 128 * 75;
+
+struct WgPicArgs {
+    const unsigned short* p16;    // F16K [B][8][HWc][16]
+    const float* q;               // float32 NCHW [B][q_ctot][2 Hc][2 Wc], channels q_coff .. q_coff + 2
+    float* part;                  // [gridDim.x][128][3][25]
+    int B, Hc, Wc, q_ctot, q_coff, tpi, ntk;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = a.Hc * a.Wc, Hf = 2 * a.Hc, Wf = 2 * a.Wc;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.p16, 0, a.B * 8 * HW * 32, 0x00020000);
+    // P: DMA instruction i = wave + 4 j, j < 4: plane i >> 1, pixel half i & 1 (32 records of 32 bytes, 2 lanes each)
+    auto issue_p = [&](int kt, int buf) {
+        const bool real = kt < a.ntk;
+        const int kk = real ? kt : 0;
+        const int b = kk / a.tpi, p0 = (kk - b * a.tpi) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave + 4 * j;
+            const int pl = i >> 1, half = i & 1;
+            const int px = p0 + half * 32 + (lane >> 1);
+            const int voff = (real && px < HW) ? px * 32 + (lane & 1) * 16 : 0x7ffffff0;
+            dma16(rp, lds + buf * WP_BUF + pl * WP_PLANE + half * 1024, voff, ((b * 8 + pl) * HW) * 32);
+        }
+    };
+    // Q: waves 0..2 = channel q, lane = coarse pixel: fine rows 2r-2 .. 2r+2, columns 2c-2 .. 2c+3 as three 8-byte loads per row
+    float2 qv[5][3];
+    auto load_q = [&](int kt) {
+        const bool real = kt < a.ntk && wave < 3;
+        const int kk = kt < a.ntk ? kt : 0;
+        const int b = kk / a.tpi, px = (kk - b * a.tpi) * 64 + lane;
+        const int r = px / a.Wc, c = px - r * a.Wc;
+        const float* qb = a.q + ((size_t)b * a.q_ctot + a.q_coff + (wave < 3 ? wave : 0)) * (size_t)Hf * Wf;
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int fh = 2 * r + rr - 2, fw = 2 * c - 2 + 2 * j;
+                const bool ok = real && px < HW && fh >= 0 && fh < Hf && fw >= 0 && fw < Wf;
+                qv[rr][j] = ok ? *(const float2*)(qb + (size_t)fh * Wf + fw) : make_float2(0.0f, 0.0f);
+            }
+    };
+    auto store_q = [&](int buf) {
+        if (wave >= 3) return;
+        // taps t = 5 kh + kw -> column t of this q's 32: plane 2q holds t 0..15, plane 2q+1 t 16..31 (25..31 zero)
+        unsigned short h[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            float v = 0.0f;
+            if (t < 25) { const int kh = t / 5, kw = t - 5 * kh; v = (kw & 1) ? qv[kh][kw >> 1].y : qv[kh][kw >> 1].x; }
+            h[t] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+        unsigned char* dst = lds + buf * WP_BUF + WP_PBYTES + (2 * wave) * WP_PLANE + lane * 32;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                v4u w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = (unsigned)h[pl * 16 + hf * 8 + 2 * k] | ((unsigned)h[pl * 16 + hf * 8 + 2 * k + 1] << 16);
+                *(v4u*)(dst + pl * WP_PLANE + hf * 16) = w;
+            }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned lane_off = (g4 & 1) * WP_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
+    const unsigned la = ldsb + (2 * wave) * WP_PLANE + lane_off;
+    const unsigned lb = ldsb + WP_PBYTES + lane_off;                   // + n * 2 planes
+
+    int kt = blockIdx.x, buf = 0;
+    issue_p(kt, 0);
+    load_q(kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_q(0);
+    __syncthreads();
+    for (; kt < a.ntk; kt += gridDim.x, buf ^= 1) {
+        issue_p(kt + gridDim.x, buf ^ 1);        // (the other buffer was last read in the previous iteration, which ended with a barrier)
+        load_q(kt + gridDim.x);
+        const unsigned ba = la + buf * WP_BUF, bb = lb + buf * WP_BUF;
+        sfor<0, 4>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            v2u af[2], bfr[3][2];
+            tr_read<ks * 16 * 32>(af[0], ba);
+            tr_read<ks * 16 * 32 + 128>(af[1], ba);
+            sfor<0, 3>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                tr_read<n * 2 * WP_PLANE + ks * 16 * 32>(bfr[n][0], bb);
+                tr_read<n * 2 * WP_PLANE + ks * 16 * 32 + 128>(bfr[n][1], bb);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            depend(af[0], af[1]);
+            sfor<0, 3>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                depend(bfr[n][0], bfr[n][1]);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[0], af[1]), frag(bfr[n][0], bfr[n][1]), acc[n], 0, 0, 0);
+            });
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's P records have landed, its Q window is in registers
+        store_q(buf ^ 1);
+        __syncthreads();                                            // everyone has read `buf` and written / received `buf ^ 1`
+    }
+    // accumulator n: row (a) = 32 wave + 8 (e >> 2) + 4 h + (e & 3), column (tap) = lane & 31
+    const int t = lane & 31, h = lane >> 5;
+    float* mine = a.part + (size_t)blockIdx.x * WP_NOUT;
+    if (t < 25) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = 32 * wave + 8 * (e >> 2) + 4 * h + (e & 3);
+                mine[(ch * 3 + n) * 25 + t] = acc[n][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_pic_finish(const float* __restrict__ part, float* __restrict__ dw, int nparts) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= WP_NOUT) return;
+    float s = 0.0f;
+    for (int i0 = 0; i0 < nparts; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = i0 + j < nparts ? part[(size_t)(i0 + j) * WP_NOUT + o] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    dw[o] = s;
+}
+
 template <int MA, int NQ, int KS = 3>
 void launch(const Wg3Args& a, int grid, int groups, hipStream_t st) {
     auto kfn = wgrad3x3_f16k<MA, NQ, KS>;
@@ -451,6 +604,32 @@ extern "C" int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
     if (tb > 2048) tb = 2048;
     hipLaunchKernelGGL(wgrad3_transpose_kernel, dim3(tb), dim3(256), 0, st, (float*)workspace, dw, AQ, 25, workspace_clean);
     return masic_launch_status("conv5x5_wgrad_f16k");
+}
+
+constexpr int WP_MAX_WGS = 512;
+extern "C" size_t masic_pic_wgrad_f16k_workspace_bytes() { return (size_t)WP_MAX_WGS * WP_NOUT * sizeof(float); }
+
+// dW (float32, 128 x 3 x 5 x 5) of the picture-end 5x5 stride-2 layers in the bf16 mode: p_f16k = the 128-channel tensor at the
+// coarse resolution (Hc x Wc) in F16K -- dy of Conv2d(3 -> 128) (dW = [Cout][Cin][5][5]) or x of ConvTranspose2d(128 -> 3) (dW =
+// [Cin][Cout][5][5]) --, q = the 3-channel tensor at 2 Hc x 2 Wc, float32 NCHW (channels q_coff .. q_coff + 2 of q_ctot).
+// workspace: masic_pic_wgrad_f16k_workspace_bytes() bytes, contents irrelevant on entry and exit.
+extern "C" int masic_pic_wgrad_f16k(const void* p_f16k, const float* q, float* dw, void* workspace, int B, int Hc, int Wc,
+                                    int q_ctot, int q_coff, void* stream) {
+    MASIC_REQUIRE(p_f16k && q && dw && workspace, MASIC_ERR_ARG, "pic_wgrad_f16k: null pointer");
+    MASIC_REQUIRE(B > 0 && Hc > 0 && Wc > 0 && q_coff >= 0 && q_coff + 3 <= q_ctot, MASIC_ERR_SHAPE, "pic_wgrad_f16k: bad shape");
+    MASIC_REQUIRE((long)B * 128 * Hc * Wc * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "pic_wgrad_f16k: tensor too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    WgPicArgs a{(const unsigned short*)p_f16k, q, (float*)workspace, B, Hc, Wc, q_ctot, q_coff, ceil_div(Hc * Wc, 64), 0};
+    a.ntk = a.B * a.tpi;
+    const int grid = a.ntk < WP_MAX_WGS ? a.ntk : WP_MAX_WGS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_pic_f16k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_pic_f16k, dim3(grid), dim3(256), 2 * WP_BUF, st, a);
+    hipLaunchKernelGGL(wgrad_pic_finish, dim3(ceil_div(WP_NOUT, 256)), dim3(256), 0, st, (const float*)workspace, dw, grid);
+    return masic_launch_status("pic_wgrad_f16k");
 }
 
 // dw [CA][CQ] (float32) = sum over batch and pixels of rows[b][a][p] * cols[b][q][p], both operands F16K ([B][C/16][HW][16] bf16),

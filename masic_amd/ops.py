@@ -1277,6 +1277,25 @@ def gemm_wgrad_f16k(rows16, cols16, B, CA, CQ, HW):
     return dw
 
 
+_PIC_WGRAD_WS = {}
+
+
+def pic_wgrad_f16k(p16, q, B, Hc, Wc, q_coff=0):
+    """dW (float32, flat 128*3*25 = [a][q][5][5]) of the picture-end 5x5 stride-2 layers (masic_pic_wgrad_f16k): p16 = the 128-channel
+    operand at Hc x Wc in F16K (dy of Conv2d(3 -> 128) / x of ConvTranspose2d(128 -> 3)), q = the 3-channel one, float32 NCHW at 2Hc x 2Wc."""
+    _dev(q, "q")
+    if p16.dtype != torch.int16 or p16.numel() != B * 128 * Hc * Wc or q.dim() != 4 or q.shape[0] != B or tuple(q.shape[2:]) != (2 * Hc, 2 * Wc) \
+            or q_coff + 3 > q.shape[1]:
+        raise RuntimeError("masic_amd.pic_wgrad_f16k: operand shapes do not match (B, 128, Hc, Wc) / (B, >= 3, 2 Hc, 2 Wc)")
+    key = (q.device, int(_stream().value or 0))
+    ws = _PIC_WGRAD_WS.get(key)
+    if ws is None:
+        ws = _PIC_WGRAD_WS[key] = torch.empty(lib.masic_pic_wgrad_f16k_workspace_bytes() // 4, dtype=torch.float32, device=q.device)
+    dw = torch.empty(128 * 75, dtype=torch.float32, device=q.device)
+    check(lib.masic_pic_wgrad_f16k(_p(p16), _p(q), _p(dw), _p(ws), B, Hc, Wc, q.shape[1], q_coff, _stream()), "pic_wgrad_f16k")
+    return dw
+
+
 def conv5x5_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     """dW [Cout, Cin, 5, 5] (float32) of Conv2d(k5, s1, p2) from x and dy in F16K (bf16 operands, float32 accumulate)."""
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:

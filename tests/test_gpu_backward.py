@@ -365,6 +365,32 @@ def test_conv_wgrad_bf16_nchw_operands(transposed, B, Cin, Cout, H, W):
         assert b[0].dtype == torch.bfloat16 and torch.equal(b[0], a[0].bfloat16()) and torch.equal(b[3], a[3]) and torch.equal(b[4], a[4])
 
 
+@pytest.mark.parametrize("B,Hc,Wc", [(2, 16, 24), (1, 20, 36), (3, 64, 64), (1, 5, 7)])
+def test_picture_end_weight_gradients_f16k_operand(B, Hc, Wc):
+    """ops.pic_wgrad_f16k: weight gradients of g_a_conv1 = Conv2d(3 -> 128, k5, s2) and g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)
+    (reference MASIC.py:515, :550) from the 128-channel operand in F16K and the 3-channel one in float32 NCHW, against torch autograd on
+    the bf16-rounded operands (float32 accumulation either way; ragged k-tiles, tiles that straddle image rows)."""
+    from masic_amd import ops
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    p = _rand(B, 128, Hc, Wc, seed=31)
+    q = _rand(B, 3, 2 * Hc, 2 * Wc, seed=32, scale=2.0)
+    p16 = ops.nchw_to_f16k(p.to(DEV))
+    got = ops.pic_wgrad_f16k(p16, q.to(DEV), B, Hc, Wc).cpu()
+    # Conv2d(3 -> 128): x = q, dy = p
+    w = torch.zeros(128, 3, 5, 5, requires_grad=True)
+    F.conv2d(rnd(q), w, None, stride=2, padding=2).backward(rnd(p))
+    peak = float(w.grad.abs().max())
+    assert float((got.view(128, 3, 5, 5) - w.grad).abs().max()) <= 2e-5 * peak, "conv 3 -> 128"
+    # ConvTranspose2d(128 -> 3): x = p, dy = q
+    wt = torch.zeros(128, 3, 5, 5, requires_grad=True)
+    F.conv_transpose2d(rnd(p), wt, None, stride=2, padding=2, output_padding=1).backward(rnd(q))
+    assert float((got.view(128, 3, 5, 5) - wt.grad).abs().max()) <= 2e-5 * float(wt.grad.abs().max()), "deconv 128 -> 3"
+    # a channel view of a wider tensor
+    q6 = torch.cat([_rand(B, 2, 2 * Hc, 2 * Wc, seed=33), q, _rand(B, 1, 2 * Hc, 2 * Wc, seed=34)], dim=1)
+    got6 = ops.pic_wgrad_f16k(p16, q6.to(DEV), B, Hc, Wc, q_coff=2).cpu()
+    assert torch.equal(got6, got)
+
+
 def test_picture_end_input_gradients_f16k_forms():
     """bf16 mode, input gradients of the two picture-end layers (reference MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128, k5, s2), :550
     g_s_conv4 = ConvTranspose2d(128 -> 3, k5, s2)) on the F16K kernels -- the depth-to-space transposed convolution and the
