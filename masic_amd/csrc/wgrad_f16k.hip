@@ -354,11 +354,14 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
 // of the last synthesis layer: 134 MB instead of 268, by DMA, fragments by transposed LDS reads as above), and the Q operand is
 // built in LDS as an im2col tile: lane = coarse pixel, wave = q channel, 15 coalesced 8-byte loads of its 5 x 6 fine window, rounded
 // to bf16 and stored as the two 16-"channel" records (taps 0..15, 16..24 + zeros) of that pixel -- the layout the transposed read
-// expects.  Workgroup = 4 waves, k-tiles of 64 coarse pixels, two buffers (61 KB: two workgroups per CU), wave w owns output
-// channels 32w .. 32w+31 x 3 q x 25 taps (three accumulators).  Each workgroup stores one partial of the 9 600 weights; a finishing
+// expects.  Workgroup = 4 waves, k-tiles of 64 coarse pixels, wave w owns output channels 32w .. 32w+31 x 3 q x 25 taps (three
+// accumulators).  The kernel is bound by memory latency, not by its 12 MFMAs per tile and wave: P (HBM) is requested two tiles
+// ahead -- a ring of three DMA buffers behind a counted vmcnt --, Q (25 MB, L2 resident) one tile ahead through registers; 78 KB of
+// LDS: two workgroups per CU.  Each workgroup stores one partial of the 9 600 weights; a finishing
 // pass adds the partials in index order (deterministic, no atomics, nothing to zero).
 constexpr int WP_PLANE = 64 * 32 + 128;              // 64 records of 32 bytes + the bank offset between planes
-constexpr int WP_PBYTES = 8 * WP_PLANE, WP_QBYTES = 6 * WP_PLANE, WP_BUF = WP_PBYTES + WP_QBYTES;
+constexpr int WP_PBYTES = 8 * WP_PLANE, WP_QBYTES = 6 * WP_PLANE;
+constexpr int WP_LDS = 3 * WP_PBYTES + 2 * WP_QBYTES;      // P ring of three | Q ring of two
 constexpr int WP_NOUT = 128 * 75;
 
 struct WgPicArgs {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
     const int HW = a.Hc * a.Wc, Hf = 2 * a.Hc, Wf = 2 * a.Wc;
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.p16, 0, a.B * 8 * HW * 32, 0x00020000);
     // P: DMA instruction i = wave + 4 j, j < 4: plane i >> 1, pixel half i & 1 (32 records of 32 bytes, 2 lanes each)
-    auto issue_p = [&](int kt, int buf) {
+    auto issue_p = [&](int kt, int pbuf) {
         const bool real = kt < a.ntk;
         const int kk = real ? kt : 0;
         const int b = kk / a.tpi, p0 = (kk - b * a.tpi) * 64;
@@ -386,37 +389,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
             const int pl = i >> 1, half = i & 1;
             const int px = p0 + half * 32 + (lane >> 1);
             const int voff = (real && px < HW) ? px * 32 + (lane & 1) * 16 : 0x7ffffff0;
-            dma16(rp, lds + buf * WP_BUF + pl * WP_PLANE + half * 1024, voff, ((b * 8 + pl) * HW) * 32);
+            dma16(rp, lds + pbuf * WP_PBYTES + pl * WP_PLANE + half * 1024, voff, ((b * 8 + pl) * HW) * 32);
         }
     };
-    // Q: waves 0..2 = channel q, lane = coarse pixel: fine rows 2r-2 .. 2r+2, columns 2c-2 .. 2c+3 as three 8-byte loads per row
-    float2 qv[5][3];
-    auto load_q = [&](int kt) {
-        const bool real = kt < a.ntk && wave < 3;
-        const int kk = kt < a.ntk ? kt : 0;
+    // Q: waves 0..2 = channel q, lane = coarse pixel: fine rows 2r-2 .. 2r+2, columns 2c-2 .. 2c+3 as three 8-byte loads per row.
+    // Always 15 load instructions (clamped addresses, values zeroed afterwards): the counted wait below relies on it.
+    auto load_q = [&](int kt, float2 (&qv)[5][3], unsigned (&qok)[5]) {
+        if (wave >= 3) return;
+        const bool real = kt < a.ntk;
+        const int kk = real ? kt : 0;
         const int b = kk / a.tpi, px = (kk - b * a.tpi) * 64 + lane;
         const int r = px / a.Wc, c = px - r * a.Wc;
-        const float* qb = a.q + ((size_t)b * a.q_ctot + a.q_coff + (wave < 3 ? wave : 0)) * (size_t)Hf * Wf;
+        const float* qb = a.q + ((size_t)b * a.q_ctot + a.q_coff + wave) * (size_t)Hf * Wf;
 #pragma unroll
         for (int rr = 0; rr < 5; ++rr)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int fh = 2 * r + rr - 2, fw = 2 * c - 2 + 2 * j;
                 const bool ok = real && px < HW && fh >= 0 && fh < Hf && fw >= 0 && fw < Wf;
-                qv[rr][j] = ok ? *(const float2*)(qb + (size_t)fh * Wf + fw) : make_float2(0.0f, 0.0f);
+                const int ch = fh < 0 ? 0 : (fh >= Hf ? Hf - 1 : fh), cw = fw < 0 ? 0 : (fw >= Wf ? Wf - 2 : fw);
+                qv[rr][j] = *(const float2*)(qb + (size_t)ch * Wf + cw);
+                qok[rr] = (qok[rr] & ~(1u << j)) | ((unsigned)ok << j);
             }
     };
-    auto store_q = [&](int buf) {
+    auto store_q = [&](int qbuf, float2 (&qv)[5][3], const unsigned (&okm)[5]) {
         if (wave >= 3) return;
+        // the loaded window is first touched HERE, behind the counted wait: without this the compiler converts each value to bf16 right
+        // behind its load (fewer live registers) and waits for the loads before the MFMAs they were meant to run under
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(qv[rr][j].x), "+v"(qv[rr][j].y));
         // taps t = 5 kh + kw -> column t of this q's 32: plane 2q holds t 0..15, plane 2q+1 t 16..31 (25..31 zero)
         unsigned short h[32];
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
             float v = 0.0f;
-            if (t < 25) { const int kh = t / 5, kw = t - 5 * kh; v = (kw & 1) ? qv[kh][kw >> 1].y : qv[kh][kw >> 1].x; }
+            if (t < 25) {
+                const int kh = t / 5, kw = t - 5 * kh;
+                v = (kw & 1) ? qv[kh][kw >> 1].y : qv[kh][kw >> 1].x;
+                v = ((okm[kh] >> (kw >> 1)) & 1u) ? v : 0.0f;
+            }
             h[t] = __builtin_bit_cast(unsigned short, (__bf16)v);
         }
-        unsigned char* dst = lds + buf * WP_BUF + WP_PBYTES + (2 * wave) * WP_PLANE + lane * 32;
+        unsigned char* dst = lds + 3 * WP_PBYTES + qbuf * WP_QBYTES + (2 * wave) * WP_PLANE + lane * 32;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -427,6 +443,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
                 *(v4u*)(dst + pl * WP_PLANE + hf * 16) = w;
             }
     };
+    // this wave's LDS stores are done, then the workgroup barrier -- NOT __syncthreads(), whose fence also waits for every outstanding
+    // global load / DMA (vmcnt(0)): the requests of the tile after next are meant to stay in flight across it
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     f32x16 acc[3];
 #pragma unroll
     for (int n = 0; n < 3; ++n)
@@ -435,18 +457,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
     const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     const unsigned lane_off = (g4 & 1) * WP_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
     const unsigned la = ldsb + (2 * wave) * WP_PLANE + lane_off;
-    const unsigned lb = ldsb + WP_PBYTES + lane_off;                   // + n * 2 planes
-
-    int kt = blockIdx.x, buf = 0;
-    issue_p(kt, 0);
-    load_q(kt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_q(0);
-    __syncthreads();
-    for (; kt < a.ntk; kt += gridDim.x, buf ^= 1) {
-        issue_p(kt + gridDim.x, buf ^ 1);        // (the other buffer was last read in the previous iteration, which ended with a barrier)
-        load_q(kt + gridDim.x);
-        const unsigned ba = la + buf * WP_BUF, bb = lb + buf * WP_BUF;
+    const unsigned lb = ldsb + 3 * WP_PBYTES + lane_off;               // + n * 2 planes
+    auto contract = [&](int pbuf, int qbuf) {
+        const unsigned ba = la + pbuf * WP_PBYTES, bb = lb + qbuf * WP_QBYTES;
         sfor<0, 4>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             v2u af[2], bfr[3][2];
@@ -465,10 +478,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[0], af[1]), frag(bfr[n][0], bfr[n][1]), acc[n], 0, 0, 0);
             });
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's P records have landed, its Q window is in registers
-        store_q(buf ^ 1);
-        __syncthreads();                                            // everyone has read `buf` and written / received `buf ^ 1`
+    };
+    // Pipeline: P two tiles ahead by DMA (ring of three; the compiler does not see these requests, the counted wait below does), Q one
+    // tile ahead through registers (ordinary loads requested BEFORE the tile's DMAs, first touched in store_q: the compiler's own
+    // wait covers them).  Registers that carry loads across the loop's back edge were tried for Q: the compiler's wait insertion
+    // then waits for most of the current tile's requests too, and inline-asm loads get copied while still in flight.
+    float2 qa[5][3];
+    unsigned oka[5] = {0, 0, 0, 0, 0};
+    const int st = gridDim.x;
+    int kt = blockIdx.x, pb = 0, qb_ = 0;
+    issue_p(kt, 0);
+    issue_p(kt + st, 1);
+    load_q(kt, qa, oka);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_q(0, qa, oka);
+    lds_barrier();
+    for (; kt < a.ntk; kt += st, pb = pb == 2 ? 0 : pb + 1, qb_ ^= 1) {
+        load_q(kt + st, qa, oka);
+        asm volatile("" ::: "memory");
+        issue_p(kt + 2 * st, pb == 0 ? 2 : pb - 1);     // (that slot was last read in the previous iteration, which ended with a barrier)
+        contract(pb, qb_);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but this iteration's four DMAs: the next tile's P records and Q window
+        store_q(qb_ ^ 1, qa, oka);
+        lds_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // accumulator n: row (a) = 32 wave + 8 (e >> 2) + 4 h + (e & 3), column (tap) = lane & 31
     const int t = lane & 31, h = lane >> 5;
     float* mine = a.part + (size_t)blockIdx.x * WP_NOUT;
@@ -484,17 +518,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_pic_f16k(const WgPicArgs a) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_pic_finish(const float* __restrict__ part, float* __restrict__ dw, int nparts) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= WP_NOUT) return;
+    // 64 weights per block, four slices of the partials per weight (thread = (slice, weight)), fixed order
+    __shared__ float red[4][64];
+    const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + j;
     float s = 0.0f;
-    for (int i0 = 0; i0 < nparts; i0 += 8) {
-        float v[8];
+    if (o < WP_NOUT)
+        for (int i0 = sl; i0 < nparts; i0 += 32) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = i0 + j < nparts ? part[(size_t)(i0 + j) * WP_NOUT + o] : 0.0f;
+            for (int k = 0; k < 8; ++k) v[k] = i0 + 4 * k < nparts ? part[(size_t)(i0 + 4 * k) * WP_NOUT + o] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
-    }
-    dw[o] = s;
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+    red[sl][j] = s;
+    __syncthreads();
+    if (sl == 0 && o < WP_NOUT) dw[o] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
 template <int MA, int NQ, int KS = 3>
@@ -627,8 +666,8 @@ extern "C" int masic_pic_wgrad_f16k(const void* p_f16k, const float* q, float* d
         (void)hipFuncSetAttribute((const void*)wgrad_pic_f16k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_pic_f16k, dim3(grid), dim3(256), 2 * WP_BUF, st, a);
-    hipLaunchKernelGGL(wgrad_pic_finish, dim3(ceil_div(WP_NOUT, 256)), dim3(256), 0, st, (const float*)workspace, dw, grid);
+    hipLaunchKernelGGL(wgrad_pic_f16k, dim3(grid), dim3(256), WP_LDS, st, a);
+    hipLaunchKernelGGL(wgrad_pic_finish, dim3(ceil_div(WP_NOUT, 64)), dim3(256), 0, st, (const float*)workspace, dw, grid);
     return masic_launch_status("pic_wgrad_f16k");
 }
 
