@@ -248,6 +248,10 @@ int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f16k, float* 
  * channels (multiples of 16); dw float32 [CA][CQ].  Conv2d weight [Cout][Cin]: rows = dy, cols = x; ConvTranspose2d(k1) weight
  * [Cin][Cout]: rows = x, cols = dy. */
 int masic_gemm_wgrad_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int B, int CA, int CQ, int HW, void* stream);
+/* ... with the layer's bias gradient in the same launch: bias_of 1: dw[CA*CQ .. CA*CQ + CA) = sums of the rows operand over batch and
+ * pixels (dy of a Conv2d), 2: dw[CA*CQ .. CA*CQ + CQ) = sums of the columns operand (dy of a ConvTranspose2d); dw then holds that
+ * many more floats.  0: masic_gemm_wgrad_f16k. */
+int masic_gemm_wgrad_bias_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int bias_of, int B, int CA, int CQ, int HW, void* stream);
 /* F16K in, F16K out with up to two F16K residual tensors added after the activation: out = act(conv(x) + bias) + res1 [+ res2]
  * (ResidualBlock: compressai/layers/layers.py:160-190; Enhancement_Block: MASIC.py:149-164) -- Independent_EN with bf16
  * operands keeps its 32 / 64 / 96-channel full-resolution activations in F16K.  y_f16k is a channel view (d->out_ctot / out_coff). */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "masic_conv3x3_wgrad_f16k_workspace_bytes": (c_size_t, [c_int, c_int]),
     "masic_conv3x3_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_gemm_wgrad_f16k": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "masic_gemm_wgrad_bias_f16k": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_conv3x3_wgrad_f16k_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "masic_pic_wgrad_f16k_workspace_bytes": (c_size_t, []),
     "masic_pic_wgrad_f16k": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

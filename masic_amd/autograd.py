@@ -678,9 +678,12 @@ class GmmHeadsFn(Function):
         slope = lambda act: 0.01 if act == ops.ACT_LEAKY else 0.0
         grads = [None] * 18
 
-        def wgrad(mod, a16, g16):                  # dW in the module's weight layout
+        def wgrad(mod, a16, g16, with_bias=False):  # dW in the module's weight layout (+ the bias gradient: channel sums of dy, same launch)
             Cin, Cout = mod.in_channels, mod.out_channels
-            dw = ops.gemm_wgrad_f16k(a16, g16, B, Cin, Cout, HW) if mod.transposed_conv else ops.gemm_wgrad_f16k(g16, a16, B, Cout, Cin, HW)
+            dw = (ops.gemm_wgrad_f16k(a16, g16, B, Cin, Cout, HW, bias_of=2 if with_bias else 0) if mod.transposed_conv
+                  else ops.gemm_wgrad_f16k(g16, a16, B, Cout, Cin, HW, bias_of=1 if with_bias else 0))
+            if with_bias:
+                return dw[0].view(tuple(mod.weight.shape)), dw[1]
             return dw.view(tuple(mod.weight.shape))
 
         def dgrad(level, g16s, out):               # the three stacks' input gradients of one level: one grouped GEMM on W^T
@@ -708,6 +711,9 @@ class GmmHeadsFn(Function):
                 gm = gin[k] if acts[level] == ops.ACT_NONE else ops.f16k_act_bwd(gin[k], saved[k], slope(acts[level]))
                 g16.append(gm)
                 mod = mods[k][level]
+                if mod.bias is not None and _WGRAD1_BIAS:
+                    grads[6 * k + 2 * level], grads[6 * k + 2 * level + 1] = wgrad(mod, x16 if level == 0 else t0[k], gm, with_bias=True)
+                    continue
                 if mod.bias is not None:
                     grads[6 * k + 2 * level + 1] = ops.f16k_channel_sum(gm, B, mod.out_channels, HW)
                 grads[6 * k + 2 * level] = wgrad(mod, x16 if level == 0 else t0[k], gm)
@@ -741,6 +747,7 @@ def gmm_heads(head, x):
     return GmmHeadsFn.apply(x, head, *params)
 
 
+_WGRAD1_BIAS = os.environ.get("MASIC_WGRAD1_BIAS", "1") != "0"          # 0: bias gradients of the head layers by a reduction pass of their own (A/B timing)
 _HEADS_MULTIPACK = os.environ.get("MASIC_HEADS_MULTIPACK", "1") != "0"     # 0: one pack launch per weight and orientation (A/B timing)
 _GMM_HEADS_FN = os.environ.get("MASIC_GMM_HEADS_FN", "1") != "0"     # 0: one ConvFn per head layer (A/B timing)
 

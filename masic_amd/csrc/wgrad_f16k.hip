@@ -251,6 +251,9 @@ struct Wg1Args {
     float* dw;                    // [CA][CQ] float32, zeroed by the caller
     int B, HW, CA16, CQ16, CA, CQ;
     int q_tiles, tpi, ntk, nsplit;
+    float* db;                    // bias_mode 1: [CA] sums of the rows operand over batch and pixels, 2: [CQ] sums of the columns operand
+    int bias_mode;                //   (the bias gradient of the 1x1 layer: dy is the rows operand of a Conv2d, the columns operand of a
+                                  //   ConvTranspose2d); zeroed by the caller; 0: none
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
@@ -283,6 +286,17 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
     f32x16 acc[2][2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][0][e] = 0.0f; acc[0][1][e] = 0.0f; acc[1][0][e] = 0.0f; acc[1][1][e] = 0.0f; }
+    // channel sums of dy next to the weight gradient (its bias gradient; a separate reduction pass over dy cost 20-30 us per layer):
+    // one more MFMA per fragment against a matrix of ones, in the workgroups of the first column (rows operand) / row (columns operand)
+    // of output tiles only
+    const bool bsum = a.bias_mode == 1 ? (int)blockIdx.x % a.q_tiles == 0 && wq == 0
+                                       : (a.bias_mode == 2 ? (int)blockIdx.x / a.q_tiles == 0 && wa == 0 : false);
+    f32x16 accb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accb[0][e] = 0.0f; accb[1][e] = 0.0f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
     const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     const unsigned lane_off = (g4 & 1) * W1_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
     const unsigned la = ldsb + (4 * wa) * W1_PLANE + lane_off;                    // + m * 2 planes: this wave's 64 rows = 4 planes
@@ -325,6 +339,13 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), bq, acc[m][n], 0, 0, 0);
                 });
             });
+            if (bsum) {
+                sfor<0, 2>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    if (a.bias_mode == 1) accb[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), ones, accb[m], 0, 0, 0);
+                    else accb[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, frag(bfr[pb][m][0], bfr[pb][m][1]), accb[m], 0, 0, 0);
+                });
+            }
         });
         __builtin_amdgcn_s_barrier();            // everyone is done reading this buffer before the next iteration's DMA overwrites it
     }
@@ -342,6 +363,23 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
                 if (co < a.CA) atomicAdd(a.dw + (size_t)co * a.CQ + ci, acc[m][n][e]);
             }
         }
+    if (bsum) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (a.bias_mode == 1) {            // row sums: every column of the accumulator holds them; column 0 writes
+                if (j == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = a0 + 64 * wa + 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+                        if (co < a.CA) atomicAdd(a.db + co, accb[m][e]);
+                    }
+                }
+            } else {                           // column sums: every row holds them; row 0 (h = 0, e = 0) writes
+                const int ci = q0 + 64 * wq + 32 * m + j;
+                if (h == 0 && ci < a.CQ) atomicAdd(a.db + ci, accb[m][0]);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ picture-end layers
@@ -675,15 +713,25 @@ extern "C" int masic_pic_wgrad_f16k(const void* p_f16k, const float* q, float* d
 // CA, CQ multiples of 16.  For a Conv2d(Cin -> Cout, k1) weight [Cout][Cin]: rows = dy, cols = x; for the ConvTranspose2d(k1) form
 // [Cin][Cout] (reference MASIC.py:338-376): rows = x, cols = dy.
 extern "C" int masic_gemm_wgrad_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int B, int CA, int CQ, int HW, void* stream) {
+    return masic_gemm_wgrad_bias_f16k(rows_f16k, cols_f16k, dw, 0, B, CA, CQ, HW, stream);
+}
+
+// bias_of: 0 none; 1: dw[CA*CQ .. CA*CQ + CA) = sums of the rows operand over batch and pixels; 2: dw[CA*CQ .. + CQ) = sums of the
+// columns operand -- the bias gradient of the layer (dy = rows of a Conv2d, columns of a ConvTranspose2d), in the same launch
+extern "C" int masic_gemm_wgrad_bias_f16k(const void* rows_f16k, const void* cols_f16k, float* dw, int bias_of, int B, int CA, int CQ, int HW,
+                                          void* stream) {
     MASIC_REQUIRE(rows_f16k && cols_f16k && dw, MASIC_ERR_ARG, "gemm_wgrad_f16k: null pointer");
+    MASIC_REQUIRE(bias_of >= 0 && bias_of <= 2, MASIC_ERR_ARG, "gemm_wgrad_f16k: bias_of %d", bias_of);
     MASIC_REQUIRE(B > 0 && HW > 0 && CA > 0 && CQ > 0 && CA % 16 == 0 && CQ % 16 == 0, MASIC_ERR_UNSUPPORTED, "gemm_wgrad_f16k: channel counts must be multiples of 16");
     MASIC_REQUIRE((long)B * (CA > CQ ? CA : CQ) * HW * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (masic_zero_async(dw, (size_t)CA * CQ * sizeof(float), st) != hipSuccess) {
+    const size_t nb = bias_of == 1 ? CA : (bias_of == 2 ? CQ : 0);
+    if (masic_zero_async(dw, ((size_t)CA * CQ + nb) * sizeof(float), st) != hipSuccess) {
         masic_set_error("gemm_wgrad_f16k: zero fill failed");
         return MASIC_ERR_LAUNCH;
     }
-    Wg1Args a{(const unsigned short*)rows_f16k, (const unsigned short*)cols_f16k, dw, B, HW, CA / 16, CQ / 16, CA, CQ, ceil_div(CQ, 128), ceil_div(HW, W1_PX), 0, 0};
+    Wg1Args a{(const unsigned short*)rows_f16k, (const unsigned short*)cols_f16k, dw, B, HW, CA / 16, CQ / 16, CA, CQ, ceil_div(CQ, 128), ceil_div(HW, W1_PX), 0, 0,
+               dw + (size_t)CA * CQ, bias_of};
     a.ntk = a.B * a.tpi;
     const int base = ceil_div(CA, 128) * a.q_tiles;
     // pixel splits: as many as keep the grid within ONE round of the 256 CUs -- every split adds a full output tile of float atomics

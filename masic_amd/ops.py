@@ -1267,14 +1267,18 @@ def deconv_s2_as_conv_weight_dev(weight, bias=None):
     return w, b
 
 
-def gemm_wgrad_f16k(rows16, cols16, B, CA, CQ, HW):
+def gemm_wgrad_f16k(rows16, cols16, B, CA, CQ, HW, bias_of=0):
     """dw [CA, CQ] = sum_{b,p} rows[b, a, p] * cols[b, q, p] from F16K operands (masic_gemm_wgrad_f16k): the weight gradient of a 1x1
-    layer -- Conv2d: (dy, x) -> [Cout, Cin]; ConvTranspose2d(k=1): (x, dy) -> [Cin, Cout]."""
+    layer -- Conv2d: (dy, x) -> [Cout, Cin]; ConvTranspose2d(k=1): (x, dy) -> [Cin, Cout].
+    bias_of = 1 / 2: also the sums over batch and pixels of the rows / columns operand (the layer's bias gradient when that operand is
+    dy) from the same launch; returns (dw, sums) -- two views of one buffer."""
     if rows16.dtype != torch.int16 or cols16.dtype != torch.int16 or rows16.numel() != B * CA * HW or cols16.numel() != B * CQ * HW:
         raise RuntimeError("masic_amd.gemm_wgrad_f16k: F16K buffer sizes do not match (B, C, HW)")
-    dw = torch.empty((CA, CQ), dtype=torch.float32, device=rows16.device)
-    check(lib.masic_gemm_wgrad_f16k(_p(rows16), _p(cols16), _p(dw), B, CA, CQ, HW, _stream()), "gemm_wgrad_f16k")
-    return dw
+    nb = CA if bias_of == 1 else (CQ if bias_of == 2 else 0)
+    out = torch.empty(CA * CQ + nb, dtype=torch.float32, device=rows16.device)
+    check(lib.masic_gemm_wgrad_bias_f16k(_p(rows16), _p(cols16), _p(out), int(bias_of), B, CA, CQ, HW, _stream()), "gemm_wgrad_f16k")
+    dw = out[:CA * CQ].view(CA, CQ)
+    return (dw, out[CA * CQ:]) if nb else dw
 
 
 _PIC_WGRAD_WS = {}

@@ -269,6 +269,15 @@ def test_gemm_wgrad_f16k_1x1_layers(B, Cout, Cin, H, W):
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), "Conv2d orientation"
     got_t = ops.gemm_wgrad_f16k(x16, g16, B, Cin, Cout, H * W).cpu().double()
     assert float((got_t - want.t()).abs().max()) <= 2e-5 * float(want.abs().max()), "ConvTranspose2d orientation"
+    # the bias gradient (channel sums of dy) from the same launch: dy as the rows operand (Conv2d), as the columns operand (transposed)
+    bsum = q(dy).sum(dim=(0, 2, 3))
+    dw1, db1 = ops.gemm_wgrad_f16k(g16, x16, B, Cout, Cin, H * W, bias_of=1)
+    dw2, db2 = ops.gemm_wgrad_f16k(x16, g16, B, Cin, Cout, H * W, bias_of=2)
+    assert float((dw1.cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((dw2.cpu().double() - want.t()).abs().max()) <= 2e-5 * float(want.abs().max())
+    for db in (db1, db2):
+        assert db.shape == (Cout,)
+        assert float((db.cpu().double() - bsum).abs().max()) <= 2e-5 * float(bsum.abs().max()) + 1e-4, "bias gradient"
     if Cin % 32 == 0 and Cout % 32 == 0:
         mnn.set_precision("bf16")
         try:
