@@ -412,6 +412,18 @@ int masic_copy_view(const float* x, float* y, int B, int C, int HW, int out_ctot
 size_t masic_reduce_workspace_bytes(void);
 int masic_sum_log(const float* x, size_t n, double* out, void* workspace, void* stream);
 int masic_sse(const float* a, const float* b, size_t n, double* out, void* workspace, void* stream);
+/* The rate-distortion criterion of the training step (newtrain_codec_real.py:73-87) in two launches: loss (float32) =
+ * cm (mse1 + mse2) + bpp, mse_i = sum (x_i_hat - x_i)^2 / n_pic, bpp = cb sum_k sum log lik_k, per[k] = cb sum log lik_k (float64 device
+ * scalars); nliks <= 4 (0: the distortion-only criterion of the CQE stage, newtrain_cqe_real.py:66-96).  Sums in the order of masic_sse /
+ * masic_sum_log.  workspace: masic_rd_loss_workspace_bytes().  masic_rd_loss_bwd: its gradients times the float32 device scalar g in one
+ * launch: g_x_i = (s_pic (x_i_hat - x_i)) g, g_liks[k] = (s_lik / lik_k) g. */
+size_t masic_rd_loss_workspace_bytes(void);
+int masic_rd_loss(const float* x1_hat, const float* x1, const float* x2_hat, const float* x2, size_t n_pic,
+                  const float* const* liks, const size_t* lik_n, int nliks, double cb, double cm,
+                  float* loss, double* mse1, double* mse2, double* bpp, double* const* per, void* workspace, void* stream);
+int masic_rd_loss_bwd(const float* x1_hat, const float* x1, const float* x2_hat, const float* x2, size_t n_pic,
+                      const float* const* liks, const size_t* lik_n, int nliks, float s_pic, float s_lik, const float* g,
+                      float* g_x1, float* g_x2, float* const* g_liks, void* stream);
 
 /* ==========================================================================================
  * Backward entry points (what torch autograd derives for the reference graph).

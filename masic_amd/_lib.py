@@ -142,6 +142,9 @@ SIGNATURES = {
     "masic_reduce_workspace_bytes": (c_size_t, []),
     "masic_sum_log": (c_int, [_P, c_size_t, _P, _P, _P]),
     "masic_sse": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "masic_rd_loss_workspace_bytes": (c_size_t, []),
+    "masic_rd_loss": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P, _P]),
+    "masic_rd_loss_bwd": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
     # backward
     "masic_conv2d_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "masic_conv2d_wgrad": (c_int, [_P, _P, _P, _P, ctypes.POINTER(ConvDesc), _P]),

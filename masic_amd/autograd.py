@@ -573,15 +573,20 @@ class RateDistortionFn(Function):
         B, _, H, W = x1.shape
         ctx.cb = 1.0 / (-math.log(2) * B * H * W)
         ctx.cm = lmbda * 255 ** 2
-        sums = [ops.sum_log(l) for l in liks]
-        bpp = sum(sums) * ctx.cb
-        mse1 = ops.sse(x1_hat, x1) / x1.numel()
-        mse2 = ops.sse(x2_hat, x2) / x2.numel()
         ctx.save_for_backward(x1, x2, x1_hat, x2_hat, *liks)
-        loss = (ctx.cm * (mse1 + mse2) + bpp).float()
         # the pieces of the criterion's report (bpp per likelihood tensor, the two MSEs) ride along as non-differentiable outputs: the
         # criterion used to evaluate all six reductions a second time under no_grad (~30 launches per step)
-        extras = (mse1, mse2, bpp if torch.is_tensor(bpp) else ops.zeros((), torch.float64, x1.device)) + tuple(t * ctx.cb for t in sums)
+        if _RD_FUSED and len(liks) <= 4 and all(t.dtype == torch.float32 for t in (x1, x2, x1_hat, x2_hat, *liks)):
+            # two launches: all six reductions, then every scalar of the criterion (same summation order: the same bits)
+            loss, mse1, mse2, bpp, per = ops.rd_loss(x1_hat, x1, x2_hat, x2, liks, ctx.cb, ctx.cm)
+            extras = (mse1, mse2, bpp) + tuple(per)
+        else:
+            sums = [ops.sum_log(l) for l in liks]
+            bpp = sum(sums) * ctx.cb
+            mse1 = ops.sse(x1_hat, x1) / x1.numel()
+            mse2 = ops.sse(x2_hat, x2) / x2.numel()
+            loss = (ctx.cm * (mse1 + mse2) + bpp).float()
+            extras = (mse1, mse2, bpp if torch.is_tensor(bpp) else ops.zeros((), torch.float64, x1.device)) + tuple(t * ctx.cb for t in sums)
         ctx.mark_non_differentiable(*extras)
         return (loss,) + extras
 
@@ -590,10 +595,16 @@ class RateDistortionFn(Function):
         x1, x2, x1_hat, x2_hat, *liks = ctx.saved_tensors
         # g (a device scalar, 1 for `loss.backward()`) multiplies on the device: float(g) here would make the host wait for the whole
         # forward before it may launch the first kernel of the backward
+        if _RD_FUSED and len(liks) <= 4 and g.dtype == torch.float32 and g.numel() == 1 and all(t.dtype == torch.float32 for t in (x1_hat, x2_hat, *liks)):
+            g1, g2, gl = ops.rd_loss_bwd(x1_hat, x1, x2_hat, x2, liks, ctx.cm * 2.0 / x1.numel(), ctx.cb, _c(g))     # one launch
+            return (None, None, None, g1, g2, *gl)
         g1 = ops.elementwise(ops.EW_DIFF_SCALE, x1_hat, x1, s0=ctx.cm * 2.0 / x1.numel()).mul_(g)
         g2 = ops.elementwise(ops.EW_DIFF_SCALE, x2_hat, x2, s0=ctx.cm * 2.0 / x2.numel()).mul_(g)
         gl = [ops.elementwise(ops.EW_RECIP_SCALE, l, None, s0=ctx.cb).mul_(g) for l in liks]
         return (None, None, None, g1, g2, *gl)
+
+
+_RD_FUSED = os.environ.get("MASIC_RD_FUSED", "1") != "0"             # 0: the criterion as six reductions + torch scalar arithmetic (A/B timing)
 
 
 # ------------------------------------------------------------------------------------------ fused transforms (bf16-operand training)

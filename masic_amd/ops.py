@@ -457,6 +457,50 @@ def sse(a, b):
     return out[0]
 
 
+_RD_WS = {}
+
+
+def _rd_ptrs(liks):
+    n = len(liks)
+    arr = (ctypes.c_void_p * max(n, 1))(*[l.data_ptr() for l in liks])
+    cnt = (ctypes.c_size_t * max(n, 1))(*[l.numel() for l in liks])
+    return arr, cnt
+
+
+def rd_loss(x1_hat, x1, x2_hat, x2, liks, cb, cm):
+    """The rate-distortion criterion in two launches (masic_rd_loss): returns (loss float32 0-dim, mse1, mse2, bpp, [per-tensor bpp]) --
+    float64 0-dim device tensors; loss = cm (mse1 + mse2) + bpp, bpp = cb sum_k sum log liks[k].  Up to four likelihood tensors."""
+    for t in (x1_hat, x1, x2_hat, x2, *liks):
+        _dev(t, "tensor")
+    if not (x1_hat.numel() == x1.numel() == x2_hat.numel() == x2.numel()) or len(liks) > 4:
+        raise RuntimeError("masic_amd.rd_loss: pictures of one size and at most four likelihood tensors")
+    dev = x1.device
+    key = (dev, int(_stream().value or 0))
+    ws = _RD_WS.get(key)
+    if ws is None:
+        ws = _RD_WS[key] = torch.empty(lib.masic_rd_loss_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    vals = [torch.empty((), dtype=torch.float64, device=dev) for _ in range(3 + len(liks))]
+    arr, cnt = _rd_ptrs(liks)
+    per = (ctypes.c_void_p * max(len(liks), 1))(*[v.data_ptr() for v in vals[3:]])
+    check(lib.masic_rd_loss(_p(x1_hat), _p(x1), _p(x2_hat), _p(x2), x1.numel(), arr, cnt, len(liks), float(cb), float(cm),
+                            _p(loss), _p(vals[0]), _p(vals[1]), _p(vals[2]), per, _p(ws), _stream()), "rd_loss")
+    return loss, vals[0], vals[1], vals[2], vals[3:]
+
+
+def rd_loss_bwd(x1_hat, x1, x2_hat, x2, liks, s_pic, s_lik, g):
+    """Gradients of rd_loss's loss times the float32 device scalar g, one launch: (g_x1_hat, g_x2_hat, [g_lik])."""
+    if g.dtype != torch.float32 or g.numel() != 1 or not g.is_cuda:
+        raise RuntimeError("masic_amd.rd_loss_bwd: g must be a float32 device scalar")
+    g1, g2 = torch.empty_like(x1_hat), torch.empty_like(x2_hat)
+    gl = [torch.empty_like(l) for l in liks]
+    arr, cnt = _rd_ptrs(liks)
+    outs = (ctypes.c_void_p * max(len(liks), 1))(*[t.data_ptr() for t in gl])
+    check(lib.masic_rd_loss_bwd(_p(x1_hat), _p(x1), _p(x2_hat), _p(x2), x1.numel(), arr, cnt, len(liks), float(s_pic), float(s_lik),
+                                _p(g), _p(g1), _p(g2), outs, _stream()), "rd_loss_bwd")
+    return g1, g2, gl
+
+
 # --------------------------------------------------------------------------------------------- backward kernels
 EW_ACT_BWD, EW_ABS_BWD, EW_SQUARE, EW_ABS, EW_AXPY, EW_RECIP_SCALE, EW_DIFF_SCALE, EW_MUL, EW_REPARAM, EW_REPARAM_BWD, EW_ADD = range(11)
 

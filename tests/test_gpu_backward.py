@@ -433,6 +433,30 @@ def test_picture_end_input_gradients_f16k_forms():
     assert torch.equal(w1, w2) and torch.equal(b1, b2)
 
 
+@pytest.mark.parametrize("nliks", [4, 0, 2])
+def test_rate_distortion_criterion_fused_launches(nliks, monkeypatch):
+    """RateDistortionFn (newtrain_codec_real.py:73-87; 0 likelihood tensors: the CQE stage's distortion, newtrain_cqe_real.py:66-96) as
+    two launches forward and one backward (masic_rd_loss / masic_rd_loss_bwd) against the chain of six reductions, torch scalar
+    arithmetic and per-tensor elementwise kernels it replaces: the same summation order, so every value and gradient bit for bit."""
+    from masic_amd import autograd as A
+    x1, x2 = _rand(2, 3, 40, 56, seed=1).to(DEV), _rand(2, 3, 40, 56, seed=2).to(DEV)
+    shapes = [(2, 192, 5, 7), (2, 192, 5, 7), (2, 128, 2, 2), (2, 128, 2, 2)][:nliks]
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(A, "_RD_FUSED", fused)
+        xh1 = (x1 + 0.05 * _rand(2, 3, 40, 56, seed=3).to(DEV)).requires_grad_(True)
+        xh2 = (x2 + 0.05 * _rand(2, 3, 40, 56, seed=4).to(DEV)).requires_grad_(True)
+        liks = [(_rand(*sh, seed=10 + i).to(DEV).abs() * 0.3 + 1e-3).requires_grad_(True) for i, sh in enumerate(shapes)]
+        out = A.RateDistortionFn.apply(0.01, x1, x2, xh1, xh2, *liks)
+        (out[0] * 3.0).backward()
+        res[fused] = [o.detach().clone() for o in out] + [xh1.grad, xh2.grad] + [l.grad for l in liks]
+    assert len(res[True]) == len(res[False]) == 4 + nliks + 2 + nliks
+    for got, want in zip(res[True], res[False]):
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert torch.equal(got, want)
+    assert float(res[True][0]) > 0
+
+
 def test_entropy_bottleneck_backward_and_aux():
     from compressai.entropy_models import EntropyBottleneck
     from masic_amd import synth
