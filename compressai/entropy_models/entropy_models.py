@@ -172,7 +172,11 @@ class EntropyBottleneck(EntropyModel):
     def _table(self, differentiable=False):
         if differentiable:      # one autograd node: the table gradient goes back to the 14 parameters with one launch
             from masic_amd.autograd import eb_param_table
-            return eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
+            table = eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
+            # the same values serve the detached uses until the parameters change (the auxiliary step of the same iteration)
+            params = list(self._matrices) + list(self._biases) + list(self._factors)
+            self.__dict__["_table_cache"] = (tuple((p._version, p.data_ptr()) for p in params), table.detach())
+            return table
         # inference: the [C, 58] table only changes with the parameters -- rebuilt per parameter version, not per forward
         params = list(self._matrices) + list(self._biases) + list(self._factors)
         key = tuple((p._version, p.data_ptr()) for p in params)

@@ -511,6 +511,12 @@ int masic_entropy_bottleneck_bwd(const float* z_hat, const float* params, const 
 int masic_eb_table_split(const float* g_table, float* flat, int C, const int* widths, int nparts, void* stream);
 int masic_entropy_bottleneck_auxloss_bwd(const float* params, const float* quantiles, float* g_quantiles,
                                          int C, double tail_mass, float gout, void* stream);
+/* The auxiliary step's loss and gradient (newtrain_codec_real.py:143-145: sum of EntropyBottleneck.loss() over the model's bottlenecks,
+ * backward) for n <= 4 bottlenecks in two launches.  params[e]: [C[e]][58] tables, quantiles[e] / g_quantiles[e]: [C[e]][3];
+ * loss[0] = total, loss[1 + e] = bottleneck e; workspace: >= n * 3 * max C floats. */
+int masic_entropy_bottleneck_aux_step(const float* const* params, const float* const* quantiles, float* const* g_quantiles,
+                                      const int* C, const double* tail_mass, int n, float* loss, float* workspace, int workspace_floats,
+                                      void* stream);
 /* warp backward w.r.t. the source image; g_src [B,C,Hs,Ws] must be ZERO-FILLED by the caller (float atomics) */
 int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,
                                int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream);

@@ -521,6 +521,52 @@ __global__ __launch_bounds__(256) void eb_auxloss_bwd_kernel(const float* __rest
     g_q[i] = eb_backward_tape(M, F, tp, gs, gM, gB, gF);
 }
 
+// The auxiliary step of a training iteration (newtrain_codec_real.py:143-145: aux_loss = sum of EntropyBottleneck.loss(), backward) for
+// up to four bottlenecks in two launches: every (channel, quantile) element evaluates logits(q) with its tape once -- |logits - target|
+// for the loss, sign(logits - target) back through the tape for d/d quantiles -- then one block adds the elements per bottleneck in a
+// fixed order.  Replaces, per bottleneck, a one-block forward kernel, a backward kernel and the torch glue around them (11 launches
+// for HSIC's two bottlenecks).
+struct EbAuxArgs { const float* params[4]; const float* quantiles[4]; float* g_q[4]; int C[4]; float target[4]; int n; };
+
+__global__ __launch_bounds__(256) void eb_aux_fused_kernel(const EbAuxArgs a, float* __restrict__ absd, int pitch) {
+    const int e = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.C[e] * 3) return;
+    const int c = i / 3, q = i - 3 * c;
+    const float* row = a.params[e] + (size_t)c * MASIC_EB_PARAMS_PER_CHANNEL;
+    float M[33], Bv[13], F[12];
+    for (int k = 0; k < 33; ++k) M[k] = softplusf_(row[k]);
+    for (int k = 0; k < 13; ++k) Bv[k] = row[33 + k];
+    for (int k = 0; k < 12; ++k) F[k] = tanhf(row[46 + k]);
+    EbTape tp;
+    const float lg = eb_forward_tape(M, Bv, F, a.quantiles[e][i], tp);
+    const float t = q == 0 ? -a.target[e] : (q == 1 ? 0.0f : a.target[e]);
+    const float d = lg - t;
+    const float gs = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    float gM[33] = {0}, gB[13] = {0}, gF[12] = {0};
+    a.g_q[e][i] = eb_backward_tape(M, F, tp, gs, gM, gB, gF);
+    absd[(size_t)e * pitch + i] = fabsf(d);
+}
+
+// loss[0] = sum over bottlenecks (in index order) of the per-bottleneck sums loss[1 + e]
+__global__ __launch_bounds__(256) void eb_aux_sum_kernel(const EbAuxArgs a, const float* __restrict__ absd, int pitch, float* __restrict__ loss) {
+    __shared__ float red[256];
+    float total = 0.0f;
+    for (int e = 0; e < a.n; ++e) {
+        float acc = 0.0f;
+        for (int i = threadIdx.x; i < a.C[e] * 3; i += 256) acc += absd[(size_t)e * pitch + i];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { loss[1 + e] = red[0]; total = e == 0 ? red[0] : total + red[0]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = total;
+}
+
 // ---------------------------------------------------------------------------- warp backward (w.r.t. the source)
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ g_dst, const float* __restrict__ minv,
                                                        float* __restrict__ g_src, int C, int Hs, int Ws, int Hd, int Wd, int align_corners) {
@@ -706,6 +752,30 @@ extern "C" int masic_entropy_bottleneck_auxloss_bwd(const float* params, const f
     hipLaunchKernelGGL(eb_auxloss_bwd_kernel, dim3(ceil_div(C * 3, 256)), dim3(256), 0, (hipStream_t)stream, params, quantiles,
                        g_quantiles, C, target, gout);
     return masic_launch_status("entropy_bottleneck_auxloss_bwd");
+}
+
+// n <= 4 bottlenecks: params[e] [C[e]][58] (masic_eb_param_table), quantiles[e] / g_quantiles[e] [C[e]][3]; loss: 1 + n floats -- the
+// total, then each bottleneck's sum; workspace: 4 * 3 * max C floats
+extern "C" int masic_entropy_bottleneck_aux_step(const float* const* params, const float* const* quantiles, float* const* g_quantiles,
+                                                 const int* C, const double* tail_mass, int n, float* loss, float* workspace, int workspace_floats,
+                                                 void* stream) {
+    MASIC_REQUIRE(params && quantiles && g_quantiles && C && tail_mass && loss && workspace, MASIC_ERR_ARG, "entropy_bottleneck_aux_step: null pointer");
+    MASIC_REQUIRE(n >= 1 && n <= 4, MASIC_ERR_UNSUPPORTED, "entropy_bottleneck_aux_step: %d bottlenecks (1..4)", n);
+    EbAuxArgs a{};
+    a.n = n;
+    int cmax = 0;
+    for (int e = 0; e < n; ++e) {
+        MASIC_REQUIRE(params[e] && quantiles[e] && g_quantiles[e] && C[e] > 0, MASIC_ERR_ARG, "entropy_bottleneck_aux_step: bottleneck %d", e);
+        a.params[e] = params[e]; a.quantiles[e] = quantiles[e]; a.g_q[e] = g_quantiles[e]; a.C[e] = C[e];
+        a.target[e] = (float)__builtin_log(2.0 / tail_mass[e] - 1.0);
+        cmax = C[e] > cmax ? C[e] : cmax;
+    }
+    const int pitch = 3 * cmax;
+    MASIC_REQUIRE(workspace_floats >= n * pitch, MASIC_ERR_ARG, "entropy_bottleneck_aux_step: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(eb_aux_fused_kernel, dim3(ceil_div(pitch, 256), n), dim3(256), 0, st, a, workspace, pitch);
+    hipLaunchKernelGGL(eb_aux_sum_kernel, dim3(1), dim3(256), 0, st, a, (const float*)workspace, pitch, loss);
+    return masic_launch_status("entropy_bottleneck_aux_step");
 }
 
 extern "C" int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,

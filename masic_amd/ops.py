@@ -711,6 +711,29 @@ def entropy_bottleneck_bwd(z_hat, table, g_lik, g_zhat, lik_bound=LIK_BOUND):
     return g_z, g_t
 
 
+def entropy_bottleneck_aux_step(tables, quantiles, tail_masses):
+    """Loss and d loss / d quantiles of sum_e EntropyBottleneck_e.loss() in two launches (masic_entropy_bottleneck_aux_step):
+    returns (total loss, float32 0-dim; [gradient like quantiles[e]])."""
+    n = len(tables)
+    if not 1 <= n <= 4 or len(quantiles) != n or len(tail_masses) != n:
+        raise RuntimeError("masic_amd.entropy_bottleneck_aux_step: 1..4 bottlenecks")
+    qs = [_dev(q.detach().contiguous(), "quantiles") for q in quantiles]
+    for t, q in zip(tables, qs):
+        _dev(t, "EB table")
+        if q.numel() != 3 * t.shape[0]:
+            raise RuntimeError("masic_amd.entropy_bottleneck_aux_step: quantiles do not match the table")
+    dev = tables[0].device
+    gq = [torch.empty_like(q) for q in qs]
+    cmax = max(t.shape[0] for t in tables)
+    ws = torch.empty(n * 3 * cmax, dtype=torch.float32, device=dev)
+    loss = torch.empty(1 + n, dtype=torch.float32, device=dev)
+    vp = ctypes.c_void_p * n
+    check(lib.masic_entropy_bottleneck_aux_step(vp(*[t.data_ptr() for t in tables]), vp(*[q.data_ptr() for q in qs]), vp(*[g.data_ptr() for g in gq]),
+                                                (ctypes.c_int * n)(*[t.shape[0] for t in tables]), (ctypes.c_double * n)(*[float(m) for m in tail_masses]),
+                                                n, _p(loss), _p(ws), ws.numel(), _stream()), "entropy_bottleneck_aux_step")
+    return loss[0], gq
+
+
 def entropy_bottleneck_auxloss_bwd(table, quantiles, gout, tail_mass=1e-9):
     _dev(table); _dev(quantiles)
     g_q = torch.empty_like(quantiles)

@@ -2,6 +2,8 @@
 (coremasic/mywork/newtrain_codec_real.py:135-146): zero_grad x2 -> forward -> RD loss -> backward -> Adam step ->
 aux loss -> backward -> aux Adam step.  Optimizers are torch's (plumbing); every tensor op of forward and backward
 is a HIP launch.  With a GradientAllReducer the main-loss gradients are averaged across ranks before the step."""
+import os
+
 import torch
 
 from .loss import distortion, rate_distortion
@@ -26,6 +28,32 @@ def _step(optimizer):
         torch._C._increment_version([p for g in optimizer.param_groups for p in g["params"]])
 
 
+_AUX_FUSED = os.environ.get("MASIC_AUX_FUSED", "1") != "0"      # 0: model.aux_loss().backward() through autograd (A/B timing)
+
+
+def aux_backward(model):
+    """aux_loss = model.aux_loss(); aux_loss.backward() (newtrain_codec_real.py:143-144) -- the sum of EntropyBottleneck.loss() over the
+    model's bottlenecks and its gradient, which reaches the quantiles only (every density parameter is detached, reference
+    entropy_models.py:345-348).  For device models with <= 4 bottlenecks: two launches that write loss and gradient directly
+    (ops.entropy_bottleneck_aux_step; the gradient is accumulated into `quantiles.grad` as autograd would), otherwise autograd."""
+    from compressai.entropy_models import EntropyBottleneck
+    ebs = [m for m in model.modules() if isinstance(m, EntropyBottleneck)]
+    if (_AUX_FUSED and 1 <= len(ebs) <= 4 and torch.is_grad_enabled()
+            and all(m.quantiles.is_cuda and m.quantiles.requires_grad and m.quantiles.dtype == torch.float32 for m in ebs)):
+        from . import ops
+        loss, grads = ops.entropy_bottleneck_aux_step([m._table() for m in ebs], [m.quantiles for m in ebs], [m.tail_mass for m in ebs])
+        for m, g in zip(ebs, grads):
+            g = g.view_as(m.quantiles)
+            if m.quantiles.grad is None:
+                m.quantiles.grad = g
+            else:
+                m.quantiles.grad.add_(g)
+        return loss
+    aux_loss = model.aux_loss()
+    aux_loss.backward()
+    return aux_loss
+
+
 def train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer=None):
     optimizer.zero_grad()
     aux_optimizer.zero_grad()
@@ -37,8 +65,7 @@ def train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer
     if reducer is not None:
         reducer.finish()
     _step(optimizer)
-    aux_loss = model.aux_loss()
-    aux_loss.backward()
+    aux_loss = aux_backward(model)
     _step(aux_optimizer)
     return out_criterion, aux_loss
 

@@ -495,6 +495,33 @@ def test_entropy_bottleneck_backward_and_aux():
     assert all(p.grad is None for n, p in eb.named_parameters() if n != "quantiles")
 
 
+def test_aux_step_two_launches_equal_autograd(monkeypatch):
+    """train.aux_backward: the sum of EntropyBottleneck.loss() over HSIC's two bottlenecks and its gradient (newtrain_codec_real.py:
+    143-144) written by two launches, against model.aux_loss().backward(): the same gradients bit for bit (both run the same tape),
+    the loss to float32 summation noise; a second call accumulates into quantiles.grad as autograd does."""
+    import MASIC
+    from masic_amd import synth, train
+    net = MASIC.HSIC(16, 32, 3)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=5))
+    net = net.to(DEV).train()
+    ebs = (net.entropy_bottleneck1, net.entropy_bottleneck2)
+    monkeypatch.setattr(train, "_AUX_FUSED", False)
+    want = train.aux_backward(net)
+    wg = [m.quantiles.grad.clone() for m in ebs]
+    for m in ebs:
+        m.quantiles.grad = None
+    monkeypatch.setattr(train, "_AUX_FUSED", True)
+    got = train.aux_backward(net)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    for m, g in zip(ebs, wg):
+        assert m.quantiles.grad.shape == m.quantiles.shape
+        assert torch.equal(m.quantiles.grad, g)
+    train.aux_backward(net)
+    for m, g in zip(ebs, wg):
+        assert torch.equal(m.quantiles.grad, g + g)
+
+
 def test_gmm_backward():
     from masic_amd import autograd as A
     B, M, K, H, W = 2, 24, 5, 6, 10
