@@ -711,9 +711,12 @@ class GmmHeadsFn(Function):
             g = ops.zeros(ys[k].shape, torch.float32, ys[k].device) if g is None else _c(g)
             if acts[2] != ops.ACT_NONE:
                 g = ops.elementwise(ops.EW_ACT_BWD, g, ys[k], s0=acts[2])
+            g16.append(ops.nchw_to_f16k(g))
+            if mods[k][2].bias is not None and _WGRAD1_BIAS:     # (the bias gradient: sums of dy as the weight gradient sees it, bf16-rounded)
+                grads[6 * k + 4], grads[6 * k + 5] = wgrad(mods[k][2], t1[k], g16[k], with_bias=True)
+                continue
             if mods[k][2].bias is not None:
                 grads[6 * k + 5] = ops.channel_sum(g)
-            g16.append(ops.nchw_to_f16k(g))
             grads[6 * k + 4] = wgrad(mods[k][2], t1[k], g16[k])
         for level, saved in ((1, t1), (0, t0)):
             gin = dgrad(level + 1, g16, "f16k")
