@@ -143,6 +143,14 @@ int masic_conv_f16k_supported(const masic_conv_desc_t* d);
 int masic_conv_f16k_kernel_name(const masic_conv_desc_t* d, int gdn, char* buf, size_t n);   /* symbol as rocprofv3 prints it */
 size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d);
 int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream);
+/* Batched packing (a training step re-packs every weight it touches, each for its forward and for its input gradient):
+ * masic_conv_f16k_pack_job writes, into host memory (masic_conv_f16k_pack_job_bytes() bytes), the job that one
+ * masic_conv_f16k_pack_weight(w, w_packed, d) call stands for and returns its grid width (>= 1; negative: error code);
+ * masic_conv_f16k_pack_jobs_run launches a table of such jobs, held in DEVICE memory, as ONE kernel (max_nb = the largest grid
+ * width in the table).  Pointers inside the jobs must stay valid; the weights are read when the kernel runs. */
+size_t masic_conv_f16k_pack_job_bytes(void);
+int masic_conv_f16k_pack_job(const float* w, void* w_packed, const masic_conv_desc_t* d, void* job_host);
+int masic_conv_f16k_pack_jobs_run(const void* jobs_dev, int njobs, int max_nb, void* stream);
 int masic_conv_f16k_fwd(const void* x_f16k, const void* w_packed, const float* bias, const float* gate,
                         float* y_nchw, void* y_f16k, const masic_conv_desc_t* d, void* stream);
 /* The same with the (inverse) GDN that follows the 128-channel convolutions of the analysis / synthesis transforms

@@ -57,6 +57,9 @@ SIGNATURES = {
     "masic_conv_f16k_kernel_name": (c_int, [_P, c_int, ctypes.c_char_p, c_size_t]),
     "masic_conv_f16k_packed_bytes": (c_size_t, [_P]),
     "masic_conv_f16k_pack_weight": (c_int, [_P, _P, _P, _P]),
+    "masic_conv_f16k_pack_job_bytes": (c_size_t, []),
+    "masic_conv_f16k_pack_job": (c_int, [_P, _P, ctypes.POINTER(ConvDesc), _P]),
+    "masic_conv_f16k_pack_jobs_run": (c_int, [_P, c_int, c_int, _P]),
     "masic_conv_f16k_fwd": (c_int, [_P] * 8),
     "masic_conv_f16k_d2s_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "masic_pmf_to_quantized_cdf": (c_int, [_P, c_int, c_int, _P]),

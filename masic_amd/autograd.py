@@ -173,7 +173,8 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
             return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
         if dx_f16k:
-            return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16), None, d16, want_nchw=not (gx_f16k and Cin % 16 == 0))
+            return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16, persistent=weight.is_leaf and weight.is_contiguous() and not mod.masked_conv), None, d16,
+                                   want_nchw=not (gx_f16k and Cin % 16 == 0))
         g32 = ops.f16k_to_nchw_dev(g16, B, Cout, Ho, Wo) if g is None else (g if g.dtype == torch.float32 else g.float())
         return ops.conv2d(g32, ops.pack_conv_weight(weight.detach(), d), None, d)
 
@@ -491,7 +492,7 @@ class EnhancementBlockFn(Function):
         def dgrad(g16, w, **kw):            # the transposed convolution on the same weight, epilogue operands as conv2d_f16k_res
             if resident:
                 return ops.conv3x3_resident(g16, ops.pack_conv3x3_resident_weight(w.detach(), transposed=True), None, B, C, C, H, W, res_ctot=C, **kw)
-            return ops.conv2d_f16k_res(g16, ops.pack_conv_f16k_weight(w.detach(), d16), None, d16, res_ctot=C, **kw)
+            return ops.conv2d_f16k_res(g16, ops.pack_conv_f16k_weight(w.detach(), d16, persistent=w.is_leaf and w.is_contiguous()), None, d16, res_ctot=C, **kw)
         go = g_out
         for i in (2, 1, 0):
             rb, x_in, t, u = blocks[i]

@@ -233,12 +233,12 @@ struct PackStreamArgs {
     unsigned phase_offs[4];   // bytes
 };
 
-__global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* __restrict__ wp) {
-    const ConvGeom g = a.gs[blockIdx.y];
-    const unsigned phase_off = a.phase_offs[blockIdx.y];
+__device__ __forceinline__ void pack_f16k_stream_body(const PackStreamArgs& a, unsigned short* __restrict__ wp, int phase, int bx, int nbx) {
+    const ConvGeom g = a.gs[phase];
+    const unsigned phase_off = a.phase_offs[phase];
     const int spc = (g.ntaps + a.T - 1) / a.T;
     const size_t total = (size_t)a.ncb * a.nchunks * spc * a.T * a.KS * 2048;        // bf16 elements
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bx * blockDim.x + threadIdx.x; i < total; i += (size_t)nbx * blockDim.x) {
         size_t r = i;
         const int e = (int)(r & 7); r >>= 3;
         const int co = (int)(r & 127); r >>= 7;
@@ -261,6 +261,21 @@ __global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* 
         const __bf16 bv = (__bf16)v;
         wp[(phase_off >> 1) + i] = __builtin_bit_cast(unsigned short, bv);
     }
+}
+
+__global__ void pack_f16k_stream_kernel(const PackStreamArgs a, unsigned short* __restrict__ wp) {
+    pack_f16k_stream_body(a, wp, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// Many layers' streams in one launch (a training step re-packs every weight it touches -- each for its forward and for its input
+// gradient -- ~50 launches of ~5 us whose work is a few microseconds): blockIdx.y = job, blockIdx.z = phase; a job is what one
+// masic_conv_f16k_pack_weight call would launch.  The job table lives in device memory (built once per set of layers).
+struct PackStreamJob { PackStreamArgs a; unsigned short* wp; int nb, np; };
+
+__global__ void pack_f16k_stream_multi_kernel(const PackStreamJob* __restrict__ jobs) {
+    const PackStreamJob& j = jobs[blockIdx.y];
+    if ((int)blockIdx.z >= j.np || (int)blockIdx.x >= j.nb) return;
+    pack_f16k_stream_body(j.a, j.wp, blockIdx.z, blockIdx.x, j.nb);
 }
 
 // fp8 operands: the same stream with 32-channel blocks -- slab (tap, block) = LDS image [k-half hh][co 128][16 ci] of
@@ -1141,7 +1156,8 @@ extern "C" size_t masic_conv_f16k_packed_bytes(const masic_conv_desc_t* d) {
     return c.ok ? c.packed_bytes : 0;
 }
 
-extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
+namespace {
+int pack_stream_job(const float* w, void* w_packed, const masic_conv_desc_t* d, PackStreamJob& j) {
     int rc = check_desc(d);
     if (rc != MASIC_OK) return rc;
     MASIC_REQUIRE(w && w_packed, MASIC_ERR_ARG, "conv_f16k_pack_weight: null pointer");
@@ -1149,18 +1165,51 @@ extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const
     const int np = build_geoms(*d, g);
     const F16kCfg c = choose_f16k(*d, g, np);
     MASIC_REQUIRE(c.ok, MASIC_ERR_UNSUPPORTED, "conv_f16k: layer shape has no F16K configuration");
-    PackStreamArgs a{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, {}, {}};
+    j.a = PackStreamArgs{w, d->Cin, d->Cout, d->KH, d->KW, d->transposed, c.KS, c.T, c.Cin16 / c.KS, c.ncb, {}, {}};
     size_t tot = 0;
     for (int p = 0; p < np; ++p) {
-        a.gs[p] = g[p];
-        a.phase_offs[p] = c.phase_off[p];
+        j.a.gs[p] = g[p];
+        j.a.phase_offs[p] = c.phase_off[p];
         const size_t t = (size_t)c.stream_bytes[p] / 2 * c.ncb;
         tot = tot > t ? tot : t;
     }
     int nb = (int)((tot + 255) / 256);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(pack_f16k_stream_kernel, dim3(nb, np), dim3(256), 0, (hipStream_t)stream, a, (unsigned short*)w_packed);
+    j.wp = (unsigned short*)w_packed;
+    j.nb = nb;
+    j.np = np;
+    return MASIC_OK;
+}
+}  // namespace
+
+extern "C" int masic_conv_f16k_pack_weight(const float* w, void* w_packed, const masic_conv_desc_t* d, void* stream) {
+    PackStreamJob j{};
+    const int rc = pack_stream_job(w, w_packed, d, j);
+    if (rc != MASIC_OK) return rc;
+    hipLaunchKernelGGL(pack_f16k_stream_kernel, dim3(j.nb, j.np), dim3(256), 0, (hipStream_t)stream, j.a, j.wp);
     return masic_launch_status("conv_f16k_pack_weight");
+}
+
+// Batched form: masic_conv_f16k_pack_job writes the job one masic_conv_f16k_pack_weight(w, w_packed, d) call stands for into host
+// memory (masic_conv_f16k_pack_job_bytes() bytes per job; returns the job's grid width >= 1, or a negative error code);
+// masic_conv_f16k_pack_jobs_run launches a table of such jobs -- in DEVICE memory, njobs <= 65535 -- as one kernel (max_nb: the
+// largest grid width among them).  The pointers inside the jobs must stay valid; weights are read at launch time.
+extern "C" size_t masic_conv_f16k_pack_job_bytes(void) { return sizeof(PackStreamJob); }
+
+extern "C" int masic_conv_f16k_pack_job(const float* w, void* w_packed, const masic_conv_desc_t* d, void* job_host) {
+    MASIC_REQUIRE(job_host != nullptr, MASIC_ERR_ARG, "conv_f16k_pack_job: null pointer");
+    PackStreamJob j{};
+    const int rc = pack_stream_job(w, w_packed, d, j);
+    if (rc != MASIC_OK) return rc < 0 ? rc : -rc;
+    if (j.nb > 96) j.nb = 96;            // the batched grid is (widest job, jobs, 4 phases): the loops are grid-stride, empty blocks are not free
+    *(PackStreamJob*)job_host = j;
+    return j.nb;
+}
+
+extern "C" int masic_conv_f16k_pack_jobs_run(const void* jobs_dev, int njobs, int max_nb, void* stream) {
+    MASIC_REQUIRE(jobs_dev && njobs >= 1 && njobs <= 65535 && max_nb >= 1, MASIC_ERR_ARG, "conv_f16k_pack_jobs_run: bad arguments");
+    hipLaunchKernelGGL(pack_f16k_stream_multi_kernel, dim3(max_nb, njobs, 4), dim3(256), 0, (hipStream_t)stream, (const PackStreamJob*)jobs_dev);
+    return masic_launch_status("conv_f16k_pack_jobs_run");
 }
 
 namespace {

@@ -150,7 +150,7 @@ class _PackedWeightMixin:
     def packed_f16k_weight(self, desc):
         w = self.weight
         return _cached(self, "_packed_f16k_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi),
-                       lambda: ops.pack_conv_f16k_weight(w.detach().contiguous(), desc))
+                       lambda: ops.pack_conv_f16k_weight(w.detach().contiguous(), desc, persistent=w.is_contiguous() and not self.masked_conv))     # (a masked layer zeroes taps in place right before its pack)
 
     # ---- fp8 operands (masic_amd/csrc/conv_f16k.hip: conv_f16k<..., F8>; activations F8K [B][C/32][H*W][32] fp8)
     def _desc_f8k(self, B, Hi, Wi, out_ctot=None, out_coff=0, act=ops.ACT_NONE, gate_ctot=0, gate_c=0):

@@ -796,14 +796,99 @@ def conv_f16k_supported(desc):
     return bool(lib.masic_conv_f16k_supported(ctypes.byref(desc)))
 
 
-def pack_conv_f16k_weight(weight, desc):
+def pack_conv_f16k_weight(weight, desc, persistent=False):
+    """The weight as conv_f16k's slab stream.  persistent: `weight` is (a detached view of) a long-lived parameter -- the pack is
+    registered with StreamPacks below and refreshed together with all the other registered packs in ONE launch when the parameters
+    change (a training step), instead of one launch per layer and orientation."""
     _dev(weight, "weight")
+    if persistent and _PACK_MULTI:
+        return _stream_packs(weight.device).get(weight, desc)
     nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
     if nbytes == 0:
         check(-1, "conv_f16k_packed_bytes")
     packed = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_conv_f16k_pack_weight(_p(weight), _p(packed), ctypes.byref(desc), _stream()), "conv_f16k_pack_weight")
     return packed
+
+
+_PACK_MULTI = _os.environ.get("MASIC_PACK_MULTI", "1") != "0"      # 0: one pack launch per weight and orientation (A/B timing)
+_DESC_KEY = ("B", "Cin", "Hi", "Wi", "in_ctot", "Cout", "KH", "KW", "stride", "pad", "transposed", "masked", "prec")
+
+
+class StreamPacks:
+    """Registry of the conv_f16k weight packs of long-lived parameters on one device.  An entry = (parameter storage, layer geometry)
+    -> a persistent packed buffer + the parameter version it was packed from.  `get` returns the buffer; when it finds the entry stale
+    and most other entries stale too (the first pack request after an optimizer step), every registered pack is refreshed by ONE launch
+    (masic_conv_f16k_pack_jobs_run on a job table kept in device memory); a lone stale entry (a masked layer re-zeroing its taps, a
+    layer seen for the first time, any request under no_grad) is packed by itself, on the requesting stream, as without the registry."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}          # key -> [weight, desc, out, version, job bytes, nb]
+        self.table = None          # device uint8: the jobs of all entries, in dict order
+        self.max_nb = 1
+        self.job_bytes = lib.masic_conv_f16k_pack_job_bytes()
+
+    def _register(self, key, weight, desc):
+        nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+        if nbytes == 0:
+            check(-1, "conv_f16k_packed_bytes")
+        out = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
+        d = ConvDesc()
+        ctypes.pointer(d)[0] = desc
+        job = ctypes.create_string_buffer(self.job_bytes)
+        nb = lib.masic_conv_f16k_pack_job(_p(weight), _p(out), ctypes.byref(d), job)
+        if nb < 1:
+            check(nb if nb < 0 else -1, "conv_f16k_pack_job")
+        e = self.entries[key] = [weight, d, out, None, job.raw, nb]
+        self.table = None
+        return e
+
+    def get(self, weight, desc):
+        key = (weight.data_ptr(),) + tuple(getattr(desc, f) for f in _DESC_KEY)
+        e = self.entries.get(key)
+        if e is None:
+            e = self._register(key, weight, desc)
+        if e[3] == weight._version:
+            return e[2]
+        stale = sum(1 for x in self.entries.values() if x[3] != x[0]._version)
+        # (batched only inside `with batched_packs():` -- the training steps of masic_amd/train.py, one stream: a refresh rewrites every
+        # registered buffer, and the multi-stream eval forward must not have buffers rewritten or first filled by another stream than the
+        # one about to read them)
+        if stale >= 4 and 2 * stale >= len(self.entries) and _BATCHED_PACKS[0] > 0:
+            if self.table is None:
+                raw = b"".join(x[4] for x in self.entries.values())
+                self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+                self.max_nb = max(x[5] for x in self.entries.values())
+            check(lib.masic_conv_f16k_pack_jobs_run(_p(self.table), len(self.entries), self.max_nb, _stream()), "conv_f16k_pack_jobs_run")
+            for x in self.entries.values():
+                x[3] = x[0]._version
+        else:
+            check(lib.masic_conv_f16k_pack_weight(_p(e[0]), _p(e[2]), ctypes.byref(e[1]), _stream()), "conv_f16k_pack_weight")
+            e[3] = weight._version
+        return e[2]
+
+
+_STREAM_PACKS = {}
+_BATCHED_PACKS = [0]
+
+
+class batched_packs:
+    """Context of a single-stream training step: stale weight packs are refreshed together (StreamPacks)."""
+
+    def __enter__(self):
+        _BATCHED_PACKS[0] += 1
+
+    def __exit__(self, *exc):
+        _BATCHED_PACKS[0] -= 1
+        return False
+
+
+def _stream_packs(device):
+    sp = _STREAM_PACKS.get(device)
+    if sp is None:
+        sp = _STREAM_PACKS[device] = StreamPacks(device)
+    return sp
 
 
 def pack_gdn_f16k(beta, gamma, beta_min=1e-6):

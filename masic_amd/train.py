@@ -55,6 +55,12 @@ def aux_backward(model):
 
 
 def train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer=None):
+    from . import ops
+    with ops.batched_packs():       # (the step runs on one stream: the weight packs of all layers are refreshed by one launch)
+        return _train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer)
+
+
+def _train_step(model, optimizer, aux_optimizer, d1, d2, h_matrix, lmbda, reducer=None):
     optimizer.zero_grad()
     aux_optimizer.zero_grad()
     if reducer is not None:
@@ -94,9 +100,11 @@ def cqe_train_step(model, model2, optimizer, d1, d2, h_matrix, lmbda, reducer=No
     else:
         with torch.no_grad():
             out_net = model(d1, d2, h_matrix)
-    out_net2 = model2(out_net["x1_hat"], out_net["x2_hat"], h_matrix)
-    out_criterion = distortion(out_net2, d1, d2, lmbda)
-    out_criterion["loss"].backward()
+    from . import ops
+    with ops.batched_packs():       # (Independent_EN's forward and backward run on one stream; HSIC's multi-stream forward above does not)
+        out_net2 = model2(out_net["x1_hat"], out_net["x2_hat"], h_matrix)
+        out_criterion = distortion(out_net2, d1, d2, lmbda)
+        out_criterion["loss"].backward()
     if reducer is not None:
         reducer.finish()
     _step(optimizer)

@@ -495,6 +495,42 @@ def test_entropy_bottleneck_backward_and_aux():
     assert all(p.grad is None for n, p in eb.named_parameters() if n != "quantiles")
 
 
+def test_weight_packs_refreshed_by_one_launch_equal_single_packs():
+    """ops.StreamPacks: inside a training step (ops.batched_packs) the conv_f16k weight packs of all registered layers -- forward and
+    input-gradient orientation -- are refreshed by ONE launch when the parameters changed; every refreshed buffer must hold exactly
+    what masic_conv_f16k_pack_weight writes for that layer, stale entries must be repacked after an optimizer step, and masked layers
+    (which zero taps in place right before packing, without a version bump) must not be registered."""
+    import ctypes
+    import MASIC
+    from masic_amd import nn as mnn, ops, synth
+    from masic_amd.ops import lib
+    from masic_amd.train import make_optimizers, train_step
+    net = MASIC.HSIC(128, 32, 3)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=12))
+    net = net.to(DEV).train()
+    x1, x2, hm = (t.to(DEV) for t in synth.synth_inputs(1, 64, 64, seed=12))
+    mnn.set_precision("bf16")
+    try:
+        opt, aopt = make_optimizers(net)
+        for _ in range(2):
+            train_step(net, opt, aopt, x1, x2, hm, 0.01)
+        sp = ops._stream_packs(x1.device)
+        mine = {k: e for k, e in sp.entries.items() if any(e[0].data_ptr() == p.data_ptr() for p in net.parameters())}
+        assert len(mine) >= 12                                   # analysis / synthesis / hyper layers, both orientations
+        assert all(e[1].masked == 0 for e in mine.values())
+        assert all(e[3] != e[0]._version for e in mine.values())  # the optimizer stepped: everything is stale
+        with ops.batched_packs():
+            net(x1, x2, hm)                                      # the first request refreshes every entry
+        for key, e in mine.items():
+            assert e[3] == e[0]._version, key
+            ref = torch.empty_like(e[2])
+            ops.check(lib.masic_conv_f16k_pack_weight(e[0].data_ptr(), ref.data_ptr(), ctypes.byref(e[1]), None), "pack")
+            torch.cuda.synchronize()
+            assert torch.equal(ref, e[2]), key
+    finally:
+        mnn.set_precision("f32")
+
+
 def test_aux_step_two_launches_equal_autograd(monkeypatch):
     """train.aux_backward: the sum of EntropyBottleneck.loss() over HSIC's two bottlenecks and its gradient (newtrain_codec_real.py:
     143-144) written by two launches, against model.aux_loss().backward(): the same gradients bit for bit (both run the same tape),
