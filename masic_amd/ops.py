@@ -824,7 +824,8 @@ class StreamPacks:
 
     def __init__(self, device):
         self.device = device
-        self.entries = {}          # key -> [weight, desc, out, version, job bytes, nb]
+        self.entries = {}          # key -> [weight, desc, out, version, job bytes, nb, tick of the last request]
+        self.tick = 0              # counts batched refreshes; entries not requested for four of them (their model is gone) are dropped
         self.table = None          # device uint8: the jobs of all entries, in dict order
         self.max_nb = 1
         self.job_bytes = lib.masic_conv_f16k_pack_job_bytes()
@@ -840,7 +841,10 @@ class StreamPacks:
         nb = lib.masic_conv_f16k_pack_job(_p(weight), _p(out), ctypes.byref(d), job)
         if nb < 1:
             check(nb if nb < 0 else -1, "conv_f16k_pack_job")
-        e = self.entries[key] = [weight, d, out, None, job.raw, nb]
+        if len(self.entries) >= 1024:      # many models and no training step in between (a test session): forget the oldest half
+            for k in sorted(self.entries, key=lambda k: self.entries[k][6])[:512]:
+                del self.entries[k]
+        e = self.entries[key] = [weight, d, out, None, job.raw, nb, self.tick]
         self.table = None
         return e
 
@@ -849,6 +853,7 @@ class StreamPacks:
         e = self.entries.get(key)
         if e is None:
             e = self._register(key, weight, desc)
+        e[6] = self.tick
         if e[3] == weight._version:
             return e[2]
         stale = sum(1 for x in self.entries.values() if x[3] != x[0]._version)
@@ -856,6 +861,12 @@ class StreamPacks:
         # registered buffer, and the multi-stream eval forward must not have buffers rewritten or first filled by another stream than the
         # one about to read them)
         if stale >= 4 and 2 * stale >= len(self.entries) and _BATCHED_PACKS[0] > 0:
+            self.tick += 1
+            dead = [k for k, x in self.entries.items() if x[6] < self.tick - 4]
+            for k in dead:                 # (the registry holds the only reference that keeps such a weight and its pack alive)
+                del self.entries[k]
+            if dead:
+                self.table = None
             if self.table is None:
                 raw = b"".join(x[4] for x in self.entries.values())
                 self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
