@@ -27,6 +27,8 @@
 //         records through v_permlane32_swap) next to -- or instead of -- the float32 NCHW tensor the weight gradient reads,
 //   and the per-channel sums of dx (the bias gradient of the convolution in front of the GDN) ride along: per-lane float32
 //   sums over the workgroup's tiles, reduced across lanes and waves once at the end, one more row of the partial slot.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -74,6 +76,7 @@ struct GdnBwdArgs {
     float* part;                 // [GB_NBLK][GB_SLOT]
     long long npix;              // B * HW
     int HW, ntiles, inverse, want_sum;
+    int dbg;                     // timing-only ablations (MASIC_GDNB_DBG): 1 no stores, 2 no third contraction, 4 no loads, 8 no first two contractions
 };
 
 __device__ __forceinline__ unsigned gb_pack2bf(float lo, float hi) {
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
         const size_t base16 = ((size_t)b * 8 * hw + pix) * 16 + 4 * h;       // F16K: record 0 of the pixel, + 4h elements
         const size_t rs16 = (size_t)hw * 16;
         f32x16 xv[4], gv[4];
-        if constexpr (X16) gb_load_f16k(xv, a.x16 + base16, rs16, ok);
-        if constexpr (G16) gb_load_f16k(gv, a.g16 + base16, rs16, ok);
+        if constexpr (X16) gb_load_f16k(xv, a.x16 + base16, rs16, ok && !(a.dbg & 4));
+        if constexpr (G16) gb_load_f16k(gv, a.g16 + base16, rs16, ok && !(a.dbg & 4));
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi0 + (m * 8 + s) * 1024));
-                nv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, nv[m], 0, 0, 0);
+                if (!(a.dbg & 8)) nv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, nv[m], 0, 0, 0);
             }
         }
         // ---- s (kept in nv) and t (kept in gv)
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi1 + (m * 8 + s) * 1024));
-                uv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[m], 0, 0, 0);
+                if (!(a.dbg & 8)) uv[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[m], 0, 0, 0);
             }
         }
         // ---- dx = s + 2 x u (kept in uv); rows past the end contribute zeros (x = g = 0 there)
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
                 uv[m][e] = fmaf(2.0f * xv[m][e], uv[m][e], nv[m][e]);
                 dsum[m][e] += uv[m][e];
             }
-        if (ok && a.gx != nullptr) {
+        if (ok && a.gx != nullptr && !(a.dbg & 1)) {
             float* op = a.gx + base;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) op[(unsigned)(32 * m + (e & 3) + 8 * (e >> 2)) * hw] = uv[m][e];
         }
-        if (ok && a.gxb != nullptr) {
+        if (ok && a.gxb != nullptr && !(a.dbg & 1)) {
             unsigned short* ob = a.gxb + base;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -247,13 +250,14 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     uint4 st;
                     st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
-                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * m + r) * rs16) = st;
+                    if (ok && !(a.dbg & 1)) *reinterpret_cast<uint4*>(rec + (size_t)(2 * m + r) * rs16) = st;
                 }
         }
         __syncthreads();                                           // both tiles complete
         // ---- d gamma^[32w + .][.] += t x^2^T over the 128 pixels, d beta^ with B = ones
         const unsigned char* ta = tl + (32 * w + j) * GB_TP + 16 * h;
         const unsigned char* xb = xl + j * GB_TP + 16 * h;
+        if (!(a.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const gbf16x8 af = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(ta + 32 * ks));
@@ -294,6 +298,254 @@ __global__ __launch_bounds__(256, 1) void gdn_bwd_c128(const GdnBwdArgs a) {
     if (j == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) pp[128 * 128 + 32 * w + (e & 3) + 8 * (e >> 2) + 4 * h] = db[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ eight-wave form (F16K operands)
+// The four-wave kernel above holds 400 registers per lane -- one wave per SIMD -- and is bound by that single wave's instruction
+// issue: with no loads, no stores and no MFMAs at all it still takes 60 % of its time (tools/bench_gdn_bwd.py: MASIC_GDNB_DBG=15),
+// a quarter of it 2-byte LDS stores of the [channel][pixel] tiles.  Here a workgroup is 8 waves = 4 pixel groups x 2 channel halves
+// (two waves per SIMD, 64 channels of 32 pixels per wave: half the registers), and ONE pair of LDS tiles serves all three
+// contractions: x^2 and t are written as F16K-like records [16-channel block s][pixel][16] (16 bytes per lane and k-step: the 8
+// values of the lane's MFMA B fragment, in fragment order), so
+//   n = gamma^ x^2 and u = gamma^T t read their B fragments back from the records (one ds_read_b128 per k-step; the other channel
+//     half comes from the partner wave through the same tile), and
+//   d gamma^ += t x^2^T contracts over the pixels of the records with transposed LDS reads (ds_read_b64_tr_b16, as wgrad_f16k.hip):
+//     wave w owns the 32 x 64 block (rows 32 (w & 3), columns 64 (w >> 2)) of d gamma^ -- in RECORD order, mapped back to channels
+//     when the partials are stored (position 8 h + c of a 16-channel block is channel 8 (c >> 2) + 4 h + (c & 3)).
+constexpr int G8_PLANE = 128 * 32 + 128;             // [128 px][16 ch] bf16 records + the bank offset between planes
+constexpr int G8_TILE = 8 * G8_PLANE;                // 33792
+constexpr int G8_LDS = 2 * GB_IMG + 2 * G8_TILE + 512;
+
+typedef unsigned g8v2u __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void g8_tr_read(g8v2u& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ gbf16x8 g8_frag(const g8v2u& lo, const g8v2u& hi) {
+    return __builtin_bit_cast(gbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+__device__ __forceinline__ int g8_pos_chan(int q) { return 8 * ((q & 7) >> 2) + 4 * (q >> 3) + (q & 3); }   // record position -> channel of the block
+__device__ __forceinline__ void g8_barrier() {       // LDS traffic of this wave done, then the workgroup barrier (no vmcnt: stores / loads stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* tl = lds + 2 * GB_IMG;            // t records
+    unsigned char* xl = tl + G8_TILE;                // x^2 records
+    const float* bet = reinterpret_cast<const float*>(xl + G8_TILE);
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = w & 3, hf = w >> 2;
+    const int j = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < (2 * GB_IMG + 512) / 16; i += 512) {
+        const int dst = i < 2 * GB_IMG / 16 ? i * 16 : 2 * GB_IMG + 2 * G8_TILE + (i - 2 * GB_IMG / 16) * 16;
+        *reinterpret_cast<uint4*>(lds + dst) = a.img[i];
+    }
+    __syncthreads();
+
+    f32x16 dg[2], db, dsum[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dg[0][e] = 0.0f; dg[1][e] = 0.0f; db[e] = 0.0f; dsum[0][e] = 0.0f; dsum[1][e] = 0.0f; }
+    gbf16x8 ones;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
+
+    const unsigned char* gi0 = lds + lane * 16;
+    const unsigned char* gi1 = lds + GB_IMG + lane * 16;
+    const unsigned hw = (unsigned)a.HW;
+    const int px = 32 * pg + j;
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned lane_off = (g4 & 1) * G8_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
+    const unsigned la = ldsb + 2 * GB_IMG + (2 * pg) * G8_PLANE + lane_off;                         // t rows: 32-channel block pg
+    const unsigned lb = ldsb + 2 * GB_IMG + G8_TILE + (4 * hf) * G8_PLANE + lane_off;               // x^2 columns: blocks 2 hf, 2 hf + 1
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long long p = (long long)tile * 128 + px;
+        const bool ok = p < a.npix;
+        const long long b = ok ? p / a.HW : 0;
+        const size_t pix = (size_t)(ok ? p - b * a.HW : 0);
+        const size_t base = (size_t)b * 128 * hw + pix + (size_t)(4 * h) * hw;
+        const size_t rs16 = (size_t)hw * 16;
+        const unsigned short* xr = a.x16 + ((size_t)b * 8 * hw + pix) * 16 + 4 * h;
+        const unsigned short* gr = a.g16 + ((size_t)b * 8 * hw + pix) * 16 + 4 * h;
+        f32x16 xv[2], gv[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t ro = (size_t)(2 * (2 * hf + ml) + (q >> 1)) * rs16 + 8 * (q & 1);
+                uint2 rx = make_uint2(0u, 0u), rg = make_uint2(0u, 0u);
+                if (ok) { rx = *reinterpret_cast<const uint2*>(xr + ro); rg = *reinterpret_cast<const uint2*>(gr + ro); }
+                xv[ml][4 * q + 0] = __builtin_bit_cast(float, rx.x << 16);
+                xv[ml][4 * q + 1] = __builtin_bit_cast(float, rx.x & 0xffff0000u);
+                xv[ml][4 * q + 2] = __builtin_bit_cast(float, rx.y << 16);
+                xv[ml][4 * q + 3] = __builtin_bit_cast(float, rx.y & 0xffff0000u);
+                gv[ml][4 * q + 0] = __builtin_bit_cast(float, rg.x << 16);
+                gv[ml][4 * q + 1] = __builtin_bit_cast(float, rg.x & 0xffff0000u);
+                gv[ml][4 * q + 2] = __builtin_bit_cast(float, rg.y << 16);
+                gv[ml][4 * q + 3] = __builtin_bit_cast(float, rg.y & 0xffff0000u);
+            }
+        // ---- x^2 records of this wave's four 16-channel blocks (k-steps 4 hf .. 4 hf + 3)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            gbf16x8 bq;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float xe = xv[sl >> 1][8 * (sl & 1) + c]; bq[c] = (__bf16)__fmul_rn(xe, xe); }
+            *reinterpret_cast<uint4*>(xl + (4 * hf + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
+        }
+        g8_barrier();                                              // (A) all x^2 records of the tile are in place
+        // ---- n = beta^ + gamma^ x^2 for this wave's two channel blocks
+        f32x16 nv[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 be = *reinterpret_cast<const float4*>(bet + (2 * hf + ml) * 32 + 8 * q + 4 * h);
+                nv[ml][4 * q] = be.x; nv[ml][4 * q + 1] = be.y; nv[ml][4 * q + 2] = be.z; nv[ml][4 * q + 3] = be.w;
+            }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const gbf16x8 bq = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(xl + s * G8_PLANE + px * 32 + 16 * h));
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi0 + (((2 * hf + ml) * 8 + s) * 1024)));
+                nv[ml] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, nv[ml], 0, 0, 0);
+            }
+        }
+        // ---- s (kept in nv) and t (kept in gv)
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float r = __builtin_amdgcn_rsqf(nv[ml][e]), gg = gv[ml][e], gxr = gg * xv[ml][e] * r;
+                if (a.inverse) { nv[ml][e] = gg * __builtin_amdgcn_sqrtf(nv[ml][e]); gv[ml][e] = 0.5f * gxr; }
+                else { nv[ml][e] = gg * r; gv[ml][e] = -0.5f * gxr * r * r; }
+            }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            gbf16x8 bq;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bq[c] = (__bf16)gv[sl >> 1][8 * (sl & 1) + c];
+            *reinterpret_cast<uint4*>(tl + (4 * hf + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
+        }
+        g8_barrier();                                              // (B) all t records of the tile are in place
+        // ---- u = gamma^T t
+        f32x16 uv[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) uv[ml][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const gbf16x8 bq = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(tl + s * G8_PLANE + px * 32 + 16 * h));
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi1 + (((2 * hf + ml) * 8 + s) * 1024)));
+                uv[ml] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[ml], 0, 0, 0);
+            }
+        }
+        // ---- dx = s + 2 x u; stores
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                uv[ml][e] = fmaf(2.0f * xv[ml][e], uv[ml][e], nv[ml][e]);
+                dsum[ml][e] += uv[ml][e];
+            }
+        if (ok && a.gx != nullptr) {
+            float* op = a.gx + base;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) op[(unsigned)(32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2)) * hw] = uv[ml][e];
+        }
+        if (ok && a.gxb != nullptr) {
+            unsigned short* ob = a.gxb + base;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const __bf16 bv = (__bf16)uv[ml][e];
+                    ob[(unsigned)(32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2)) * hw] = __builtin_bit_cast(unsigned short, bv);
+                }
+        }
+        if (a.gx16 != nullptr) {
+            unsigned short* rec = a.gx16 + ((size_t)b * 8 * hw + pix) * 16 + 8 * h;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned a0 = gb_pack2bf(uv[ml][8 * r + 0], uv[ml][8 * r + 1]), a1 = gb_pack2bf(uv[ml][8 * r + 2], uv[ml][8 * r + 3]);
+                    const unsigned b0 = gb_pack2bf(uv[ml][8 * r + 4], uv[ml][8 * r + 5]), b1 = gb_pack2bf(uv[ml][8 * r + 6], uv[ml][8 * r + 7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    uint4 st;
+                    st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
+                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * (2 * hf + ml) + r) * rs16) = st;
+                }
+        }
+        // ---- d gamma^ block (rows: t block pg, columns: x^2 blocks 2 hf, 2 hf + 1) over the 128 pixels; d beta^ with B = ones
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            g8v2u af[2], bf[2][2];
+            // (template offsets need constants: the k-step loop is unrolled)
+            switch (ks) {
+#define G8_KS(K)                                                                                     \
+                case K:                                                                              \
+                    g8_tr_read<K * 16 * 32>(af[0], la); g8_tr_read<K * 16 * 32 + 128>(af[1], la);   \
+                    g8_tr_read<K * 16 * 32>(bf[0][0], lb); g8_tr_read<K * 16 * 32 + 128>(bf[0][1], lb);                                 \
+                    g8_tr_read<2 * G8_PLANE + K * 16 * 32>(bf[1][0], lb); g8_tr_read<2 * G8_PLANE + K * 16 * 32 + 128>(bf[1][1], lb);   \
+                    break;
+                G8_KS(0) G8_KS(1) G8_KS(2) G8_KS(3) G8_KS(4) G8_KS(5) G8_KS(6) G8_KS(7)
+#undef G8_KS
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+            const gbf16x8 fa = g8_frag(af[0], af[1]);
+            dg[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, g8_frag(bf[0][0], bf[0][1]), dg[0], 0, 0, 0);
+            dg[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, g8_frag(bf[1][0], bf[1][1]), dg[1], 0, 0, 0);
+            if (hf == 0) db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, db, 0, 0, 0);
+        }
+        g8_barrier();                                              // (C) the records have been read: the next tile may overwrite them
+    }
+
+    float* ppart = a.part + (size_t)blockIdx.x * GB_SLOT;
+    if (a.want_sum) {
+        float* red = reinterpret_cast<float*>(tl);
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = dsum[ml][e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (j == 0) red[pg * 128 + 32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2) + 4 * h] = v;
+            }
+        __syncthreads();
+        if (tid < 128) ppart[128 * 128 + 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+    }
+    // accumulator (row r = 8 (e >> 2) + 4 h + (e & 3), column n = lane & 31) of block (pg, 2 hf + nb): record positions -> channels
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int jc = 32 * (2 * hf + nb) + 16 * (j >> 4) + g8_pos_chan(j & 15);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = 8 * (e >> 2) + 4 * h + (e & 3);
+            const int ic = 32 * pg + 16 * (r >> 4) + g8_pos_chan(r & 15);
+            ppart[ic * 128 + jc] = dg[nb][e];
+        }
+    }
+    if (hf == 0 && j == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = 8 * (e >> 2) + 4 * h + (e & 3);
+            ppart[128 * 128 + 32 * pg + 16 * (r >> 4) + g8_pos_chan(r & 15)] = db[e];
+        }
     }
 }
 
@@ -353,6 +605,7 @@ extern "C" int masic_gdn_bwd_fused_ex2(const float* x, const void* x_f16k, const
     a.x16 = (const unsigned short*)x_f16k; a.g16 = (const unsigned short*)g_f16k; a.gx16 = (unsigned short*)gx_f16k; a.gxb = (unsigned short*)gx_bf16;
     a.HW = H * W; a.npix = (long long)B * H * W; a.inverse = inverse; a.want_sum = g_sum != nullptr;
     a.ntiles = (int)((a.npix + 127) / 128);
+    { const char* e = getenv("MASIC_GDNB_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int nblk = a.ntiles < GB_NBLK ? a.ntiles : GB_NBLK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -365,7 +618,18 @@ extern "C" int masic_gdn_bwd_fused_ex2(const float* x, const void* x_f16k, const
             }
         attr_set = true;
     }
-    if (x_f16k && g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
+    static const bool w8 = [] { const char* e = getenv("MASIC_GDNB_W8"); return e == nullptr || e[0] != '0'; }();
+    if (x_f16k && g_f16k && w8) {
+        static bool attr8 = false;
+        if (!attr8) {
+            if (hipFuncSetAttribute((const void*)gdn_bwd_c128_w8, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) != hipSuccess) {
+                masic_set_error("gdn_bwd_fused: cannot reserve %d bytes of LDS", G8_LDS);
+                return MASIC_ERR_LAUNCH;
+            }
+            attr8 = true;
+        }
+        hipLaunchKernelGGL(gdn_bwd_c128_w8, dim3(nblk), dim3(512), G8_LDS, st, a);
+    } else if (x_f16k && g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
     else if (x_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, false>), dim3(nblk), dim3(256), GB_LDS, st, a);
     else if (g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<false, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
     else hipLaunchKernelGGL((gdn_bwd_c128<false, false>), dim3(nblk), dim3(256), GB_LDS, st, a);
