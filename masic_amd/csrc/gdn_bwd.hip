@@ -331,7 +331,10 @@ __device__ __forceinline__ void g8_barrier() {       // LDS traffic of this wave
     __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
+// NML: 32-channel blocks per wave -- 2: eight waves (4 pixel groups x 2 channel halves), 1: sixteen waves (x 4 channel quarters, four
+// waves per SIMD at <= 128 registers)
+template <int NML>
+__global__ __launch_bounds__(1024 / NML, 1) void gdn_bwd_c128_wn(const GdnBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* tl = lds + 2 * GB_IMG;            // t records
     unsigned char* xl = tl + G8_TILE;                // x^2 records
@@ -339,18 +342,22 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
     const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = w & 3, hf = w >> 2;
+    const int pg = w & 3, cq = w >> 2, m0 = NML * cq;          // this wave: pixels 32 pg .., channel blocks m0 .. m0 + NML - 1
     const int j = lane & 31, h = lane >> 5;
 
-    for (int i = tid; i < (2 * GB_IMG + 512) / 16; i += 512) {
+    for (int i = tid; i < (2 * GB_IMG + 512) / 16; i += 1024 / NML) {
         const int dst = i < 2 * GB_IMG / 16 ? i * 16 : 2 * GB_IMG + 2 * G8_TILE + (i - 2 * GB_IMG / 16) * 16;
         *reinterpret_cast<uint4*>(lds + dst) = a.img[i];
     }
     __syncthreads();
 
-    f32x16 dg[2], db, dsum[2];
+    f32x16 dg[NML], db, dsum[NML];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { dg[0][e] = 0.0f; dg[1][e] = 0.0f; db[e] = 0.0f; dsum[0][e] = 0.0f; dsum[1][e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) {
+        db[e] = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NML; ++n) { dg[n][e] = 0.0f; dsum[n][e] = 0.0f; }
+    }
     gbf16x8 ones;
 #pragma unroll
     for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
     const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     const unsigned lane_off = (g4 & 1) * G8_PLANE + ((8 * (g4 >> 1) + qq) * 32) + 8 * pp;
     const unsigned la = ldsb + 2 * GB_IMG + (2 * pg) * G8_PLANE + lane_off;                         // t rows: 32-channel block pg
-    const unsigned lb = ldsb + 2 * GB_IMG + G8_TILE + (4 * hf) * G8_PLANE + lane_off;               // x^2 columns: blocks 2 hf, 2 hf + 1
+    const unsigned lb = ldsb + 2 * GB_IMG + G8_TILE + (2 * m0) * G8_PLANE + lane_off;               // x^2 columns: blocks m0 .. m0 + NML - 1
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const long long p = (long long)tile * 128 + px;
@@ -373,12 +380,12 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
         const size_t rs16 = (size_t)hw * 16;
         const unsigned short* xr = a.x16 + ((size_t)b * 8 * hw + pix) * 16 + 4 * h;
         const unsigned short* gr = a.g16 + ((size_t)b * 8 * hw + pix) * 16 + 4 * h;
-        f32x16 xv[2], gv[2];
+        f32x16 xv[NML], gv[NML];
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const size_t ro = (size_t)(2 * (2 * hf + ml) + (q >> 1)) * rs16 + 8 * (q & 1);
+                const size_t ro = (size_t)(2 * (m0 + ml) + (q >> 1)) * rs16 + 8 * (q & 1);
                 uint2 rx = make_uint2(0u, 0u), rg = make_uint2(0u, 0u);
                 if (ok) { rx = *reinterpret_cast<const uint2*>(xr + ro); rg = *reinterpret_cast<const uint2*>(gr + ro); }
                 xv[ml][4 * q + 0] = __builtin_bit_cast(float, rx.x << 16);
@@ -390,36 +397,36 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
                 gv[ml][4 * q + 2] = __builtin_bit_cast(float, rg.y << 16);
                 gv[ml][4 * q + 3] = __builtin_bit_cast(float, rg.y & 0xffff0000u);
             }
-        // ---- x^2 records of this wave's four 16-channel blocks (k-steps 4 hf .. 4 hf + 3)
+        // ---- x^2 records of this wave's 16-channel blocks (k-steps 2 m0 .. 2 m0 + 2 NML - 1)
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
+        for (int sl = 0; sl < 2 * NML; ++sl) {
             gbf16x8 bq;
 #pragma unroll
             for (int c = 0; c < 8; ++c) { const float xe = xv[sl >> 1][8 * (sl & 1) + c]; bq[c] = (__bf16)__fmul_rn(xe, xe); }
-            *reinterpret_cast<uint4*>(xl + (4 * hf + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
+            *reinterpret_cast<uint4*>(xl + (2 * m0 + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
         }
         g8_barrier();                                              // (A) all x^2 records of the tile are in place
         // ---- n = beta^ + gamma^ x^2 for this wave's two channel blocks
-        f32x16 nv[2];
+        f32x16 nv[NML];
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 be = *reinterpret_cast<const float4*>(bet + (2 * hf + ml) * 32 + 8 * q + 4 * h);
+                const float4 be = *reinterpret_cast<const float4*>(bet + (m0 + ml) * 32 + 8 * q + 4 * h);
                 nv[ml][4 * q] = be.x; nv[ml][4 * q + 1] = be.y; nv[ml][4 * q + 2] = be.z; nv[ml][4 * q + 3] = be.w;
             }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const gbf16x8 bq = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(xl + s * G8_PLANE + px * 32 + 16 * h));
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi0 + (((2 * hf + ml) * 8 + s) * 1024)));
+            for (int ml = 0; ml < NML; ++ml) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi0 + (((m0 + ml) * 8 + s) * 1024)));
                 nv[ml] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, nv[ml], 0, 0, 0);
             }
         }
         // ---- s (kept in nv) and t (kept in gv)
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float r = __builtin_amdgcn_rsqf(nv[ml][e]), gg = gv[ml][e], gxr = gg * xv[ml][e] * r;
@@ -427,31 +434,31 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
                 else { nv[ml][e] = gg * r; gv[ml][e] = -0.5f * gxr * r * r; }
             }
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
+        for (int sl = 0; sl < 2 * NML; ++sl) {
             gbf16x8 bq;
 #pragma unroll
             for (int c = 0; c < 8; ++c) bq[c] = (__bf16)gv[sl >> 1][8 * (sl & 1) + c];
-            *reinterpret_cast<uint4*>(tl + (4 * hf + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
+            *reinterpret_cast<uint4*>(tl + (2 * m0 + sl) * G8_PLANE + px * 32 + 16 * h) = __builtin_bit_cast(uint4, bq);
         }
         g8_barrier();                                              // (B) all t records of the tile are in place
         // ---- u = gamma^T t
-        f32x16 uv[2];
+        f32x16 uv[NML];
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int e = 0; e < 16; ++e) uv[ml][e] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const gbf16x8 bq = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(tl + s * G8_PLANE + px * 32 + 16 * h));
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi1 + (((2 * hf + ml) * 8 + s) * 1024)));
+            for (int ml = 0; ml < NML; ++ml) {
+                const gbf16x8 ga = __builtin_bit_cast(gbf16x8, *reinterpret_cast<const uint4*>(gi1 + (((m0 + ml) * 8 + s) * 1024)));
                 uv[ml] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bq, uv[ml], 0, 0, 0);
             }
         }
         // ---- dx = s + 2 x u; stores
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 uv[ml][e] = fmaf(2.0f * xv[ml][e], uv[ml][e], nv[ml][e]);
@@ -460,24 +467,24 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
         if (ok && a.gx != nullptr) {
             float* op = a.gx + base;
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml)
+            for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) op[(unsigned)(32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2)) * hw] = uv[ml][e];
+                for (int e = 0; e < 16; ++e) op[(unsigned)(32 * (m0 + ml) + (e & 3) + 8 * (e >> 2)) * hw] = uv[ml][e];
         }
         if (ok && a.gxb != nullptr) {
             unsigned short* ob = a.gxb + base;
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml)
+            for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const __bf16 bv = (__bf16)uv[ml][e];
-                    ob[(unsigned)(32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2)) * hw] = __builtin_bit_cast(unsigned short, bv);
+                    ob[(unsigned)(32 * (m0 + ml) + (e & 3) + 8 * (e >> 2)) * hw] = __builtin_bit_cast(unsigned short, bv);
                 }
         }
         if (a.gx16 != nullptr) {
             unsigned short* rec = a.gx16 + ((size_t)b * 8 * hw + pix) * 16 + 8 * h;
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml)
+            for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const unsigned a0 = gb_pack2bf(uv[ml][8 * r + 0], uv[ml][8 * r + 1]), a1 = gb_pack2bf(uv[ml][8 * r + 2], uv[ml][8 * r + 3]);
@@ -486,30 +493,34 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     uint4 st;
                     st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
-                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * (2 * hf + ml) + r) * rs16) = st;
+                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * (m0 + ml) + r) * rs16) = st;
                 }
         }
-        // ---- d gamma^ block (rows: t block pg, columns: x^2 blocks 2 hf, 2 hf + 1) over the 128 pixels; d beta^ with B = ones
+        // ---- d gamma^ block (rows: t block pg, columns: x^2 blocks m0 .. m0 + NML - 1) over the 128 pixels; d beta^ with B = ones
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            g8v2u af[2], bf[2][2];
+            g8v2u af[2], bf[NML][2];
             // (template offsets need constants: the k-step loop is unrolled)
             switch (ks) {
 #define G8_KS(K)                                                                                     \
                 case K:                                                                              \
                     g8_tr_read<K * 16 * 32>(af[0], la); g8_tr_read<K * 16 * 32 + 128>(af[1], la);   \
                     g8_tr_read<K * 16 * 32>(bf[0][0], lb); g8_tr_read<K * 16 * 32 + 128>(bf[0][1], lb);                                 \
-                    g8_tr_read<2 * G8_PLANE + K * 16 * 32>(bf[1][0], lb); g8_tr_read<2 * G8_PLANE + K * 16 * 32 + 128>(bf[1][1], lb);   \
+                    if constexpr (NML == 2) {                                                                                            \
+                        g8_tr_read<2 * G8_PLANE + K * 16 * 32>(bf[NML - 1][0], lb); g8_tr_read<2 * G8_PLANE + K * 16 * 32 + 128>(bf[NML - 1][1], lb); \
+                    }                                                                                                                    \
                     break;
                 G8_KS(0) G8_KS(1) G8_KS(2) G8_KS(3) G8_KS(4) G8_KS(5) G8_KS(6) G8_KS(7)
 #undef G8_KS
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+            asm volatile("" : "+v"(af[0]), "+v"(af[1]));
+#pragma unroll
+            for (int n = 0; n < NML; ++n) asm volatile("" : "+v"(bf[n][0]), "+v"(bf[n][1]));
             const gbf16x8 fa = g8_frag(af[0], af[1]);
-            dg[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, g8_frag(bf[0][0], bf[0][1]), dg[0], 0, 0, 0);
-            dg[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, g8_frag(bf[1][0], bf[1][1]), dg[1], 0, 0, 0);
-            if (hf == 0) db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, db, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NML; ++n) dg[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, g8_frag(bf[n][0], bf[n][1]), dg[n], 0, 0, 0);
+            if (cq == 0) db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, db, 0, 0, 0);
         }
         g8_barrier();                                              // (C) the records have been read: the next tile may overwrite them
     }
@@ -518,21 +529,21 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
     if (a.want_sum) {
         float* red = reinterpret_cast<float*>(tl);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = dsum[ml][e];
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (j == 0) red[pg * 128 + 32 * (2 * hf + ml) + (e & 3) + 8 * (e >> 2) + 4 * h] = v;
+                if (j == 0) red[pg * 128 + 32 * (m0 + ml) + (e & 3) + 8 * (e >> 2) + 4 * h] = v;
             }
         __syncthreads();
         if (tid < 128) ppart[128 * 128 + 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     }
-    // accumulator (row r = 8 (e >> 2) + 4 h + (e & 3), column n = lane & 31) of block (pg, 2 hf + nb): record positions -> channels
+    // accumulator (row r = 8 (e >> 2) + 4 h + (e & 3), column n = lane & 31) of block (pg, m0 + nb): record positions -> channels
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int jc = 32 * (2 * hf + nb) + 16 * (j >> 4) + g8_pos_chan(j & 15);
+    for (int nb = 0; nb < NML; ++nb) {
+        const int jc = 32 * (m0 + nb) + 16 * (j >> 4) + g8_pos_chan(j & 15);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = 8 * (e >> 2) + 4 * h + (e & 3);
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(512, 1) void gdn_bwd_c128_w8(const GdnBwdArgs a) {
             ppart[ic * 128 + jc] = dg[nb][e];
         }
     }
-    if (hf == 0 && j == 0) {
+    if (cq == 0 && j == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = 8 * (e >> 2) + 4 * h + (e & 3);
@@ -622,13 +633,16 @@ extern "C" int masic_gdn_bwd_fused_ex2(const float* x, const void* x_f16k, const
     if (x_f16k && g_f16k && w8) {
         static bool attr8 = false;
         if (!attr8) {
-            if (hipFuncSetAttribute((const void*)gdn_bwd_c128_w8, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)gdn_bwd_c128_wn<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gdn_bwd_c128_wn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) != hipSuccess) {
                 masic_set_error("gdn_bwd_fused: cannot reserve %d bytes of LDS", G8_LDS);
                 return MASIC_ERR_LAUNCH;
             }
             attr8 = true;
         }
-        hipLaunchKernelGGL(gdn_bwd_c128_w8, dim3(nblk), dim3(512), G8_LDS, st, a);
+        static const int waves = getenv("MASIC_GDNB_WAVES") ? atoi(getenv("MASIC_GDNB_WAVES")) : 8;
+        if (waves == 16) hipLaunchKernelGGL(gdn_bwd_c128_wn<1>, dim3(nblk), dim3(1024), G8_LDS, st, a);
+        else hipLaunchKernelGGL(gdn_bwd_c128_wn<2>, dim3(nblk), dim3(512), G8_LDS, st, a);
     } else if (x_f16k && g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
     else if (x_f16k) hipLaunchKernelGGL((gdn_bwd_c128<true, false>), dim3(nblk), dim3(256), GB_LDS, st, a);
     else if (g_f16k) hipLaunchKernelGGL((gdn_bwd_c128<false, true>), dim3(nblk), dim3(256), GB_LDS, st, a);
