@@ -387,7 +387,7 @@ __global__ __launch_bounds__(1024 / NML, 1) void gdn_bwd_c128_wn(const GdnBwdArg
             for (int q = 0; q < 4; ++q) {
                 const size_t ro = (size_t)(2 * (m0 + ml) + (q >> 1)) * rs16 + 8 * (q & 1);
                 uint2 rx = make_uint2(0u, 0u), rg = make_uint2(0u, 0u);
-                if (ok) { rx = *reinterpret_cast<const uint2*>(xr + ro); rg = *reinterpret_cast<const uint2*>(gr + ro); }
+                if (ok && !(a.dbg & 4)) { rx = *reinterpret_cast<const uint2*>(xr + ro); rg = *reinterpret_cast<const uint2*>(gr + ro); }
                 xv[ml][4 * q + 0] = __builtin_bit_cast(float, rx.x << 16);
                 xv[ml][4 * q + 1] = __builtin_bit_cast(float, rx.x & 0xffff0000u);
                 xv[ml][4 * q + 2] = __builtin_bit_cast(float, rx.y << 16);
@@ -464,14 +464,14 @@ __global__ __launch_bounds__(1024 / NML, 1) void gdn_bwd_c128_wn(const GdnBwdArg
                 uv[ml][e] = fmaf(2.0f * xv[ml][e], uv[ml][e], nv[ml][e]);
                 dsum[ml][e] += uv[ml][e];
             }
-        if (ok && a.gx != nullptr) {
+        if (ok && a.gx != nullptr && !(a.dbg & 1)) {
             float* op = a.gx + base;
 #pragma unroll
             for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) op[(unsigned)(32 * (m0 + ml) + (e & 3) + 8 * (e >> 2)) * hw] = uv[ml][e];
         }
-        if (ok && a.gxb != nullptr) {
+        if (ok && a.gxb != nullptr && !(a.dbg & 1)) {
             unsigned short* ob = a.gxb + base;
 #pragma unroll
             for (int ml = 0; ml < NML; ++ml)
@@ -493,10 +493,11 @@ __global__ __launch_bounds__(1024 / NML, 1) void gdn_bwd_c128_wn(const GdnBwdArg
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     uint4 st;
                     st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
-                    if (ok) *reinterpret_cast<uint4*>(rec + (size_t)(2 * (m0 + ml) + r) * rs16) = st;
+                    if (ok && !(a.dbg & 1)) *reinterpret_cast<uint4*>(rec + (size_t)(2 * (m0 + ml) + r) * rs16) = st;
                 }
         }
         // ---- d gamma^ block (rows: t block pg, columns: x^2 blocks m0 .. m0 + NML - 1) over the 128 pixels; d beta^ with B = ones
+        if (!(a.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             g8v2u af[2], bf[NML][2];
