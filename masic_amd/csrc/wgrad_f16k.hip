@@ -287,10 +287,15 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][0][e] = 0.0f; acc[0][1][e] = 0.0f; acc[1][0][e] = 0.0f; acc[1][1][e] = 0.0f; }
     // channel sums of dy next to the weight gradient (its bias gradient; a separate reduction pass over dy cost 20-30 us per layer):
-    // one more MFMA per fragment against a matrix of ones, in the workgroups of the first column (rows operand) / row (columns operand)
-    // of output tiles only
-    const bool bsum = a.bias_mode == 1 ? (int)blockIdx.x % a.q_tiles == 0 && wq == 0
-                                       : (a.bias_mode == 2 ? (int)blockIdx.x / a.q_tiles == 0 && wa == 0 : false);
+    // one more MFMA per fragment against a matrix of ones.  The workgroups of a row (column) of output tiles all stage the same dy
+    // tile, so the duty rotates: workgroup t of the row takes every q_tiles-th (a_tiles-th) of its k-tiles, and the two waves that hold
+    // the same fragments split the k-steps -- with the whole job in the first workgroup of each row the launch waited for that one
+    // (38 -> 55 us per layer).
+    const int a_tiles = (int)gridDim.x / a.q_tiles;
+    const int duty_n = a.bias_mode == 1 ? a.q_tiles : (a.bias_mode == 2 ? a_tiles : 1);
+    const int duty_i = a.bias_mode == 1 ? (int)blockIdx.x % a.q_tiles : (int)blockIdx.x / a.q_tiles;
+    const int duty_w = a.bias_mode == 1 ? wq : wa;           // this wave's parity of k-steps
+    int duty_c = 0;                                           // counts this workgroup's k-tiles modulo duty_n
     f32x16 accb[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { accb[0][e] = 0.0f; accb[1][e] = 0.0f; }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), bq, acc[m][n], 0, 0, 0);
                 });
             });
-            if (bsum) {
+            if (a.bias_mode != 0 && duty_c == duty_i && (ks & 1) == duty_w) {
                 sfor<0, 2>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     if (a.bias_mode == 1) accb[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[pb][m][0], af[pb][m][1]), ones, accb[m], 0, 0, 0);
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
             }
         });
         __builtin_amdgcn_s_barrier();            // everyone is done reading this buffer before the next iteration's DMA overwrites it
+        duty_c = duty_c + 1 == duty_n ? 0 : duty_c + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int j = lane & 31, h = lane >> 5;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16k(const Wg1Args a) {
                 if (co < a.CA) atomicAdd(a.dw + (size_t)co * a.CQ + ci, acc[m][n][e]);
             }
         }
-    if (bsum) {
+    if (a.bias_mode != 0) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (a.bias_mode == 1) {            // row sums: every column of the accumulator holds them; column 0 writes

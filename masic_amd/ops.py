@@ -860,9 +860,10 @@ class StreamPacks:
         # (batched only inside `with batched_packs():` -- the training steps of masic_amd/train.py, one stream: a refresh rewrites every
         # registered buffer, and the multi-stream eval forward must not have buffers rewritten or first filled by another stream than the
         # one about to read them)
-        if stale >= 4 and 2 * stale >= len(self.entries) and _BATCHED_PACKS[0] > 0:
+        capturing = torch.cuda.is_current_stream_capturing()      # (no host -> device copy of a new job table inside a graph capture)
+        if stale >= 4 and 2 * stale >= len(self.entries) and _BATCHED_PACKS[0] > 0 and not (capturing and self.table is None):
             self.tick += 1
-            dead = [k for k, x in self.entries.items() if x[6] < self.tick - 4]
+            dead = [] if capturing else [k for k, x in self.entries.items() if x[6] < self.tick - 4]
             for k in dead:                 # (the registry holds the only reference that keeps such a weight and its pack alive)
                 del self.entries[k]
             if dead:
