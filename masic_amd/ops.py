@@ -856,12 +856,15 @@ class StreamPacks:
         e[6] = self.tick
         if e[3] == weight._version:
             return e[2]
-        stale = sum(1 for x in self.entries.values() if x[3] != x[0]._version)
+        # "most entries are stale" = the parameters were stepped; judged on the entries in use (requested since the refresh before last):
+        # the leftovers of a model that is gone must not keep the majority fresh
+        active = [x for x in self.entries.values() if x[6] >= self.tick - 1]
+        stale = sum(1 for x in active if x[3] != x[0]._version)
         # (batched only inside `with batched_packs():` -- the training steps of masic_amd/train.py, one stream: a refresh rewrites every
         # registered buffer, and the multi-stream eval forward must not have buffers rewritten or first filled by another stream than the
         # one about to read them)
         capturing = torch.cuda.is_current_stream_capturing()      # (no host -> device copy of a new job table inside a graph capture)
-        if stale >= 4 and 2 * stale >= len(self.entries) and _BATCHED_PACKS[0] > 0 and not (capturing and self.table is None):
+        if stale >= 4 and 2 * stale >= len(active) and _BATCHED_PACKS[0] > 0 and not (capturing and self.table is None):
             self.tick += 1
             dead = [] if capturing else [k for k, x in self.entries.items() if x[6] < self.tick - 4]
             for k in dead:                 # (the registry holds the only reference that keeps such a weight and its pack alive)

@@ -510,6 +510,7 @@ def test_weight_packs_refreshed_by_one_launch_equal_single_packs():
     net = net.to(DEV).train()
     x1, x2, hm = (t.to(DEV) for t in synth.synth_inputs(1, 64, 64, seed=12))
     mnn.set_precision("bf16")
+    ops._STREAM_PACKS.clear()        # (entries of earlier tests' models would dilute the "most entries are stale" rule)
     try:
         opt, aopt = make_optimizers(net)
         for _ in range(2):
