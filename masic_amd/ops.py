@@ -1400,7 +1400,7 @@ def conv2d_f16k_gdn_dual(x16, packed, bias, desc, gdn, products=3):
     return pre, y
 
 
-def conv_a_gdn_dual(x, packed, bias, gdn, in_coff=0, products=3):
+def conv_a_gdn_dual(x, packed, bias, gdn, in_coff=0, products=None):
     """First analysis layer + GDN -> (pre-GDN F16K, post-GDN F16K, Ho, Wo)."""
     _dev(x, "x")
     B, ctot, H, W = x.shape
