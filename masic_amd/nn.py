@@ -245,7 +245,7 @@ class _PackedWeightMixin:
                             gdn=None if gdn is None else (packed_gdn_f16k(gdn), gdn.inverse), out16=out16)
         return y, desc.Ho, desc.Wo
 
-    def run_f16k_dual(self, x16, B, Hi, Wi, gdn, products=3):
+    def run_f16k_dual(self, x16, B, Hi, Wi, gdn, products=None):
         """Training-mode forward of conv + (I)GDN on F16K: returns (pre-GDN F16K, post-GDN F16K, Ho, Wo)."""
         desc = self._desc_f16k(B, Hi, Wi, out_ctot=(self.out_channels + 15) // 16 * 16)
         pre, y = ops.conv2d_f16k_gdn_dual(x16, self.packed_f16k_weight(desc), None if self.bias is None else self.bias.detach(), desc,

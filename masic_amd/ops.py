@@ -1388,7 +1388,7 @@ def conv2d_f16k_few(x16, packed, bias32, desc, C, res32=None):
 
 
 # --------------------------------------------------------------------------------------------- training-mode fused forward (dual outputs)
-def conv2d_f16k_gdn_dual(x16, packed, bias, desc, gdn, products=3):
+def conv2d_f16k_gdn_dual(x16, packed, bias, desc, gdn, products=None):
     """F16K in -> (conv + bias before the GDN, GDN result), both F16K of desc.out_ctot channels.  gdn = (pack_gdn_f16k(..), inverse)."""
     if x16.dtype != torch.int16 or x16.numel() != desc.B * desc.in_ctot * desc.Hi * desc.Wi:
         raise RuntimeError("masic_amd.conv2d_f16k_gdn_dual: input buffer does not match the descriptor")
