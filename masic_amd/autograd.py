@@ -89,6 +89,7 @@ class ConvFn(Function):
 _PIC_END_DGRAD = os.environ.get("MASIC_PIC_END_DGRAD", "1") != "0"   # 0: input gradients of g_a_conv1 / g_s_conv4 on the float32 NCHW kernels (A/B timing)
 _GDN_BWD_SMALL = os.environ.get("MASIC_GDN_BWD_SMALL", "1") != "0"   # 0: GDN(3) backward as the nine-launch generic chain (A/B timing)
 _WGRAD5_F16K = os.environ.get("MASIC_WGRAD5_F16K", "1") != "0"     # 0: 5x5 stride-1 weight gradients on the float32-tile kernel (A/B timing)
+_DGRAD_FEW = os.environ.get("MASIC_DGRAD_FEW", "1") != "0"         # 0: input gradients of the <= 8-channel-input layers on the float32 direct kernel (A/B timing)
 _PIC_WGRAD = os.environ.get("MASIC_PIC_WGRAD", "1") != "0"         # 0: weight gradients of g_a_conv1 / g_s_conv4 on the float32-tile kernel (A/B timing)
 _WGRAD1_F16K = os.environ.get("MASIC_WGRAD1_F16K", "1") != "0"     # 0: 1x1 weight gradients on the float32 NCHW kernel (A/B timing)
 _WGRAD3_F16K = os.environ.get("MASIC_WGRAD3_F16K", "1") != "0"     # 0: 3x3 weight gradients on the tap-generic float32-tile kernel (A/B timing)
@@ -121,8 +122,8 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     Cout, Ho, Wo = g_shape[1], g_shape[2], g_shape[3]
     from . import nn as _mnn          # both gradients use the forward's operand precision (float32 accumulate either way)
     bf16 = _mnn._PRECISION != PREC_F32
-    d = d16 = None
-    dx_gemm = dx_f16k = False
+    d = d16 = d_few = None
+    dx_gemm = dx_f16k = dx_few = False
     if need_gx:
         d = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, prec=_mnn._PRECISION)
         if (d.Ho, d.Wo) != (Hi, Wi):
@@ -133,6 +134,12 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             # bf16 layout, float32 NCHW out; measured 1.1 ms of a 30 ms step against the implicit-GEMM kernel
             d16 = ops.make_conv_desc(B, Cout, Ho, Wo, Cin, kh, kw, s, p, transposed=not mod.transposed_conv, in_ctot=Cout, prec=_mnn._PRECISION)
             dx_f16k = ops.conv_f16k_supported(d16)
+            if not dx_f16k and _DGRAD_FEW and Cin <= 8 and s == 1 and not mod.transposed_conv and not mod.masked_conv:
+                # few input channels (the 3 / 6 -> 32 input layers of Independent_EN, MASIC.py:1456-1470): dx as the transposed convolution
+                # to 32 zero-padded channels on the MFMA path, only the real ones stored (masic_conv_f16k_few_fwd); the generic float32
+                # kernel took 263 us per launch at 8 x 512 x 512
+                d_few = ops.make_conv_desc(B, Cout, Ho, Wo, 32, kh, kw, s, p, transposed=True, in_ctot=Cout, prec=_mnn._PRECISION)
+                dx_few = ops.conv_f16k_supported(d_few)
     # 3x3 stride-1 layers (Independent_EN, hyper transforms): dW from both operands in F16K, transposed LDS reads (wgrad_f16k.hip)
     dw_f16k = (need_gw and _WGRAD3_F16K and bf16 and not mod.transposed_conv and not mod.masked_conv and (kh, kw, s, p) == (3, 3, 1, 1)
                and Cin % 32 == 0 and Cout % 32 == 0 and x_shape[1] == Cin)
@@ -140,7 +147,7 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     dw5_f16k = (need_gw and _WGRAD5_F16K and bf16 and not mod.transposed_conv and (kh, kw, s, p) == (5, 5, 1, 2)
                 and Cin % 32 == 0 and Cout % 32 == 0 and x_shape[1] == Cin)
     if g16 is None or act != ops.ACT_NONE:
-        g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dw_f16k or dw5_f16k) else None  # dy in F16K, converted once for both gradients
+        g16 = ops.nchw_to_f16k(g) if (dx_gemm or dx_f16k or dx_few or dw_f16k or dw5_f16k) else None  # dy in F16K, converted once for both gradients
 
     pic_end = _PIC_END_DGRAD and bf16 and need_gx and act == ops.ACT_NONE and (kh, kw, s, p) == (5, 5, 2, 2)
     # the two picture-end layers (MASIC.py:515 g_a_conv1 = Conv2d(3 -> 128), :550 g_s_conv4 = ConvTranspose2d(128 -> 3)); without
@@ -172,6 +179,10 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
             # dx = W^T g: the same GEMM kernel on the transposed weight (packed per step: the weights change with every optimizer step)
             wt = ops.pack_gemm_f16k_weight(weight.detach().contiguous(), Cout, Cin, not mod.transposed_conv)
             return ops.gemm_f16k(g16, wt, None, B, Cout, Cin, Ho, Wo, ops.ACT_NONE, want_nchw=True)
+        if dx_few:
+            wpad = ops.zeros((Cout, 32, kh, kw), torch.float32, weight.device)      # ConvTranspose2d layout [in = Cout][out = 32]
+            wpad[:, :Cin] = weight.detach()
+            return ops.conv2d_f16k_few(g16, ops.pack_conv_f16k_weight(wpad, d_few), ops.zeros(32, torch.float32, weight.device), d_few, Cin)
         if dx_f16k:
             return ops.conv2d_f16k(g16, ops.pack_conv_f16k_weight(weight.detach(), d16, persistent=weight.is_leaf and weight.is_contiguous() and not mod.masked_conv), None, d16,
                                    want_nchw=not (gx_f16k and Cin % 16 == 0))
