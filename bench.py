@@ -62,6 +62,111 @@ def host_cores():
     return max(1, min(avail, 16))
 
 
+# ------------------------------------------------------------------------------------------------ the reference drivers' loop shape
+def driver_loop_pieces():
+    """What an UNCHANGED driver brings: its own plain-torch criterion and optimizers (coremasic/mywork/newtrain_codec_real.py:66-87,
+    :434-435; newtrain_cqe_real.py:69-96 kind=0 without the ms_ssim report entries, :472).  Nothing of masic_amd.train / masic_amd.loss."""
+    import math
+    import torch.nn as nn
+
+    class RateDistortionLoss(nn.Module):
+        def __init__(self, lmbda=1e-2, rate=True):
+            super().__init__()
+            self.mse = nn.MSELoss()
+            self.lmbda = lmbda
+            self.rate = rate
+
+        def forward(self, output, target1, target2):
+            N, _, H, W = target1.size()
+            out = {}
+            num_pixels = N * H * W
+            out['mse_loss'] = self.mse(output['x1_hat'], target1) + self.mse(output['x2_hat'], target2)
+            out['loss'] = self.lmbda * 255 ** 2 * out['mse_loss']
+            if self.rate:
+                out['bpp_loss'] = sum((torch.log(likelihoods).sum() / (-math.log(2) * num_pixels)) for likelihoods in output['likelihoods'].values())
+                out['loss'] = out['loss'] + out['bpp_loss']
+            out['psnr1'] = 10 * math.log10(1 / self.mse(output['x1_hat'], target1))
+            out['psnr2'] = 10 * math.log10(1 / self.mse(output['x2_hat'], target2))
+            return out
+
+    def codec_iteration(i, model, criterion, optimizer, aux_optimizer, d1, d2, h_matrix):       # newtrain_codec_real.py:132-161
+        optimizer.zero_grad()
+        aux_optimizer.zero_grad()
+        out_net = model(d1, d2, h_matrix)
+        out_criterion = criterion(out_net, d1, d2)
+        out_criterion['loss'].backward()
+        optimizer.step()
+        aux_loss = model.aux_loss()
+        aux_loss.backward()
+        aux_optimizer.step()
+        if i % 10 == 0:
+            return (out_criterion["loss"].item(), out_criterion["mse_loss"].item(), out_criterion["bpp_loss"].item(), aux_loss.item())
+        return out_criterion['loss']
+
+    def cqe_iteration(i, model, model2, criterion, optimizer, aux_optimizer, d1, d2, h_matrix):   # newtrain_cqe_real.py:152-180
+        optimizer.zero_grad()
+        aux_optimizer.zero_grad()
+        out_net = model(d1, d2, h_matrix)            # eval mode, grad enabled: as the driver runs it
+        out_net2 = model2(out_net['x1_hat'], out_net['x2_hat'], h_matrix)
+        out_criterion = criterion(out_net2, d1, d2)
+        out_criterion['loss'].backward()
+        optimizer.step()
+        aux_loss = model.aux_loss()
+        if i % 10 == 0:
+            return (out_criterion["loss"].item(), out_criterion["mse_loss"].item(), aux_loss.item())
+        return out_criterion['loss']
+
+    return RateDistortionLoss, codec_iteration, cqe_iteration
+
+
+def rehearsal_reducer_check(dev, rank, world):
+    """MASIC_BENCH_REHEARSAL only (several ranks on one GPU over gloo): the reducer sees world > 1 on the REAL model once --
+    HSIC(16,24,3) gradients of a 2*world-pair batch == the all-reduced mean over the ranks' 2-pair shards (each rank checks)."""
+    import MASIC
+    from compressai.entropy_models import EntropyModel
+    from masic_amd import synth
+    from masic_amd.loss import rate_distortion
+    from masic_amd.parallel import GradientAllReducer, shard_range
+    NOISE_KEYS = ("z1", "y1_ctx", "y1", "z2", "y2_ctx", "y1_warp", "y2")     # the seven draws of a training forward, in order (SURVEY appendix D)
+    N, M, K, H, W = 16, 24, 3, 64, 64
+    B = 2 * world
+    net = MASIC.HSIC(N, M, K)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=77))
+    net = net.to(dev).train()
+    x1, x2, hm = (t.to(dev) for t in synth.synth_inputs(B, H, W, seed=77))
+    noise = {k: v.to(dev) for k, v in synth.synth_noise(B, N, M, H, W, seed=77).items()}
+    hw_z = (H // 64) * (W // 64)
+
+    def run(lo, hi, red):
+        queue = [noise[k][:, :, lo * hw_z:hi * hw_z].contiguous() if k[0] == "z" else noise[k][lo:hi].contiguous() for k in NOISE_KEYS]
+        orig = EntropyModel._get_noise_cached
+        EntropyModel._get_noise_cached = lambda self, x: queue.pop(0).reshape(x.shape)
+        try:
+            net.zero_grad()
+            if red is not None:
+                red.arm()
+            out = net(x1[lo:hi].contiguous(), x2[lo:hi].contiguous(), hm[lo:hi].contiguous())
+            rate_distortion(out, x1[lo:hi].contiguous(), x2[lo:hi].contiguous(), 0.01)["loss"].backward()
+            if red is not None:
+                red.finish()
+        finally:
+            EntropyModel._get_noise_cached = orig
+        return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in net.named_parameters()}
+
+    full = run(0, B, None)
+    red = GradientAllReducer(net, bucket_bytes=256 << 10)
+    worst = 0.0
+    for _ in range(2):                 # second step: learnt no-gradient set, overlapped launches from the hooks
+        mine = run(*shard_range(B, rank, world), red)
+        for n, g in full.items():
+            assert (g is None) == (mine[n] is None), n
+            if g is not None:
+                worst = max(worst, float((mine[n] - g).abs().max()) / (float(g.abs().max()) + 1e-30))
+    red.remove()
+    assert worst <= 1e-4, f"rank {rank}: all-reduced shard-mean gradients differ from the full-batch gradients by {worst:.2e}"
+    return {"world": world, "model": "HSIC(16,24,3)", "pairs": B, "buckets": len(red.buckets), "worst_rel_err": worst}
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs (oracle = checker)
 def cpu_baseline(N, M, K, seed, budget_s=45.0):
     """Oracle (CPU float32 restatement pinned to the reference, kind "port") on the host cores.  BASELINE.md section 4 legs:
@@ -284,6 +389,7 @@ def main():
     from masic_amd import nn as mnn
     from masic_amd import ops, synth
     from masic_amd.loss import distortion, rate_distortion
+    rehearsal_info = rehearsal_reducer_check(dev, rank, world) if (rehearsal and world > 1) else None
     mnn.set_precision(args.precision)
 
     N, M, K = 128, 192, 5
@@ -329,6 +435,22 @@ def main():
             out = step(xa, xb, hm, **ahead)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+
+        # ---- the same step WITHOUT the look-ahead: the homography arrives with its own batch, as the reference computes it right before
+        # model(d1, d2, h_matrix) (newtrain_codec_real.py:124-137) -- each call waits for the previous replay, reads it, runs the host chain
+        no_lookahead = None
+        if not args.no_graph:
+            for _ in range(2):
+                step(xa, xb, hm)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(xa, xb, hm)
+            barrier()
+            t_nl = max_over_ranks(time.perf_counter() - t0)
+            no_lookahead = {"value": world * B * args.steps / t_nl, "unit": "stereo pairs/s", "ms_per_step": t_nl / args.steps * 1e3, "steps": args.steps,
+                            "what": "the headline step called as step(x1, x2, h_matrix) with no next_h_matrix: device->host read of the homography, float32 host chain, "
+                                    "upload, replay -- strictly in sequence"}
 
         # ---- upload-inclusive rates (never `value`): the boundary takes device pointers; a caller that owns host batches pays PCIe
         upload = None
@@ -546,7 +668,7 @@ def main():
             from masic_amd.parallel import GradientAllReducer
             from masic_amd.train import cqe_train_step
             en.train()
-            opt2 = torch.optim.Adam(list(en.parameters()), lr=1e-4, fused=True)      # cqe_train_step bumps the version counters a fused step leaves alone
+            opt2 = torch.optim.Adam(list(en.parameters()), lr=1e-4, fused=True)      # (masic_amd/fresh.py's step hook bumps the version counters a fused step leaves alone)
             red2 = GradientAllReducer(en) if world > 1 else None
             for _ in range(2):                        # warm-up: weight packs of both kinds, optimizer state, allocator pools
                 cqe_train_step(net, en, opt2, x1, x2, hm, 0.01, red2)
@@ -559,9 +681,30 @@ def main():
             cqe_info["train_step"] = {"value": world * B * args.train_steps / tc, "unit": "stereo pairs/s", "steps": args.train_steps,
                                       "ms_per_step": tc / args.train_steps * 1e3, "loss_after": float(crit2["loss"]),
                                       "what": "newtrain_cqe_real.py:128-174: HSIC eval forward (no_grad) + Independent_EN forward + distortion loss + "
-                                              "backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + Adam"}
+                                              "backward" + ((" + gloo gradient all-reduce (REHEARSAL)" if rehearsal else " + RCCL gradient all-reduce") if world > 1 else "") + " + Adam"}
             if red2 is not None:
                 red2.remove()
+            if world == 1:
+                # the reference driver's own loop on the product modules (plain criterion, plain Adam, HSIC in eval mode WITH grad enabled)
+                RDL, _, cqe_it = driver_loop_pieces()
+                net.eval()
+                en.train()
+                crit_d = RDL(0.01, rate=False)
+                opt_d = torch.optim.Adam(en.parameters(), lr=1e-4)
+                aopt_d = torch.optim.Adam(net.aux_parameters(), lr=1e-3)
+                for i in range(2):
+                    cqe_it(1, net, en, crit_d, opt_d, aopt_d, x1, x2, hm)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(args.train_steps):
+                    r = cqe_it(i, net, en, crit_d, opt_d, aopt_d, x1, x2, hm)
+                barrier()
+                td = time.perf_counter() - t0
+                cqe_info["train_step_driver_loop"] = {"value": B * args.train_steps / td, "unit": "stereo pairs/s", "steps": args.train_steps,
+                                                      "ms_per_step": td / args.train_steps * 1e3, "ratio_to_train_step": td / tc,
+                                                      "what": "newtrain_cqe_real.py:152-180 restated on the caller side only: nn.MSELoss criterion, optim.Adam(model2.parameters()) "
+                                                              "(not fused), HSIC called in eval mode with grad enabled, model.aux_loss() evaluated, .item() reads of the log line "
+                                                              "at i % 10 == 0 (tests/test_gpu_driver_loop.py checks this loop against the reference's gradients)"}
         del en
 
     train_info = None
@@ -586,6 +729,39 @@ def main():
                       "frac_of_mfma_peak": gf / 1e3 / (tt / args.train_steps) / (F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else BF16_MFMA_PEAK_TFLOPS),
                       "what": f"forward ({args.precision} operands) + RD loss + backward ({args.precision} operands, f32 accumulate)" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                               " + Adam + aux loss backward + aux Adam (newtrain_codec_real.py:135-146); algorithmic work = 3 x the forward's (SURVEY 8d)"}
+
+    driver_info = None
+    if args.train_steps > 0 and world == 1:
+        # the reference driver's own loop (newtrain_codec_real.py:132-161) on the product HSIC: its plain-torch criterion, its unfused Adam pair,
+        # model.aux_loss().backward(), its .item() reads -- no masic_amd.train / masic_amd.loss on the path
+        RDL, codec_it, _ = driver_loop_pieces()
+        driver_info = {}
+        for mode in ([args.precision] + (["f32"] if args.precision != "f32" and not args.no_f32_compare else [])):
+            if mode == "fp8":
+                continue
+            mnn.set_precision(mode)
+            net.train()
+            crit_d = RDL(0.01)
+            opt_d = torch.optim.Adam(net.parameters(), lr=1e-4)
+            aopt_d = torch.optim.Adam(net.aux_parameters(), lr=1e-3)
+            for i in range(2):
+                codec_it(1, net, crit_d, opt_d, aopt_d, x1, x2, hm)
+            barrier()
+            nd = args.train_steps if mode != "f32" else max(2, args.train_steps // 2)
+            t0 = time.perf_counter()
+            for i in range(nd):
+                r = codec_it(i, net, crit_d, opt_d, aopt_d, x1, x2, hm)
+            barrier()
+            td = time.perf_counter() - t0
+            driver_info[mode] = {"value": B * nd / td, "unit": "stereo pairs/s", "steps": nd, "ms_per_step": td / nd * 1e3,
+                                 "loss_first_logged": r[0] if isinstance(r, tuple) else float(r)}
+            if mode == args.precision and train_info is not None:
+                driver_info[mode]["ratio_to_train_step"] = (td / nd * 1e3) / train_info["ms_per_step"]
+        mnn.set_precision(args.precision)
+        driver_info["what"] = ("newtrain_codec_real.py:132-161 restated on the caller side only: RateDistortionLoss from torch.log(lik).sum() / nn.MSELoss, "
+                               "optim.Adam(net.parameters(), 1e-4) + optim.Adam(net.aux_parameters(), 1e-3) (torch's default foreach form), loss.backward(), "
+                               "model.aux_loss().backward(), .item() reads of the log line at i % 10 == 0; tests/test_gpu_driver_loop.py checks this loop "
+                               "against the reference's gradient goldens")
 
     codec_info = None
     if rank == 0 and not args.no_codec:
@@ -628,6 +804,10 @@ def main():
         extras = {}
         if train_info is not None:
             extras["train_step"] = train_info
+        if driver_info is not None:
+            extras["train_step_driver_loop"] = driver_info
+        if no_lookahead is not None:
+            extras["no_lookahead"] = no_lookahead
         if fp8_info is not None:
             extras["fp8_path"] = fp8_info
         if f32_info is not None:
@@ -641,6 +821,8 @@ def main():
             extras["independent_en"] = cqe_info
         if codec_info is not None:
             extras["bitstream"] = codec_info
+        if rehearsal_info is not None:
+            extras["rehearsal_reducer_check"] = rehearsal_info
         if extras:
             line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from compressai.ops import LowerBound
 from masic_amd import ops as _hip
+from masic_amd.fresh import stamp as _stamp
 
 from masic_amd import rans as _rans
 
@@ -175,11 +176,11 @@ class EntropyBottleneck(EntropyModel):
             table = eb_param_table(list(self._matrices), list(self._biases), list(self._factors))
             # the same values serve the detached uses until the parameters change (the auxiliary step of the same iteration)
             params = list(self._matrices) + list(self._biases) + list(self._factors)
-            self.__dict__["_table_cache"] = (tuple((p._version, p.data_ptr()) for p in params), table.detach())
+            self.__dict__["_table_cache"] = (tuple((_stamp(p), p.data_ptr()) for p in params), table.detach())
             return table
         # inference: the [C, 58] table only changes with the parameters -- rebuilt per parameter version, not per forward
         params = list(self._matrices) + list(self._biases) + list(self._factors)
-        key = tuple((p._version, p.data_ptr()) for p in params)
+        key = tuple((_stamp(p), p.data_ptr()) for p in params)
         cache = self.__dict__.get("_table_cache")
         if cache is None or cache[0] != key:
             cache = (key, _hip.eb_param_table([m.detach() for m in self._matrices], [b.detach() for b in self._biases],

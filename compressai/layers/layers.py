@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from masic_amd import ops as _hip
+from masic_amd.fresh import stamp as _stamp
 from masic_amd.nn import Conv2d
 
 __all__ = ["MaskedConv2d", "ResidualBlock", "conv3x3", "conv1x1"]
@@ -33,10 +34,10 @@ class MaskedConv2d(Conv2d):
     def zero_masked_taps(self):
         """The reference multiplies weight.data by the mask in place on every forward (layers.py:77); once a weight version is
         masked the product is idempotent, so it is skipped until the parameter changes (optimizer step, load_state_dict)."""
-        key = (self.weight._version, self.weight.data_ptr())
+        key = (_stamp(self.weight), self.weight.data_ptr())
         if self.__dict__.get("_masked_version") != key:
             _hip.mul_inplace(self.weight.data, self.mask)
-            self.__dict__["_masked_version"] = (self.weight._version, self.weight.data_ptr())
+            self.__dict__["_masked_version"] = (_stamp(self.weight), self.weight.data_ptr())
 
     def run(self, x, **kw):
         self.zero_masked_taps()

@@ -996,6 +996,7 @@ class HSIC(CompressionModel):
         B, _, H, W = x1.shape
         self._codec_check(B, H, W)
         M, K = self.M, self.K
+        fp8_table = _fp8.stream_table(self) if _mnn.get_precision() == "fp8" else None
         with torch.no_grad():
             m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
             # left view
@@ -1033,7 +1034,12 @@ class HSIC(CompressionModel):
                 f.write(s_z)
         out2 = os.path.join(output_path, str(output_name) + ".bin")
         with open(out2, "wb") as f:
-            f.write(codec.MAGIC + bytes([{"f32": 0, "bf16": 1, "fp8": 2}[_mnn.get_precision()], 0, 0, 0]))
+            f.write(codec.MAGIC + bytes([{"f32": 0, "bf16": 1, "fp8": 2}[_mnn.get_precision()], 1 if fp8_table is not None else 0, 0, 0]))
+            if fp8_table is not None:
+                # the coding tables of the fp8 mode depend on the activation scales of masic_amd.fp8.calibrate, which live outside
+                # state_dict(): the stream carries them, so any decoder holding the same weights rebuilds the same tables
+                f.write(np.array([len(fp8_table)], dtype=np.uint32).tobytes())
+                f.write(fp8_table)
             for s_y in (s_y1, s_y2):
                 f.write(np.array([len(s_y)], dtype=np.uint32).tobytes())
                 f.write(s_y)
@@ -1063,13 +1069,19 @@ class HSIC(CompressionModel):
             if head[4] != {"f32": 0, "bf16": 1, "fp8": 2}[_mnn.get_precision()]:
                 raise ValueError("HSIC.decompress: the stream was written in the %s operand mode; the coding tables depend on it "
                                  "(masic_amd.nn.set_precision)" % ("f32", "bf16", "fp8")[head[4] if head[4] < 3 else 0])
+            fp8_table = None
+            if head[5] & 1:
+                n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])
+                fp8_table = f.read(n)
+            elif head[4] == 2:
+                raise ValueError("HSIC.decompress: an fp8-mode stream without its activation-scale table")
             streams = []
             for _ in range(2):
                 n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])
                 streams.append(f.read(n))
         self._codec_check(1, H, W)
         h, w = H // 16, W // 16
-        with torch.no_grad():
+        with torch.no_grad(), _fp8.stream_scales(self, fp8_table):
             m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
             z1_hat = self.entropy_bottleneck1.decompress([views[0][0]], (h // 4, w // 4))
             z2_hat = self.entropy_bottleneck2.decompress([views[1][0]], (h // 4, w // 4))

@@ -13,7 +13,8 @@ Encoder and decoder evaluate the SAME kernels on tensors of the same shape, and 
 convolution are exact zeros, so a not-yet-decoded neighbour (zero in the decoder, the true value in the encoder) never
 changes a bit of the parameters of the pixel being coded: the encoder needs ONE pass over the full latent, the decoder
 one pass per wavefront.
-Container (.bin): b"MSR1", u8 precision id (0 f32 / 1 bf16 operands: the tables depend on it), 3 pad bytes, then per
+Container (.bin): b"MSR1", u8 precision id (0 f32 / 1 bf16 / 2 fp8 operands: the tables depend on it), u8 flags (bit 0: an
+activation-scale table follows), 2 pad bytes, [u32 length + the fp8 mode's calibration table as JSON, masic_amd/fp8.py], then per
 view u32 length + rANS words.  The .npz header keeps the reference's layout (MASIC.py:916-948)."""
 import ctypes
 

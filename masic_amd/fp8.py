@@ -80,3 +80,46 @@ def load_scales(net, table):
     mods = dict(net.named_modules())
     for name, sc in table.items():
         mods[name].__dict__["_fp8_scale"] = {k: float(v) for k, v in sc.items()}
+
+
+# ---- the scales as part of a bitstream (HSIC.compress / decompress in the fp8 mode; container: masic_amd/codec.py)
+_STREAM_OWNERS = ("encoder1", "encoder2", "decoder1", "decoder2", "_h_s1_same_resolution", "_h_s2_same_resolution")
+
+
+def stream_table(net):
+    """The calibration table of `net` as bytes for the .bin header.  Raises when a module the fp8 mode quantises in has no scales:
+    such a module would silently fall back to bf16 operands under a stream stamped fp8."""
+    import json
+    table = export_scales(net)
+    missing = [n for n in _STREAM_OWNERS if hasattr(net, n) and n not in table]
+    if missing:
+        raise RuntimeError("HSIC.compress in the fp8 operand mode needs masic_amd.fp8.calibrate(net, batches) (or load_scales) first: "
+                           "no activation scales on " + ", ".join(missing))
+    return json.dumps(table, sort_keys=True).encode()         # (repr of a Python float round-trips exactly)
+
+
+class stream_scales:
+    """Context of HSIC.decompress: while decoding, the modules carry the scales the ENCODER used (read from the stream); whatever the
+    decoder's own calibration was comes back afterwards.  `raw` None: nothing to do (f32 / bf16 streams)."""
+
+    def __init__(self, net, raw):
+        self.net, self.raw = net, raw
+
+    def __enter__(self):
+        if self.raw is None:
+            return self
+        import json
+        self.saved = {name: m.__dict__.get("_fp8_scale") for name, m in self.net.named_modules()}
+        for m in self.net.modules():
+            m.__dict__.pop("_fp8_scale", None)
+        load_scales(self.net, json.loads(self.raw.decode()))
+        return self
+
+    def __exit__(self, *exc):
+        if self.raw is None:
+            return False
+        for name, m in self.net.named_modules():
+            m.__dict__.pop("_fp8_scale", None)
+            if self.saved.get(name) is not None:
+                m.__dict__["_fp8_scale"] = self.saved[name]
+        return False

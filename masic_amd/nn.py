@@ -44,6 +44,9 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+from .fresh import invalidate_packs, set_pack_verify, stamp, weight_key  # noqa: E402,F401  (freshness keys of everything derived from a parameter)
+
+
 def _cached(obj, slot, version_key, shape_key, build):
     """Per-module pack cache: one dict per parameter version, one entry per (shape, precision) it was packed for.  A call at
     another shape adds an entry instead of evicting the previous one -- a captured HIP graph (masic_amd/graph.py) keeps
@@ -66,7 +69,7 @@ def pack_sources(module):
 
 def pack_signature(tensors):
     """(version counter, storage pointer) of each source tensor.  GraphedHSIC compares it before each replay (~50 us)."""
-    return tuple([(t._version, t.data_ptr()) for t in tensors])
+    return tuple([(stamp(t), t.data_ptr()) for t in tensors])
 
 
 def cached_packs(module):
@@ -89,7 +92,7 @@ def cached_packs(module):
 
 def packed_gdn_f16k(gdn):
     """Fragment-order parameters of a GDN module for conv_f16k's fused epilogue, cached per parameter version."""
-    key = (gdn.beta._version, gdn.gamma._version, gdn.beta.data_ptr(), gdn.gamma.data_ptr())
+    key = weight_key(gdn.beta) + weight_key(gdn.gamma)
     cache = gdn.__dict__.get("_packed_f16k_cache")
     if cache is None or cache[0] != key:
         cache = (key, ops.pack_gdn_f16k(gdn.beta.detach(), gdn.gamma.detach().contiguous(), gdn.beta_min))
@@ -122,13 +125,13 @@ class _PackedWeightMixin:
 
     def packed_weight(self, desc):
         w = self.weight
-        return _cached(self, "_packed_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi, desc.prec),
+        return _cached(self, "_packed_cache", weight_key(w), (desc.B, desc.Hi, desc.Wi, desc.prec),
                        lambda: ops.pack_conv_weight(w.detach().contiguous(), desc))
 
     def packed_gemm_weight(self):
         """[ci/16][co][16] bf16 pack of a 1x1 layer for the register-streamed GEMM (masic_amd/csrc/gemm_bf16.hip)."""
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device))
+        key = weight_key(w)
         cache = self.__dict__.get("_packed_gemm_cache")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_gemm1x1_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))
@@ -149,7 +152,7 @@ class _PackedWeightMixin:
 
     def packed_f16k_weight(self, desc):
         w = self.weight
-        return _cached(self, "_packed_f16k_cache", (w._version, w.data_ptr(), str(w.device)), (desc.B, desc.Hi, desc.Wi),
+        return _cached(self, "_packed_f16k_cache", weight_key(w), (desc.B, desc.Hi, desc.Wi),
                        lambda: ops.pack_conv_f16k_weight(w.detach().contiguous(), desc, persistent=w.is_contiguous() and not self.masked_conv))     # (a masked layer zeroes taps in place right before its pack)
 
     # ---- fp8 operands (masic_amd/csrc/conv_f16k.hip: conv_f16k<..., F8>; activations F8K [B][C/32][H*W][32] fp8)
@@ -176,7 +179,7 @@ class _PackedWeightMixin:
         y: F16K bf16 ("f16k"), F8K fp8(y / out_scale) ("f8k") or float32 NCHW ("nchw" / a view of `out_nchw`)."""
         desc = self._out_desc(self._desc_f8k, B, Hi, Wi, act, out, out_nchw, out_coff, gate, gate_c)
         w = self.weight
-        vkey = (w._version, w.data_ptr(), str(w.device))
+        vkey = weight_key(w)
         wp, ws = _cached(self, "_packed_f8k_cache", vkey, (desc.B, desc.Hi, desc.Wi), lambda: ops.pack_conv_f8k_weight(w.detach().contiguous(), desc))
         wscale = _cached(self, "_wscale_f8k_cache", vkey, (desc.B, desc.Hi, desc.Wi, float(in_scale)), lambda: (ws * float(in_scale)).contiguous())
         y = ops.conv2d_f8k(x8, wp, wscale, None if self.bias is None else self.bias.detach(), desc, out=out, out_scale=out_scale, out_nchw=out_nchw,
@@ -193,14 +196,14 @@ class _PackedWeightMixin:
     def packed_gemm_f8k_weight(self, in_scale):
         """(fp8 pack, dequantisation scales = per-channel weight scale x in_scale) of a 1x1 layer for gemm_f8k."""
         w = self.weight
-        vkey = (w._version, w.data_ptr(), str(w.device))
+        vkey = weight_key(w)
         wp, ws = _cached(self, "_packed_gemm_f8k_cache", vkey, (), lambda: ops.pack_gemm_f8k_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))
         return wp, _cached(self, "_wscale_gemm_f8k_cache", vkey, (float(in_scale),), lambda: (ws * float(in_scale)).contiguous())
 
     def packed_first_layer_weight(self):
         """Fragment image of a Conv2d(3, 128, 5, stride 2) weight for the fused conv + GDN kernel of the first analysis layer."""
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device))
+        key = weight_key(w)
         cache = self.__dict__.get("_packed_conv_a_cache")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_conv_a_weight(w.detach().contiguous()))
@@ -218,7 +221,7 @@ class _PackedWeightMixin:
         def build():
             wc, bc = ops.deconv_s2_as_conv_weight_dev(w.detach().contiguous(), None if self.bias is None else self.bias.detach())
             return ops.pack_conv_f16k_weight(wc, desc), bc
-        wp, bc = _cached(self, "_packed_d2s_cache", (w._version, w.data_ptr(), str(w.device), None if self.bias is None else self.bias._version),
+        wp, bc = _cached(self, "_packed_d2s_cache", weight_key(w) + (None if self.bias is None else weight_key(self.bias),),
                          (B, Hi, Wi), build)
         return ops.conv2d_f16k_d2s(x16, wp, bc, desc, self.out_channels, out=out, out_coff=out_coff)
 
@@ -260,7 +263,7 @@ class _PackedWeightMixin:
         if self.resident_supported(B, Hi, Wi) and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY):
             # 32 -> 32 3x3 layers: weights resident in LDS, persistent workgroups (conv_f16k.hip: conv3x3_resident_f16k)
             w = self.weight
-            wp = _cached(self, "_packed_c3_cache", (w._version, w.data_ptr(), str(w.device)), (), lambda: ops.pack_conv3x3_resident_weight(w.detach()))
+            wp = _cached(self, "_packed_c3_cache", weight_key(w), (), lambda: ops.pack_conv3x3_resident_weight(w.detach()))
             return ops.conv3x3_resident(x16, wp, bias, B, self.in_channels, self.out_channels, Hi, Wi, act=act, y16=out16, out_ctot=oc, out_coff=out_coff,
                                         res1=res1, res2=res2, res_ctot=res_ctot, y_pre=y_pre)
         desc = self._desc_f16k(B, Hi, Wi, out_ctot=oc, out_coff=out_coff, act=act)
@@ -284,7 +287,7 @@ class _PackedWeightMixin:
         kh, kw, s_, p_ = self._geometry()
         desc = ops.make_conv_desc(B, self.in_channels, Hi, Wi, 32, kh, kw, s_, p_, prec=PREC_BF16)
         w = self.weight
-        vkey = (w._version, w.data_ptr(), str(w.device), None if self.bias is None else self.bias._version)
+        vkey = weight_key(w) + (None if self.bias is None else weight_key(self.bias),)
 
         def build():
             wpad = torch.zeros((32,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
@@ -299,7 +302,7 @@ class _PackedWeightMixin:
     def packed_gemm_dma_weight(self):
         """Per-128-channel-block k16-major pack of a 1x1 layer for the DMA-staged GEMM (conv_f16k.hip: gemm_f16k)."""
         w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device))
+        key = weight_key(w)
         cache = self.__dict__.get("_packed_gemm_dma_cache")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_gemm_f16k_weight(w.detach().contiguous(), self.in_channels, self.out_channels, self.transposed_conv))

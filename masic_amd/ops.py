@@ -8,6 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .fresh import stamp as _stamp
 from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SOFTMAX_C, INOP_ABS, INOP_NONE, INOP_ROUND,  # noqa: F401
                    ConvDesc, check, lib)
 
@@ -854,12 +855,12 @@ class StreamPacks:
         if e is None:
             e = self._register(key, weight, desc)
         e[6] = self.tick
-        if e[3] == weight._version:
+        if e[3] == _stamp(weight):
             return e[2]
         # "most entries are stale" = the parameters were stepped; judged on the entries in use (requested since the refresh before last):
         # the leftovers of a model that is gone must not keep the majority fresh
         active = [x for x in self.entries.values() if x[6] >= self.tick - 1]
-        stale = sum(1 for x in active if x[3] != x[0]._version)
+        stale = sum(1 for x in active if x[3] != _stamp(x[0]))
         # (batched only inside `with batched_packs():` -- the training steps of masic_amd/train.py, one stream: a refresh rewrites every
         # registered buffer, and the multi-stream eval forward must not have buffers rewritten or first filled by another stream than the
         # one about to read them)
@@ -877,10 +878,10 @@ class StreamPacks:
                 self.max_nb = max(x[5] for x in self.entries.values())
             check(lib.masic_conv_f16k_pack_jobs_run(_p(self.table), len(self.entries), self.max_nb, _stream()), "conv_f16k_pack_jobs_run")
             for x in self.entries.values():
-                x[3] = x[0]._version
+                x[3] = _stamp(x[0])
         else:
             check(lib.masic_conv_f16k_pack_weight(_p(e[0]), _p(e[2]), ctypes.byref(e[1]), _stream()), "conv_f16k_pack_weight")
-            e[3] = weight._version
+            e[3] = _stamp(weight)
         return e[2]
 
 

@@ -61,9 +61,10 @@ class GradientAllReducer:
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._expected = None            # ids of the parameters that receive a gradient (learnt on the first step)
         self._got = set()
-        self._pending = [len(b) for b in self.buckets]
+        self._need = [set(id(p) for p in b) for b in self.buckets]      # per bucket: expected ids whose gradient has not landed yet
         self._inflight = {}
         self._armed = False
+        self._cancelled = False          # this step's overlap is off: every bucket is launched from finish()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def bucket_plan(self):
@@ -78,24 +79,42 @@ class GradientAllReducer:
         for p in self.params:
             p.grad = self._views[id(p)]
         if self._expected is None:
-            self._pending = [len(b) for b in self.buckets]
+            self._need = [set(id(p) for p in b) for b in self.buckets]
         else:
-            self._pending = [sum(1 for p in b if id(p) in self._expected) for b in self.buckets]
+            self._need = [set(id(p) for p in b if id(p) in self._expected) for b in self.buckets]
         self._got = set()
         self._inflight = {}
+        self._cancelled = False
         self._armed = True
 
     # ---- called by autograd when a parameter's gradient is complete
     def _on_grad(self, p):
+        """Readiness is tracked PER PARAMETER: bucket i is launched when every expected parameter of it has fired exactly once.
+        A parameter firing a second time (a second backward between arm() and finish(): gradient accumulation) or one outside the
+        learnt set (another graph than the step before) switches this step's overlap off -- all buckets then go out from finish(),
+        after the last backward.  If the bucket it belongs to is ALREADY being reduced, autograd has just accumulated into a buffer
+        an asynchronous collective is reading and writing: nothing can repair that, so it raises (use overlap=False to accumulate
+        gradients over several backwards)."""
         if not self._armed:
             return
         if p.grad is None or p.grad.data_ptr() != self._views[id(p)].data_ptr():
             # autograd replaced the tensor (cannot happen while .grad is bound before backward; kept as a hard check)
             raise RuntimeError("GradientAllReducer: a parameter's .grad is no longer the bucket view; call arm() after zero_grad()")
-        self._got.add(id(p))
-        i = self._bucket_of[id(p)]
-        self._pending[i] -= 1
-        if self._pending[i] == 0 and self.overlap:
+        pid = id(p)
+        i = self._bucket_of[pid]
+        repeat = pid in self._got
+        unexpected = self._expected is not None and pid not in self._expected
+        self._got.add(pid)
+        if repeat or unexpected:
+            if self._inflight.get(i) is not None:
+                raise RuntimeError("GradientAllReducer(overlap=True): a gradient was accumulated into a bucket whose all-reduce is already in "
+                                   "flight (" + ("a second backward between arm() and finish()" if repeat else "a parameter the previous "
+                                   "steps' loss did not reach") + "); construct the reducer with overlap=False for gradient accumulation / "
+                                   "changing graphs")
+            self._cancelled = True
+            return
+        self._need[i].discard(pid)
+        if not self._need[i] and self.overlap and not self._cancelled:
             self._launch(i)
 
     def _launch(self, i):
@@ -118,10 +137,13 @@ class GradientAllReducer:
             if self.average and self.world > 1:
                 self.flat[i].div_(self.world)
         self._inflight = {}
-        if self._expected is None:
+        if self._expected is None and not self._cancelled:
             self._expected = set(self._got)
-        elif self._got != self._expected:
-            self._expected = None          # the graph changed (e.g. another loss): relearn next step, this step was still correct
+        elif self._cancelled or self._got != self._expected:
+            # the graph changed (another loss, accumulation): relearn on the next step.  This step is correct all the same: a bucket is
+            # only ever launched early when all of ITS expected gradients have landed once and nothing unexpected has fired before, and a
+            # gradient landing in an in-flight bucket raises in _on_grad
+            self._expected = None
         for p in self.params:
             if id(p) not in self._got:
                 p.grad = None

@@ -20,12 +20,10 @@ def make_optimizers(model, lr=1e-4, aux_lr=1e-3, fused=None):
 
 
 def _step(optimizer):
-    """optimizer.step(); torch's fused Adam updates the parameters WITHOUT bumping their version counters (checked on torch 2.10), and
-    the weight-pack caches of the modules are keyed by them (masic_amd/nn.py) -- bump them here, or the next forward would run on the
-    packs of the previous weights.  (A driver that steps a fused optimizer itself must do the same: `torch._C._increment_version(params)`.)"""
+    """optimizer.step().  torch's fused Adam updates the parameters WITHOUT bumping their version counters, which the weight-pack caches
+    are keyed by: masic_amd/fresh.py registers a global optimizer-step hook that bumps them for every fused / capturable group, whoever
+    calls step() -- nothing to do here, and nothing for a driver that steps its own optimizer."""
     optimizer.step()
-    if any(g.get("fused") for g in optimizer.param_groups):
-        torch._C._increment_version([p for g in optimizer.param_groups for p in g["params"]])
 
 
 _AUX_FUSED = os.environ.get("MASIC_AUX_FUSED", "1") != "0"      # 0: model.aux_loss().backward() through autograd (A/B timing)

@@ -87,6 +87,84 @@ def test_gradient_allreduce_world2_gloo_matches_full_batch(overlap):
     assert all(unused_none for _, _, unused_none in res)
 
 
+def _worker_graphs(rank, world, port, q):
+    """Changing graphs and gradient accumulation at world 2 (the cases a per-bucket COUNT of hook firings gets wrong: a second
+    backward, or a parameter outside the learnt set, would have launched a bucket while autograd was still accumulating into it)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _Net()
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    lo, hi = shard_range(8, rank, world)
+
+    def full(m, a, b):
+        return ((m(a) - b) ** 2).mean()
+
+    def partial(m, a, b):          # does not reach layer c
+        return (torch.relu(m.b(torch.relu(m.a(a)))) ** 2).mean()
+
+    def ref_grads(losses):
+        r = _Net()
+        r.load_state_dict(net.state_dict())
+        for f in losses:
+            f(r, x, y).backward()
+        return [None if p.grad is None else p.grad.clone() for p in r.parameters()]
+
+    def same(want):
+        return all((p.grad is None and w is None) or (p.grad is not None and w is not None and torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7))
+                   for p, w in zip(net.parameters(), want))
+
+    res = {}
+    red = GradientAllReducer(net, bucket_bytes=4096, overlap=True)
+    # graph changes from step to step: partial -> full (layer c fires outside the learnt set) -> partial -> full
+    ok = True
+    for f in (partial, full, partial, full, full):
+        net.zero_grad()
+        red.arm()
+        f(net, x[lo:hi], y[lo:hi]).backward()
+        red.finish()
+        ok = ok and same(ref_grads([f]))
+    res["changing_graph"] = ok
+    # a second backward under overlap: the first launched buckets, the second accumulates into them -> must raise, not race
+    net.zero_grad()
+    red.arm()
+    full(net, x[lo:hi], y[lo:hi]).backward()
+    try:
+        full(net, x[lo:hi], y[lo:hi]).backward()
+        res["second_backward_raises"] = False
+    except RuntimeError as e:
+        res["second_backward_raises"] = "in flight" in str(e)
+    red.finish()                      # drains the collectives both ranks launched
+    red.remove()
+    # gradient accumulation is what overlap=False is for
+    red2 = GradientAllReducer(net, bucket_bytes=4096, overlap=False)
+    net.zero_grad()
+    red2.arm()
+    full(net, x[lo:hi], y[lo:hi]).backward()
+    partial(net, x[lo:hi], y[lo:hi]).backward()
+    red2.finish()
+    res["accumulation_without_overlap"] = same(ref_grads([full, partial]))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_changing_graph_and_accumulation():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_graphs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert r == {"changing_graph": True, "second_backward_raises": True, "accumulation_without_overlap": True}, (rank, r)
+
+
 def test_reducer_single_process_is_identity():
     net = _Net()
     x = torch.randn(4, 6)
