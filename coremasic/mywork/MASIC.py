@@ -735,11 +735,17 @@ class HSIC(CompressionModel):
 
         m_fwd, m_back = warp_matrices if warp_matrices is not None else _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True)
         if not train:
-            if getattr(self, "eval_autograd", False) and torch.is_grad_enabled():
-                # the graph the reference records when CQE training runs HSIC in eval mode WITHOUT no_grad (newtrain_cqe_real.py:130,
-                # :160): round() has zero gradient, so only the two synthesis transforms (and the warp between them) carry any
+            if torch.is_grad_enabled():
+                # eval mode WITHOUT no_grad -- how the CQE driver calls the codec (newtrain_cqe_real.py:130, :160).  round() has zero
+                # gradient, so of the graph the reference records only the two synthesis transforms (and the warp between them) carry
+                # any: those are recorded as differentiable HIP nodes, the rest stays the fused inference schedule.  `eval_autograd`:
+                # None (default) -- record them iff a synthesis parameter requires grad (what the reference's graph would hold; a frozen
+                # HSIC, requires_grad_(False), costs nothing); True / False force it.  The likelihoods carry no graph in eval mode.
+                want = getattr(self, "eval_autograd", None)
+                if want is None:
+                    want = any(p.requires_grad for m in (self.decoder1, self.decoder2) for p in m.parameters())
                 with torch.no_grad():
-                    return self._forward_eval(x1, x2, m_fwd, m_back, synthesis_grad=True)
+                    return self._forward_eval(x1, x2, m_fwd, m_back, synthesis_grad=bool(want))
             return self._forward_eval(x1, x2, m_fwd, m_back)
 
         # ---- left view

@@ -89,7 +89,7 @@ def cqe_train_step(model, model2, optimizer, d1, d2, h_matrix, lmbda, reducer=No
     if reducer is not None:
         reducer.arm()
     if reference_graph:
-        prev = getattr(model, "eval_autograd", False)
+        prev = getattr(model, "eval_autograd", None)
         model.eval_autograd = True
         try:
             out_net = model(d1, d2, h_matrix)

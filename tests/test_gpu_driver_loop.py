@@ -322,8 +322,30 @@ def test_cqe_driver_loop_vs_reference_golden():
     print(f"driver loop (CQE stage): 86 gradients vs the reference, worst error / tolerance {worst[0]:.2f} ({worst[1]})")
     assert len(grads) == 86 and worst[0] <= 1.0, worst
     assert math.isfinite(aux_loss.item())
+    # what the reference's graph leaves behind in HSIC: gradients on the two synthesis transforms (round() blocks everything upstream),
+    # never stepped -- the product records the same (HSIC.forward, eval mode with grad enabled)
+    hs_worst, nd = [0.0, ""], 0
     for n, p in hsic.named_parameters():
         assert torch.equal(p.detach(), hsic_before[n]), n
+        if n.startswith(("decoder1.", "decoder2.")):
+            _check_grad(fx, "chain/hsic_grad/" + n, p.grad, hs_worst, "chain/hsic_f32_floor/" + n)
+            nd += 1
+        else:
+            assert p.grad is None, n
+    print(f"  gradients reaching HSIC's synthesis transforms: {nd}, worst error / tolerance {hs_worst[0]:.2f} ({hs_worst[1]})")
+    assert nd == 32 and hs_worst[0] <= 1.0, hs_worst
+    # a frozen codec (requires_grad_(False), the usual way to say so) records nothing and gives Independent_EN the same gradients
+    for p_ in hsic.parameters():
+        p_.requires_grad_(False)
+    net2.zero_grad()
+    grads2 = {}
+    hooks = [p.register_post_accumulate_grad_hook(lambda p, n=n: grads2.__setitem__(n, p.grad.detach().clone())) for n, p in net2.named_parameters()]
+    net3_out = net2(*(hsic(d1, d2, hm)[k] for k in ("x1_hat", "x2_hat")), hm)
+    assert hsic(d1, d2, hm)["x1_hat"].grad_fn is None
+    criterion(net3_out, d1, d2)["loss"].backward()
+    for h in hooks:
+        h.remove()
+    assert len(grads2) == 86
 
 
 # ---------------------------------------------------------------- stale packs are impossible
