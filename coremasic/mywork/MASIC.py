@@ -113,9 +113,23 @@ def _side_streams(device, n=4):
     0 the right view's branch, 1 the left view's entropy chain, 2-3 the side stacks of the entropy-parameter heads when those
     are issued from the main stream (compress / decompress)."""
     key = torch.device(device).index
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(n))
-    return _SIDE_STREAMS[key]
+    pool = _SIDE_STREAMS.get(key)
+    if pool is None:
+        # torch hands out Stream objects round-robin from a pool of 32 HIP streams per device: two Stream objects may BE the same HIP
+        # stream.  n + 1 pairwise different ones are kept, so that n remain when the caller's current stream (a stream of its own, e.g.
+        # the warm-up stream of a graph capture) happens to be one of them -- a side stream that is the current stream would make the
+        # forward wait for its own events (capture rule 3 of masic_amd/streams.py)
+        pool, seen = [], set()
+        for _ in range(64):
+            s = torch.cuda.Stream(device=device)
+            if s.cuda_stream not in seen:
+                seen.add(s.cuda_stream)
+                pool.append(s)
+            if len(pool) == n + 1:
+                break
+        pool = _SIDE_STREAMS[key] = tuple(pool)
+    cur = torch.cuda.current_stream(device).cuda_stream
+    return tuple(s for s in pool if s.cuda_stream != cur)[:n]
 
 
 def _keep_until(t, stream):
