@@ -2046,6 +2046,176 @@ __global__ __launch_bounds__(512, KC == 2 ? 2 : 1) void gemm_f16k(const GemmGrou
     }
 }
 
+
+// ---- gemm_f16k2: the same GEMMs with 128 co x 64 px per WAVE (8 accumulator tiles) and the activations NOT staged through LDS.
+// In gemm_f16k every wave owns all 128 output channels of only 32 pixels: each of its MFMAs needs a fresh weight fragment from LDS, so a
+// k-step is 5 ds_read_b128 for 4 MFMAs -- 320 LDS cycles against 256 MFMA cycles per CU and k-step: the kernel was bound by its LDS reads
+// (0.54 PFLOP/s alone), and a 32-channel chunk was only 8 MFMAs per wave and barrier.  Here:
+//   * a wave holds 4 (co) x 2 (px) tiles: 4 weight fragments feed 8 MFMAs;
+//   * its activation operand is a pixel's own F16K half-record -- 16 contiguous bytes per lane, 1 KiB per wave-instruction, nothing another
+//     wave of the workgroup needs (all four waves share the CO block, not the pixels): it is loaded straight into registers
+//     (buffer_load_dwordx4, one 64-channel chunk ahead), so LDS holds the weight ring only (3 x 16 KiB) and carries 4 reads per 8 MFMAs;
+//   * a chunk is 64 channels = 32 MFMAs per wave and barrier; workgroup = 4 waves = 128 co x 256 px, two workgroups per CU (independent
+//     barriers: one's prologue / epilogue under the other's K loop);
+//   * per-iteration issue order [8 activation loads of chunk c+1][4 weight DMA pieces of chunk c+2], then s_waitcnt vmcnt(4): the
+//     activations of the next chunk and the weights issued an iteration earlier have landed, the newest weight pieces stay in flight;
+//   * workgroup n runs on XCD n % 8 (hardware round-robin): image b = n % 8 (+ 8 per pass), so an image's activations are fetched into ONE
+//     XCD's L2, and inside an image the pixel tile is the fastest index: the workgroups resident together share few weight blocks.
+constexpr int G2_KC = 4, G2_STAGE = G2_KC * 4096, G2_NS = 3;
+template <int N>
+__device__ __forceinline__ void vm_wait(v4u& a, v4u& b, v4u& c, v4u& d, v4u& e, v4u& f, v4u& g, v4u& h) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void buf_load128(v4u& dst, unsigned voff, v4u rsrc, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void gemm_f16k2(const GemmGroupArgs ga, int B, int npx, int tiles_per_img) {
+    // workgroup -> (image, co-block over all groups, pixel tile): workgroup n runs on XCD n % 8 (hardware round-robin), image b = n % 8 (+ 8
+    // per pass), so an image's activations are fetched into ONE XCD's L2; inside an image the pixel tile is the fastest index.  Measured
+    // (PMC FETCH_SIZE x 2, the 768 -> 3 x 1152 layer at 8 x 32 x 32): 97 MB fetched per launch against 204 MB for gemm_f16k's blockIdx.y-major
+    // order (operands: 18 MB).  A 4 x 2 XCD grid (pixel quarter x co-block half, half of the weights resident per L2) fetched 109 MB and ran
+    // within 3 % of this order: the launch is not bound by its fabric traffic.
+    const int n = blockIdx.x, kx = n >> 3;
+    const int b = (n & 7) + 8 * (kx / tiles_per_img);
+    if (b >= B) return;
+    const int t = kx % tiles_per_img, pxt = t % npx, cbg = t / npx;
+    GemmF16kArgs a = ga.g[0];
+    int cb0 = 0;
+    if (ga.n > 1 && cbg >= ga.cb_end[0]) { a = ga.g[1]; cb0 = ga.cb_end[0]; }
+    if (ga.n > 2 && cbg >= ga.cb_end[1]) { a = ga.g[2]; cb0 = ga.cb_end[1]; }
+    const int cblk = cbg - cb0;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int p0 = pxt * 256, m0 = cblk * 128;
+    const int nchunks = a.nchunks;                                                 // 64-channel chunks (Cin padded to a multiple of 64 by the pack)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)cblk * nchunks * (G2_KC * 2048)), 0, nchunks * G2_STAGE, 0x00020000);
+    // activation descriptor by hand (inline-asm loads take it as four SGPRs): base, stride 0, bytes, the flags make_buffer_rsrc is given above
+    const unsigned long long xb = (unsigned long long)(a.x + (size_t)b * a.Cin16 * a.HW * 16);
+    v4u rx;
+    rx[0] = __builtin_amdgcn_readfirstlane((unsigned)xb);
+    rx[1] = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32) & 0xffffu);
+    rx[2] = __builtin_amdgcn_readfirstlane((unsigned)(a.Cin16 * a.HW * 32));
+    rx[3] = 0x00020000u;
+    unsigned bvoff[2];                                                             // the lane's half-record in k16 block 0, per pixel sub-tile
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = p0 + wave * 64 + q * 32 + j;
+        bvoff[q] = p < a.HW ? (unsigned)p * 32u + 16u * h : 0xC0000000u;
+    }
+    const unsigned kstride = (unsigned)a.HW * 32u;                                 // bytes between k16 blocks
+    auto issue_w = [&](int c) {                                                    // 16 KiB of weights: 4 pieces per wave
+        unsigned char* st = lds + (c % G2_NS) * G2_STAGE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma_buf16(rw, st + (k * 4 + wave) * 1024, lane * 16, c * G2_STAGE + (k * 4 + wave) * 1024);
+    };
+    v4u bq[2][G2_KC][2];                                                            // [parity][k16 of the chunk][pixel sub-tile]
+    auto issue_b = [&](auto PC, int c) {
+        constexpr int pc = decltype(PC)::value;
+        static_for<0, G2_KC>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(c * G2_KC + i) * kstride);
+            buf_load128(bq[pc][i][0], bvoff[0], rx, so);
+            buf_load128(bq[pc][i][1], bvoff[1], rx, so);
+        });
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][m][e] = 0.0f;
+    // prologue: activations of chunk 0, weights of chunks 0 and 1
+    issue_b(std::integral_constant<int, 0>{}, 0);
+    issue_w(0);
+    issue_w(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              // (the activation registers are claimed by the first body's wait below)
+    __builtin_amdgcn_s_barrier();
+    const unsigned al = ldsb + (h * 128 + j) * 16;
+    auto body = [&](auto PC, int c) {
+        constexpr int pc = decltype(PC)::value;
+        issue_b(std::integral_constant<int, pc ^ 1>{}, c + 1);                     // past the end: out of range, reads as zeros
+        issue_w(c + 2);
+        const unsigned wa = al + (c % G2_NS) * G2_STAGE;
+        v4u af[2][4];
+        static_for<0, 4>([&](auto M) { constexpr int m = decltype(M)::value; ds_read128<m * 512>(af[0][m], wa); });
+        static_for<0, G2_KC>([&](auto I) {
+            constexpr int i = decltype(I)::value, fb = i & 1;
+            if constexpr (i + 1 < G2_KC)
+                static_for<0, 4>([&](auto M) { constexpr int m = decltype(M)::value; ds_read128<(i + 1) * 4096 + m * 512>(af[fb ^ 1][m], wa); });
+            lgkm_wait<(i + 1 < G2_KC ? 4 : 0)>(af[fb][0], af[fb][1], af[fb][2], af[fb][3]);
+            static_for<0, 2>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[pc][i][q]);
+                static_for<0, 4>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[fb][m]), bv, acc[q][m], 0, 0, 0);
+                });
+            });
+        });
+        // chunk c+1: its activations (issued above, the 8 oldest of this iteration) and its weights (issued one iteration ago) have landed when at
+        // most the 4 newest weight pieces are still in flight
+        vm_wait<4>(bq[pc ^ 1][0][0], bq[pc ^ 1][0][1], bq[pc ^ 1][1][0], bq[pc ^ 1][1][1], bq[pc ^ 1][2][0], bq[pc ^ 1][2][1], bq[pc ^ 1][3][0], bq[pc ^ 1][3][1]);
+        __builtin_amdgcn_s_barrier();
+    };
+    {
+        // claim chunk 0's activation registers (their loads completed with the prologue's wait: they are older than the weight pieces)
+        vm_wait<4>(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1], bq[0][2][0], bq[0][2][1], bq[0][3][0], bq[0][3][1]);
+    }
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+        body(std::integral_constant<int, 0>{}, c);
+        body(std::integral_constant<int, 1>{}, c + 1);
+    }
+    if (c < nchunks) body(std::integral_constant<int, 0>{}, c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: bias + activation -> F16K or float32 NCHW view
+    if (a.bias != nullptr) {
+        const float* bp = a.bias + m0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m0 + m * 32 < a.Cout) {
+                float bv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[q][m][e] += bv[e];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][m][e] = apply_act(acc[q][m][e], a.act);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = p0 + wave * 64 + q * 32 + j;
+        if (p >= a.HW) continue;
+        if (a.y32 != nullptr) {
+            float* yb = a.y32 + ((size_t)b * a.out_ctot + a.out_coff + m0 + 4 * h) * a.HW + p;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (m0 + m * 32 < a.Cout) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) yb[(unsigned)(m * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)a.HW] = acc[q][m][e];
+                }
+        } else {
+            const int c16 = (a.out_coff + m0) >> 4;
+            unsigned short* yb = a.y16 + (((size_t)b * (a.out_ctot >> 4) + c16) * a.HW + p) * 16 + 8 * h;
+            const unsigned op16 = (unsigned)a.HW * 16;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[q][m], yb + (size_t)(2 * m) * op16, op16);
+        }
+    }
+}
+
 }  // namespace
 
 // Up to 18 weight packs in one launch (blockIdx.y = job): the nine 1x1 layers of an entropy-parameter head, each for the forward GEMM
@@ -2167,6 +2337,22 @@ extern "C" int masic_gemm_f16k_group_fwd(const masic_gemm_group_t* groups, int n
         (void)hipFuncSetAttribute((const void*)gemm_f16k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_f16k<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    static const bool v2 = !(getenv("MASIC_GEMM_V2") && getenv("MASIC_GEMM_V2")[0] == '0');      // 0: gemm_f16k (A/B timing)
+    if (!f8 && v2) {
+        bool ok = true;
+        for (int i = 0; i < ngroups; ++i) ok = ok && groups[i].y_f8k == nullptr;
+        if (ok) {
+            for (int i = 0; i < ngroups; ++i) ga.g[i].nchunks = round_up(groups[i].Cin / 16, 4) / G2_KC;
+            const int npx = ceil_div(HW, 256), tiles_per_img = npx * ncb;
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)gemm_f16k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+            }
+            hipLaunchKernelGGL(gemm_f16k2, dim3(8 * tiles_per_img * ceil_div(B, 8)), dim3(256), G2_NS * G2_STAGE, (hipStream_t)stream, ga, B, npx, tiles_per_img);
+            return masic_launch_status("gemm_f16k_fwd");
+        }
     }
     if (f8) hipLaunchKernelGGL((gemm_f16k<4, true>), grid, dim3(512), 3 * 4 * 12288, (hipStream_t)stream, ga);
     else if (kc2) hipLaunchKernelGGL(gemm_f16k<2>, grid, dim3(512), 3 * 2 * 12288, (hipStream_t)stream, ga);
