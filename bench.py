@@ -350,6 +350,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--no-cqe", action="store_true", help="skip the Independent_EN (CQE) forward / training-step extras")
     ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive timings (extras.with_upload)")
+    ap.add_argument("--no-trained", action="store_true", help="skip extras.accuracy_vs_ref_trained (trains HSIC for --trained-steps steps first)")
+    ap.add_argument("--trained-steps", type=int, default=1500)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "
@@ -763,6 +765,41 @@ def main():
                                "model.aux_loss().backward(), .item() reads of the log line at i % 10 == 0; tests/test_gpu_driver_loop.py checks this loop "
                                "against the reference's gradient goldens")
 
+    # ---- "bpp/PSNR vs ref" at a TRAINED operating point: HSIC from the reference's default init, trained here with the HIP step (no trained
+    # weights exist in this environment; masic_amd/trainrun.py), then the ORACLE against the f32 / bf16 / fp8 eval paths on a held-out pair
+    trained_info = None
+    if rank == 0 and world == 1 and not args.no_trained and not args.no_cpu_baseline:
+        from masic_amd import fp8 as _fp8, trainrun
+        from oracle import hsic_oracle as O            # checker leg: outside every timed region, never on the product path
+        t0 = time.perf_counter()
+        lam = 0.0932
+        pool = trainrun.batch_pool(16, 8, 256, 256, dev, seed=5000)
+        net_t = trainrun.default_init(device=dev)
+        tl, _, _ = trainrun.train(net_t, args.trained_steps, pool, lam, precision="bf16")
+        t_train = time.perf_counter() - t0
+        net_t.eval()
+        held = trainrun.consistent_pair(*(t.to(dev) for t in synth.synth_inputs(1, H, W, seed=9001)), seed=9001)
+        hx1, hx2, hhm = (t.cpu() for t in held)
+        sd_t = {k: v.detach().cpu().clone() for k, v in net_t.state_dict().items()}
+        torch.set_num_threads(host_cores())
+        with torch.no_grad():
+            ref_t = O.hsic_forward(sd_t, hx1, hx2, hhm, K=K, keep=True)
+        rc = O.rd_loss(ref_t, hx1, hx2, lam)
+        rsym = O.symbols(ref_t["_aux"], sd_t)
+        rb, rp1, rp2 = float(rc["bpp_loss"]), float(rc["psnr1"]), float(rc["psnr2"])
+        _fp8.calibrate(net_t, [trainrun.consistent_pair(*(t.to(dev) for t in synth.synth_inputs(2, H, W, seed=9002)), seed=9002)])
+        trained_info = {"state": f"HSIC(128,192,5) from the reference's default init (torch.manual_seed(0)), {args.trained_steps} steps of newtrain_codec_real.py:135-146 "
+                                 f"(Adam 1e-4 / aux 1e-3, lambda {lam}) with the HIP bf16-operand step on 8x3x256x256 band-limited synthetic pairs (right view = homography "
+                                 "warp of the left + noise), trained inside this run",
+                        "train_seconds": t_train, "loss_first": tl[0][0], "loss_last": tl[-1][0],
+                        "sample": f"held-out 1x3x{H}x{W} pair (synth seed 9001)",
+                        "oracle": {"bpp": rb, "psnr1": rp1, "psnr2": rp2, "y1_symbol_range": [int(rsym["y1"].min()), int(rsym["y1"].max())]}}
+        for mode in ("f32", "bf16", "fp8"):
+            c = trainrun.compare_to_reference(trainrun.evaluate(net_t, *held, lam, mode), rsym, rb, rp1, rp2)
+            trained_info[mode] = c
+        mnn.set_precision(args.precision)
+        del net_t, pool
+
     codec_info = None
     if rank == 0 and not args.no_codec:
         # the real bitstream of one pair: HSIC.compress / decompress on rank 0, outside every timed region above
@@ -815,6 +852,8 @@ def main():
             extras["accuracy_vs_f32"] = accuracy
         if accuracy_ref is not None:
             extras["accuracy_vs_ref"] = accuracy_ref
+        if trained_info is not None:
+            extras["accuracy_vs_ref_trained"] = trained_info
         if upload is not None:
             extras["with_upload"] = upload
         if cqe_info is not None:

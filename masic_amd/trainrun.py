@@ -20,8 +20,24 @@ from . import synth
 from .train import make_optimizers, train_step
 
 
-def batch_pool(n, B, H, W, device, seed=5000):
-    return [tuple(t.to(device) for t in synth.synth_inputs(B, H, W, seed=seed + i)) for i in range(n)]
+def consistent_pair(x1, x2, hm, noise=0.01, seed=0):
+    """Replaces the right view of a synthetic pair by what the homography says it is: x2 = clamp(warp(x1, h_matrix) + noise * N(0, 1), 0, 1)
+    (the library's own warp kernel; kornia's convention as the codec applies it, MASIC.py:781).  synth_inputs builds x2 from the integer
+    part of the translation only -- fine for parity tests, but a codec TRAINED on it learns that its cross-view path (x1 warped by a
+    homography that also carries +-2 % scale and shear terms, several pixels at 512 px) is unreliable, and the right view converges far
+    behind the left one.  Deterministic: the noise comes from a CPU generator seeded by `seed`."""
+    from . import ops
+    from .homography import warp_matrices
+    H, W = x1.shape[-2:]
+    m_fwd, _ = warp_matrices(hm, (H, W), (H, W))
+    g = torch.Generator().manual_seed(77000 + seed)
+    n = torch.randn(x1.shape, generator=g).to(x1.device)
+    return x1, (ops.warp_perspective(x1.contiguous(), m_fwd, (H, W)) + noise * n).clamp_(0.0, 1.0), hm
+
+
+def batch_pool(n, B, H, W, device, seed=5000, consistent=True):
+    pool = [tuple(t.to(device) for t in synth.synth_inputs(B, H, W, seed=seed + i)) for i in range(n)]
+    return [consistent_pair(*p, seed=seed + i) for i, p in enumerate(pool)] if consistent else pool
 
 
 def default_init(N=128, M=192, K=5, seed=0, device="cuda"):

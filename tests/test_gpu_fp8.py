@@ -16,7 +16,11 @@ from tests.util import assert_close
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# fp8-operand forward vs the CPU oracle, HSIC(128,192,5), bench weights: what the mode may cost
+# fp8-operand forward vs the CPU oracle, HSIC(128,192,5).  The budget the mode is HELD TO is declared where it means something -- at a trained
+# operating point, tests/test_gpu_convergence.py::TRAINED_BUDGET["fp8"]: rate within 1 %, PSNR within 0.15 dB, <= 2 % of the int32 symbols off
+# by at most one (measured: -0.08 % / -0.02 dB / 0.45 %).  The numbers below are the STRESS point of the parity tests -- synthetic random-gain
+# weights, latents spanning +-20, reconstructions at 5 dB, where a symbol sits within fp8 rounding of a boundary far more often (measured
+# 27 % of the symbols, by up to 2); they bound the kernels' behaviour there, they are not what the mode costs a codec.
 BUDGET = {"bpp_rel": 0.01, "psnr_db": 0.05, "symbol_mismatch": 0.35, "symbol_max_abs": 3}
 
 

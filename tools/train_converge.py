@@ -37,7 +37,7 @@ def main():
     from masic_amd import fp8, synth, trainrun
     dev = torch.device("cuda", 0)
     pool = trainrun.batch_pool(args.pool, args.batch, args.size, args.size, dev)
-    held = tuple(t.to(dev) for t in synth.synth_inputs(1, 512, 512, seed=9001))
+    held = trainrun.consistent_pair(*(t.to(dev) for t in synth.synth_inputs(1, 512, 512, seed=9001)), seed=9001)
     calib = [tuple(t.to(dev) for t in synth.synth_inputs(2, 512, 512, seed=9002))]
     report = {"args": vars(args), "modes": {}}
     for mode in args.modes.split(","):
