@@ -975,11 +975,16 @@ class HSIC(CompressionModel):
 
     def _left_params_fn(self, z1_hat, h, w):
         M = self.M
-        cat1 = torch.empty((1, 4 * M, h, w), dtype=torch.float32, device=z1_hat.device)      # params1 | ctx_params1
-        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0)
+        # (bf16 operands: the concat buffer is F16K, as in the eval forward -- the context model writes its slice as bf16 records and the
+        # grouped head GEMMs read the buffer directly: no conversion pass over the 768-channel buffer per coding step)
+        cat16 = self._cat_f16k(self._h_s1_same_resolution, z1_hat.new_empty((1, M, h, w)), 4 * M)
+        cat1 = None if cat16 is not None else torch.empty((1, 4 * M, h, w), dtype=torch.float32, device=z1_hat.device)      # params1 | ctx_params1
+        self._hyper_up(self.h_s1_up, z1_hat, cat1, 0, out16=cat16)
 
         def params(y_hat):
-            self._context(self.context_prediction1, y_hat, cat1, 2 * M)
+            self._context(self.context_prediction1, y_hat, cat1, 2 * M, out16=cat16)
+            if cat16 is not None:
+                return self._h_s1_same_resolution.heads((1, 4 * M, h, w), x16=cat16[0])
             return self._h_s1_same_resolution.heads(cat1)
         return params
 
@@ -989,13 +994,20 @@ class HSIC(CompressionModel):
         dev = z2_hat.device
         x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(1, H, W))
         gates = self.mask2weights_unit(x1_mask_R)
-        cat2 = torch.empty((1, 5 * M, h, w), dtype=torch.float32, device=dev)               # params2*g0 | ctx2*g1 | y1_warp_hat*g2
-        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0)
+        cat16 = self._cat_f16k(self._h_s2_same_resolution, z2_hat.new_empty((1, M, h, w)), 5 * M)
+        cat2 = None if cat16 is not None else torch.empty((1, 5 * M, h, w), dtype=torch.float32, device=dev)   # params2*g0 | ctx2*g1 | y1_warp_hat*g2
+        self._hyper_up(self.h_s2_up, z2_hat, cat2, 0, gate=gates, gate_c=0, out16=cat16)
         x1_hat_warp = _hip.warp_perspective(x1_hat, m_fwd, (H, W))
-        _hip.quantize(self.encoder1.latent(x1_hat_warp), "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
+        y1_warp = self.encoder1.latent(x1_hat_warp)
+        if cat16 is not None:
+            _hip.nchw_to_f16k_view(y1_warp, cat16[0], cat16[1], 4 * M, in_op=_hip.INOP_ROUND, gate=gates, gate_c=2)
+        else:
+            _hip.quantize(y1_warp, "dequantize", out=cat2, out_coff=4 * M, gate=gates, gate_c=2)
 
         def params(y_hat):
-            self._context(self.context_prediction2, y_hat, cat2, 2 * M, gates, 1)
+            self._context(self.context_prediction2, y_hat, cat2, 2 * M, gates, 1, out16=cat16)
+            if cat16 is not None:
+                return self._h_s2_same_resolution.heads((1, 5 * M, h, w), x16=cat16[0])
             return self._h_s2_same_resolution.heads(cat2)
         return params, x1_hat_warp
 
@@ -1060,8 +1072,7 @@ class HSIC(CompressionModel):
                 # state_dict(): the stream carries them, so any decoder holding the same weights rebuilds the same tables
                 f.write(np.array([len(fp8_table)], dtype=np.uint32).tobytes())
                 f.write(fp8_table)
-            for s_y in (s_y1, s_y2):
-                f.write(np.array([len(s_y)], dtype=np.uint32).tobytes())
+            for s_y in (s_y1, s_y2):        # each: u32 n, n x u32 lengths, the n channel streams (masic_amd/codec.py)
                 f.write(s_y)
         nbytes = os.path.getsize(out1) + os.path.getsize(out2)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,
@@ -1095,10 +1106,12 @@ class HSIC(CompressionModel):
                 fp8_table = f.read(n)
             elif head[4] == 2:
                 raise ValueError("HSIC.decompress: an fp8-mode stream without its activation-scale table")
+            rest = f.read()
             streams = []
             for _ in range(2):
-                n = int(np.frombuffer(f.read(4), dtype=np.uint32)[0])
-                streams.append(f.read(n))
+                _, used = codec.split_channels(rest)
+                streams.append(rest[:used])
+                rest = rest[used:]
         self._codec_check(1, H, W)
         h, w = H // 16, W // 16
         with torch.no_grad(), _fp8.stream_scales(self, fp8_table):

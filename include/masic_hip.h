@@ -579,6 +579,23 @@ int masic_gmm_cdf_rows(const float* sigma, const float* mu, const float* logits,
  * exist only once the previous wavefront is decoded: open, decode_rows per wavefront (symbols[r] = index of the interval
  * of row r that holds the coder's value), close. */
 int masic_rans_encode_freqs(const int32_t* start_freq, size_t n, uint8_t* out, size_t out_cap, size_t* out_len);
+/* One rANS stream per channel -- the form the device decoder below reads (container "MSR2", masic_amd/codec.py).  start_freq:
+ * [npix * nch][2], row i * nch + c = pixel i (coding order), channel c.  out: the nch streams back to back; lengths[c] bytes each
+ * (multiples of 4, >= 8).  Replaces the reference's one `range_coder` stream per view (MASIC.py:1046-1140), whose bytes are parity-unpinned. */
+int masic_rans_encode_channels(const int32_t* start_freq, int npix, int nch, uint8_t* out, size_t out_cap, uint32_t* lengths, size_t* out_len);
+/* Device side of the decoder's loop over coding steps (reference MASIC.py:1262-1408 runs it per symbol on the host):
+ * masic_gmm_cdf_rows_at = masic_gmm_cdf_rows (decoder's view) for the pixel list pix_all[*step][npix] (step: device int);
+ * masic_rans_decode_step decodes that step's symbols -- one wavefront per channel stream -- writes them into the latent
+ * y_hat [M][HW] (value = symbol - minmax at [chan[c]][pix]) and increments *step.  words / word_off / word_cnt: the channel streams
+ * as 32-bit little-endian words, first word and word count per channel; state / pos: per-channel coder state and next word index,
+ * caller-initialised (state = word0 | word1 << 32, pos = 2) and kept across steps; done: caller-zeroed device int.  err_flag bit 2:
+ * a stream ended early.  All pointers device memory; asynchronous on `stream`; capturable into a HIP graph. */
+int masic_gmm_cdf_rows_at(const float* sigma, const float* mu, const float* logits, int M, int K, int HW,
+                          const int32_t* pix_all, const int32_t* step, int npix, const int32_t* chan, int nch, int minmax, float scale_bound,
+                          uint16_t* starts, int32_t* err_flag, void* stream);
+int masic_rans_decode_step(const uint32_t* words, const uint32_t* word_off, const uint32_t* word_cnt, uint64_t* state, uint32_t* pos,
+                           const uint16_t* starts, const int32_t* pix_all, int32_t* step, int npix, const int32_t* chan, int nch,
+                           int L, int minmax, float* y_hat, int HW, int32_t* err_flag, int32_t* done, void* stream);
 int masic_rans_decoder_open(const uint8_t* in, size_t in_len, void** handle);
 int masic_rans_decoder_decode_rows(void* handle, const uint16_t* starts, int nrows, int L, int32_t* symbols);
 /* the next n symbols with tables picked by indexes (arguments as masic_rans_decode_with_indexes), keeping the coder state between

@@ -387,19 +387,27 @@ __device__ __forceinline__ void gdn_in_registers(f32x16 (&acc)[4], const unsigne
             nrm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, bh, nrm[m], 0, 0, 0);
         }
     }
-    // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway
+    // v_sqrt_f32 / v_rsq_f32 (1 ulp): the result is rounded to bf16 or feeds a bf16-operand convolution anyway.  `inverse` is uniform:
+    // a BRANCH, not a select -- as `inverse ? sqrt : rsq` the compiler evaluated both for every element (128 quarter-rate instructions
+    // and 64 selects per lane where 64 + 0 do)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 be = *reinterpret_cast<const float4*>(bet + m * 32 + 8 * q);
-            const float bq[4] = {be.x, be.y, be.z, be.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float nv = nrm[m][4 * q + i] + bq[i];
-                acc[m][4 * q + i] *= inverse ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
-            }
+            nrm[m][4 * q + 0] += be.x; nrm[m][4 * q + 1] += be.y; nrm[m][4 * q + 2] += be.z; nrm[m][4 * q + 3] += be.w;
         }
+    if (inverse) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_sqrtf(nrm[m][e]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] *= __builtin_amdgcn_rsqf(nrm[m][e]);
+    }
 }
 
 // KS 16-channel blocks per chunk, T taps per step, D weight-slab look-ahead (steps), PSP patch DMA wave-instructions per
@@ -2075,8 +2083,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16k2(const GemmGroupArgs ga, int
     // (PMC FETCH_SIZE x 2, the 768 -> 3 x 1152 layer at 8 x 32 x 32): 97 MB fetched per launch against 204 MB for gemm_f16k's blockIdx.y-major
     // order (operands: 18 MB).  A 4 x 2 XCD grid (pixel quarter x co-block half, half of the weights resident per L2) fetched 109 MB and ran
     // within 3 % of this order: the launch is not bound by its fabric traffic.
-    const int n = blockIdx.x, kx = n >> 3;
-    const int b = (n & 7) + 8 * (kx / tiles_per_img);
+    // (Fewer than 8 images -- the bitstream coder runs one: plain order, every workgroup live; the XCD order would park B of 8 XCDs' worth.)
+    const int n = blockIdx.x, kx = B >= 8 ? n >> 3 : n % tiles_per_img;
+    const int b = B >= 8 ? (n & 7) + 8 * ((n >> 3) / tiles_per_img) : n / tiles_per_img;
     if (b >= B) return;
     const int t = kx % tiles_per_img, pxt = t % npx, cbg = t / npx;
     GemmF16kArgs a = ga.g[0];
@@ -2350,7 +2359,7 @@ extern "C" int masic_gemm_f16k_group_fwd(const masic_gemm_group_t* groups, int n
                 (void)hipFuncSetAttribute((const void*)gemm_f16k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr2 = true;
             }
-            hipLaunchKernelGGL(gemm_f16k2, dim3(8 * tiles_per_img * ceil_div(B, 8)), dim3(256), G2_NS * G2_STAGE, (hipStream_t)stream, ga, B, npx, tiles_per_img);
+            hipLaunchKernelGGL(gemm_f16k2, dim3(B >= 8 ? 8 * tiles_per_img * ceil_div(B, 8) : B * tiles_per_img), dim3(256), G2_NS * G2_STAGE, (hipStream_t)stream, ga, B, npx, tiles_per_img);
             return masic_launch_status("gemm_f16k_fwd");
         }
     }

@@ -257,6 +257,33 @@ extern "C" int masic_rans_encode_freqs(const int32_t* start_freq, size_t n, uint
     return MASIC_OK;
 }
 
+// One rANS stream PER CHANNEL (the device decoder of codec.hip runs one wavefront per stream): start_freq is [npix * nch][2], row i * nch + c =
+// symbol of pixel i (coding order) and channel c.  out: the nch streams back to back, lengths[c] bytes each (multiples of 4, >= 8).
+extern "C" int masic_rans_encode_channels(const int32_t* start_freq, int npix, int nch, uint8_t* out, size_t out_cap, uint32_t* lengths, size_t* out_len) {
+    MASIC_REQUIRE(start_freq && out && lengths && out_len && npix >= 0 && nch >= 1, MASIC_ERR_ARG, "rans_encode_channels: bad argument");
+    std::vector<uint32_t> buf((size_t)npix + 2);
+    size_t total = 0;
+    for (int c = 0; c < nch; ++c) {
+        uint32_t* p = buf.data() + buf.size();
+        uint64_t x = kLow;
+        for (int k = npix; k-- > 0;) {
+            const int32_t st = start_freq[2 * ((size_t)k * nch + c)], fr = start_freq[2 * ((size_t)k * nch + c) + 1];
+            MASIC_REQUIRE(st >= 0 && fr >= 1 && st + fr <= (1 << kPrecision), MASIC_ERR_ARG, "rans_encode_channels: pixel %d channel %d has interval [%d, %d + %d)", k, c, st, st, fr);
+            put(x, p, (uint32_t)st, (uint32_t)fr);
+        }
+        p -= 2;
+        p[0] = (uint32_t)x;
+        p[1] = (uint32_t)(x >> 32);
+        const size_t nbytes = (size_t)(buf.data() + buf.size() - p) * sizeof(uint32_t);
+        MASIC_REQUIRE(total + nbytes <= out_cap, MASIC_ERR_SHAPE, "rans_encode_channels: output buffer of %zu bytes too small", out_cap);
+        memcpy(out + total, p, nbytes);
+        lengths[c] = (uint32_t)nbytes;
+        total += nbytes;
+    }
+    *out_len = total;
+    return MASIC_OK;
+}
+
 namespace {
 struct AdaptiveDecoder {
     std::vector<uint32_t> words;

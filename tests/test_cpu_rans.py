@@ -186,3 +186,32 @@ def test_gaussian_conditional_tables_vs_reference():
     assert gc2._quantized_cdf.numpy().tolist() == fx["gc/quantized_cdf"].tolist()
     gc2.update_scale_table([1.0, 2.0])                       # already initialised and not forced: unchanged (reference :497-499)
     assert gc2._quantized_cdf.shape == gc._quantized_cdf.shape
+
+
+def test_per_channel_streams_decode_with_the_host_decoder():
+    """masic_rans_encode_channels (container MSR2: one rANS stream per latent channel, what the device decoder reads): every channel's
+    stream, decoded with the host decoder over that channel's tables, gives back the channel's symbols; the framing splits exactly."""
+    from masic_amd import codec
+    rs = np.random.RandomState(11)
+    npix, nch, L = 97, 7, 21
+    starts = np.zeros((npix * nch, L), dtype=np.int64)
+    sym = np.zeros(npix * nch, dtype=np.int64)
+    sf = np.zeros((npix * nch, 2), dtype=np.int32)
+    for r in range(npix * nch):
+        f = rs.randint(1, 200, size=L).astype(np.int64)
+        f[rs.randint(L)] += 65536 - f.sum()
+        assert f.min() >= 1 and f.sum() == 65536
+        starts[r] = np.concatenate([[0], np.cumsum(f)[:-1]])
+        sym[r] = rs.randint(L)
+        sf[r] = (starts[r, sym[r]], f[sym[r]])
+    blob = codec.encode_channels(sf, npix, nch) + b"tail"
+    streams, used = codec.split_channels(blob)
+    assert used == len(blob) - 4 and len(streams) == nch and all(len(s) >= 8 and len(s) % 4 == 0 for s in streams)
+    for c, data in enumerate(streams):
+        rows = np.arange(npix) * nch + c
+        dec = codec.AdaptiveDecoder(data)
+        got = dec.decode_rows(starts[rows].astype(np.uint16))
+        dec.close()
+        assert np.array_equal(got, sym[rows]), c
+    empty, used = codec.split_channels(codec.encode_channels(np.zeros((0, 2), dtype=np.int32), 0, 0))
+    assert empty == [] and used == 4

@@ -555,3 +555,45 @@ def test_independent_en_bf16_path_at_baseline_sizes(B, H, W):
     for k in ("x1_hat", "x2_hat"):
         e = assert_close(out[k], ref[k], f"cqe bf16 vs float32 path at {H}x{W}:" + k, 2e-2)
         print(f"Independent_EN bf16 path at {B}x{H}x{W}, {k}: {e:.2e} from the float32 path")
+
+
+def test_cqe_backward_at_config3_picture_size_vs_oracle_autograd():
+    """BASELINE configs[2]'s picture size, 1 x 3 x 512 x 896 (newtrain_cqe_real.py shape): Independent_EN train-mode forward + distortion
+    criterion + backward on the HIP float32 path against torch autograd over the CPU oracle -- all 86 parameter gradients and both input
+    gradients.  This is where the backward's large-layer kernel set runs at its own size (full-resolution 3x3 weight gradients over 458 752
+    pixels, the homography-warp backward, the 96-channel input gradients); the reference-generated goldens (cqe_train.npz) are 32 x 48.
+    Tolerance 3e-4 of each tensor's largest magnitude: a weight gradient here is a float32 sum over 4.6e5 pixels, and the reference's own
+    float32 arithmetic is already 1.7e-4 from a float64 evaluation on the small golden (the fixture's f32_floor entries)."""
+    from masic_amd import synth
+    from masic_amd.loss import distortion
+    net, sd = _en(17)
+    net.train()
+    xa, xb, hm = synth.synth_inputs(1, 512, 896, seed=17)
+    d1, d2, _ = synth.synth_inputs(1, 512, 896, seed=18)
+    lm = 0.01
+    # CPU: oracle + autograd
+    psd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    ra, rb = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    ref = O.independent_en_forward(psd, ra, rb, hm)
+    mse = torch.nn.functional.mse_loss(ref["x1_hat"], d1) + torch.nn.functional.mse_loss(ref["x2_hat"], d2)
+    rloss = lm * 255 ** 2 * mse
+    rloss.backward()
+    # HIP
+    ga, gb = xa.to(DEV).requires_grad_(True), xb.to(DEV).requires_grad_(True)
+    out = net(ga, gb, hm.to(DEV))
+    crit = distortion(out, d1.to(DEV), d2.to(DEV), lm)
+    crit["loss"].backward()
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out[k], ref[k].detach(), "cqe 512x896 train:" + k)
+    assert abs(float(crit["loss"]) - float(rloss)) <= 1e-4 * abs(float(rloss))
+    worst, wname, n = 0.0, "", 0
+    for name, p in net.named_parameters():
+        r = psd[name].grad
+        assert p.grad is not None and r is not None, name
+        e = float((p.grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-30)
+        n += 1
+        if e > worst:
+            worst, wname = e, name
+    ein = max(float((g.grad.cpu() - r.grad).abs().max()) / float(r.grad.abs().max()) for g, r in ((ga, ra), (gb, rb)))
+    print(f"Independent_EN backward at 1x3x512x896: {n} parameter gradients vs oracle autograd, worst {worst:.2e} ({wname}); input gradients {ein:.2e}")
+    assert n == 86 and worst <= 3e-4 and ein <= 3e-4, (n, worst, wname, ein)
