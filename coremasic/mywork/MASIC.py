@@ -973,6 +973,65 @@ class HSIC(CompressionModel):
         if B != 1:
             raise ValueError("HSIC.compress/decompress code one stereo pair per call (the reference codes batch element 0 only)")
 
+    class _PixelParams:
+        """The entropy parameters of a view for the bitstream coder.  Callable: y_hat -> (sigma, mu, logits) over the full latent (the
+        float32 / fp8 form, and the fallback).  With bf16 operands (`skinny`): the same layers evaluated on a LIST OF PIXELS by the kernels
+        of masic_amd/csrc/skinny.hip -- `run(pix, step, list_stride, npix)` reads the latent from `y16` (F16K; the device decoder writes it,
+        the encoder fills it with `set_latent`) and writes `sigma`, `mu`, `logits` ([1, K*M, h, w] float32) at those pixels.  Encoder (all
+        pixels in one launch per layer) and decoder (one coding wavefront per launch) run the same kernels with the same k order, and a
+        pixel's result does not depend on its tile mates: bit-identical parameters on both sides."""
+
+        def __init__(self, full, skinny=None):
+            self._full, self._sk = full, skinny
+            self.skinny = skinny is not None
+            if self.skinny:
+                self.y16, self.sigma, self.mu, self.logits = skinny["y16"], skinny["sigma"], skinny["mu"], skinny["logits"]
+
+        def __call__(self, y_hat):
+            return self._full(y_hat)
+
+        def set_latent(self, y_hat):
+            _hip.nchw_to_f16k_view(y_hat.contiguous(), self.y16, self._sk["M16"], 0)
+
+        def run(self, pix, step, list_stride, npix):
+            k = self._sk
+            _hip.skinny_group([k["ctx"]], pix, step, list_stride, npix, k["h"], k["w"], ctx=True, gate=k["gate"], gate_c=1)
+            for layers in k["heads"]:
+                _hip.skinny_group(layers, pix, step, list_stride, npix, k["h"], k["w"])
+
+    def _skinny_params(self, head, ctx, cat16, C, h, w, gate=None):
+        """Buffers and layer descriptions of _PixelParams' pixel-list form, or None when it does not apply (float32 / fp8 operands, widths
+        the kernels are not built for; MASIC_CODEC_SKINNY=0)."""
+        import os
+        from masic_amd import nn as _mnn
+        M, K = self.M, self.K
+        if (cat16 is None or os.environ.get("MASIC_CODEC_SKINNY", "1") == "0" or M % 16 or (2 * M) % 32 or not head._grouped_heads_ok()
+                or ctx.kernel_size != (5, 5)):
+            return None
+        dev = cat16[0].device
+        ctx.zero_masked_taps()
+        wpc = _mnn._cached(ctx, "_packed_skinny_cache", _mnn.weight_key(ctx.weight), (), lambda: _hip.pack_skinny_ctx_weight(ctx.weight.detach()))
+        M16 = (M + 15) // 16 * 16
+        y16 = torch.zeros(M16 * h * w, dtype=torch.int16, device=dev)
+        outs = [torch.empty((1, K * M, h, w), dtype=torch.float32, device=dev) for _ in range(3)]
+        heads, t = [], [cat16[0]] * 3
+        for i in range(3):
+            layers, nxt = [], []
+            for k_, (name, tag, acts) in enumerate(head._STACKS):
+                layer = getattr(head, name)[2 * i]
+                L = dict(x=t[k_], wp=layer.packed_gemm_dma_weight(), bias=layer.bias.detach(), Cin=layer.in_channels, Cout=layer.out_channels, act=acts[i])
+                if i == 2:
+                    L["y32"], L["out_ctot"] = outs[k_], layer.out_channels
+                else:
+                    L["out_ctot"] = (layer.out_channels + 15) // 16 * 16
+                    L["y16"] = torch.zeros(L["out_ctot"] * h * w, dtype=torch.int16, device=dev)
+                    nxt.append(L["y16"])
+                layers.append(L)
+            heads.append(layers)
+            t = nxt
+        ctxl = dict(x=y16, wp=wpc, bias=None if ctx.bias is None else ctx.bias.detach(), Cin=M16, Cout=2 * M, act=_NONE, y16=cat16[0], out_ctot=C, out_coff=2 * M)
+        return dict(y16=y16, M16=M16, sigma=outs[0], mu=outs[1], logits=outs[2], ctx=ctxl, heads=heads, h=h, w=w, gate=gate)
+
     def _left_params_fn(self, z1_hat, h, w):
         M = self.M
         # (bf16 operands: the concat buffer is F16K, as in the eval forward -- the context model writes its slice as bf16 records and the
@@ -986,7 +1045,7 @@ class HSIC(CompressionModel):
             if cat16 is not None:
                 return self._h_s1_same_resolution.heads((1, 4 * M, h, w), x16=cat16[0])
             return self._h_s1_same_resolution.heads(cat1)
-        return params
+        return HSIC._PixelParams(params, self._skinny_params(self._h_s1_same_resolution, self.context_prediction1, cat16, 4 * M, h, w))
 
     def _right_params_fn(self, z2_hat, x1_hat, m_fwd, m_back, H, W, h, w):
         """-> (params_fn, x1_hat_warp): everything of the right view's tables that the decoder knows before y2."""
@@ -1009,7 +1068,8 @@ class HSIC(CompressionModel):
             if cat16 is not None:
                 return self._h_s2_same_resolution.heads((1, 5 * M, h, w), x16=cat16[0])
             return self._h_s2_same_resolution.heads(cat2)
-        return params, x1_hat_warp
+        sk = self._skinny_params(self._h_s2_same_resolution, self.context_prediction2, cat16, 5 * M, h, w, gate=gates.contiguous())
+        return HSIC._PixelParams(params, sk), x1_hat_warp
 
     @staticmethod
     def _channel_flags(y_hat):

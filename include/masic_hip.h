@@ -588,14 +588,25 @@ int masic_rans_encode_channels(const int32_t* start_freq, int npix, int nch, uin
  * masic_rans_decode_step decodes that step's symbols -- one wavefront per channel stream -- writes them into the latent
  * y_hat [M][HW] (value = symbol - minmax at [chan[c]][pix]) and increments *step.  words / word_off / word_cnt: the channel streams
  * as 32-bit little-endian words, first word and word count per channel; state / pos: per-channel coder state and next word index,
- * caller-initialised (state = word0 | word1 << 32, pos = 2) and kept across steps; done: caller-zeroed device int.  err_flag bit 2:
- * a stream ended early.  All pointers device memory; asynchronous on `stream`; capturable into a HIP graph. */
+ * caller-initialised (state = word0 | word1 << 32, pos = 2) and kept across steps; done: caller-zeroed device int; y_f16k (nullable):
+ * the latent also as F16K bf16 [ceil16(M) / 16][HW][16].  err_flag bit 2: a stream ended early.  All pointers device memory; asynchronous on `stream`; capturable into a HIP graph. */
+/* The entropy-parameter layers on a short pixel list (masic_amd/csrc/skinny.hip): up to three 1x1 layers (groups as in
+ * masic_gemm_f16k_group_fwd, bf16 operands, w_packed from masic_gemm_f16k_pack_weight) or, with ctx != 0, ONE 5x5 type-A masked
+ * convolution (w_packed from masic_skinny_ctx_pack_weight; latent h x w) evaluated at the pixels pix[(*step) * list_stride + i], i < npix
+ * (step: device int or NULL), of one image.  x and the outputs are FULL-SIZE buffers (h * w pixels): only the listed pixels are
+ * written.  gate (nullable): float32 [.][h * w], plane gate_c multiplies the result after the activation.  A pixel's result does not
+ * depend on which other pixels are in the list: the encoder (all pixels, one launch) and the decoder (one coding wavefront per
+ * launch) get bit-identical parameters.  Replaces the per-symbol crop + Conv2d calls of MASIC.py:986-1003 / :1262-1280. */
+size_t masic_skinny_ctx_packed_bytes(int Cin, int Cout);
+int masic_skinny_ctx_pack_weight(const float* w, void* w_packed, int Cin, int Cout, void* stream);
+int masic_skinny_group_fwd(const masic_gemm_group_t* groups, int ngroups, int ctx, const int32_t* pix, const int32_t* step, int list_stride,
+                           int npix, int h, int w, const float* gate, int gate_c, void* stream);
 int masic_gmm_cdf_rows_at(const float* sigma, const float* mu, const float* logits, int M, int K, int HW,
                           const int32_t* pix_all, const int32_t* step, int npix, const int32_t* chan, int nch, int minmax, float scale_bound,
                           uint16_t* starts, int32_t* err_flag, void* stream);
 int masic_rans_decode_step(const uint32_t* words, const uint32_t* word_off, const uint32_t* word_cnt, uint64_t* state, uint32_t* pos,
                            const uint16_t* starts, const int32_t* pix_all, int32_t* step, int npix, const int32_t* chan, int nch,
-                           int L, int minmax, float* y_hat, int HW, int32_t* err_flag, int32_t* done, void* stream);
+                           int L, int minmax, float* y_hat, void* y_f16k, int HW, int32_t* err_flag, int32_t* done, void* stream);
 int masic_rans_decoder_open(const uint8_t* in, size_t in_len, void** handle);
 int masic_rans_decoder_decode_rows(void* handle, const uint16_t* starts, int nrows, int L, int32_t* symbols);
 /* the next n symbols with tables picked by indexes (arguments as masic_rans_decode_with_indexes), keeping the coder state between

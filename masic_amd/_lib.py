@@ -70,9 +70,12 @@ SIGNATURES = {
     "masic_pair_prep": (c_int, [_P] + [c_int] * 6 + [_P] + [c_int] * 4 + [_P, _P]),
     "masic_gmm_cdf_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "masic_rans_encode_freqs": (c_int, [_P, c_size_t, _P, c_size_t, _P]),
+    "masic_skinny_ctx_packed_bytes": (c_size_t, [c_int, c_int]),
+    "masic_skinny_ctx_pack_weight": (c_int, [_P, _P, c_int, c_int, _P]),
+    "masic_skinny_group_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "masic_rans_encode_channels": (c_int, [_P, c_int, c_int, _P, c_size_t, _P, _P]),
     "masic_gmm_cdf_rows_at": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P]),
-    "masic_rans_decode_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "masic_rans_decode_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
     "masic_rans_decoder_open": (c_int, [_P, c_size_t, _P]),
     "masic_rans_decoder_decode_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "masic_rans_decoder_close": (None, [_P]),

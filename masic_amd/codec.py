@@ -138,8 +138,13 @@ def encode_view(params_fn, y_hat, M, K, chan, minmax, scale_bound):
     h, w = y_hat.shape[-2:]
     if chan.numel() == 0:
         return encode_channels(np.zeros((0, 2), dtype=np.int32), 0, 0)
-    sigma, mu, logits = params_fn(y_hat)
     pix = torch.from_numpy(np.concatenate(wavefront_steps(h, w))).to(y_hat.device)
+    if getattr(params_fn, "skinny", False):           # the decoder's own kernels, on all pixels at once (bit-identical parameters)
+        params_fn.set_latent(y_hat)
+        params_fn.run(pix, None, 0, pix.numel())
+        sigma, mu, logits = params_fn.sigma, params_fn.mu, params_fn.logits
+    else:
+        sigma, mu, logits = params_fn(y_hat)
     _, sf, err = gmm_tables(sigma, mu, logits, M, K, pix, chan, minmax, scale_bound, y_hat=y_hat, want_starts=False)
     check_err(err, "encode")
     return encode_channels(sf.cpu().numpy(), pix.numel(), chan.numel())
@@ -177,8 +182,15 @@ def decode_view(params_fn, data, shape, M, K, chan, minmax, scale_bound, device,
     err = torch.zeros(1, dtype=torch.int32, device=device)
     starts = torch.empty((h * nch, L), dtype=torch.int16, device=device)
 
+    skinny = getattr(params_fn, "skinny", False)
+    y16 = params_fn.y16 if skinny else None
+
     def device_step():
-        sigma, mu, logits = params_fn(y_hat)
+        if skinny:                                            # the step's <= h pixels only (masic_amd/csrc/skinny.hip)
+            params_fn.run(pix_d, step_d, h, h)
+            sigma, mu, logits = params_fn.sigma, params_fn.mu, params_fn.logits
+        else:
+            sigma, mu, logits = params_fn(y_hat)
         for t in (sigma, mu, logits):
             if not (t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == (1, K * M, h, w)):
                 raise RuntimeError("masic_amd.codec: head outputs must be contiguous float32 [1, K*M, h, w] device tensors")
@@ -186,10 +198,12 @@ def decode_view(params_fn, data, shape, M, K, chan, minmax, scale_bound, device,
         check(lib.masic_gmm_cdf_rows_at(_p(sigma), _p(mu), _p(logits), M, K, h * w, _p(pix_d), _p(step_d), h, _p(chan), nch, int(minmax),
                                         float(scale_bound), _p(starts), _p(err), st), "gmm_cdf_rows_at")
         check(lib.masic_rans_decode_step(_p(words_d), _p(off_d), _p(cnt_d), _p(state_d), _p(pos_d), _p(starts), _p(pix_d), _p(step_d), h, _p(chan), nch,
-                                         L, int(minmax), _p(y_hat), h * w, _p(err), _p(done_d), st), "rans_decode_step")
+                                         L, int(minmax), _p(y_hat), _p(y16) if y16 is not None else None, h * w, _p(err), _p(done_d), st), "rans_decode_step")
 
     def reset():
         y_hat.zero_()
+        if y16 is not None:
+            y16.zero_()
         state_d.copy_(state_init)
         pos_d.fill_(2)
         step_d.zero_()

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void rans_decode_step_kernel(const unsigned* __
                                                               const unsigned short* __restrict__ starts, const int* __restrict__ pix_all,
                                                               int* __restrict__ step, int npix, const int* __restrict__ chan, int nch, int L,
                                                               int minmax, float* __restrict__ y_hat, int HW, const unsigned* __restrict__ word_cnt,
-                                                              int* __restrict__ err, int* __restrict__ done) {
+                                                              int* __restrict__ err, int* __restrict__ done, unsigned short* __restrict__ y16) {
     const int c = blockIdx.x, lane = threadIdx.x;
     const int st = *step;
     const int* pix = pix_all + (size_t)st * npix;
@@ -184,7 +184,10 @@ __global__ __launch_bounds__(64) void rans_decode_step_kernel(const unsigned* __
                 w0 = w1;
                 w1 = pp + 1 < wn ? w[pp + 1] : 0u;
             }
-            if (lane == 0) y_hat[(size_t)m * HW + pr[i]] = (float)(s - minmax);
+            if (lane == 0) {
+                y_hat[(size_t)m * HW + pr[i]] = (float)(s - minmax);
+                if (y16 != nullptr) { const __bf16 bv = (__bf16)(float)(s - minmax); y16[((size_t)(m >> 4) * HW + pr[i]) * 16 + (m & 15)] = __builtin_bit_cast(unsigned short, bv); }
+            }
         }
         if (lane == 0) {
             state[c] = x;
@@ -219,7 +222,10 @@ __global__ __launch_bounds__(64) void rans_decode_step_kernel(const unsigned* __
                 x = (x << 32) | (pp < wn ? w[pp] : 0u);
                 ++pp;
             }
-            if (lane == 0) y_hat[(size_t)m * HW + p] = (float)(s - minmax);
+            if (lane == 0) {
+                y_hat[(size_t)m * HW + p] = (float)(s - minmax);
+                if (y16 != nullptr) { const __bf16 bv = (__bf16)(float)(s - minmax); y16[((size_t)(m >> 4) * HW + p) * 16 + (m & 15)] = __builtin_bit_cast(unsigned short, bv); }
+            }
         }
         if (lane == 0) {
             state[c] = x;
@@ -244,16 +250,17 @@ __global__ __launch_bounds__(64) void rans_decode_step_kernel(const unsigned* __
 // its symbols into the latent and increments *step.  words: all channel streams back to back as little-endian 32-bit words; word_off[c] /
 // word_cnt[c]: first word and number of words of channel c's stream; state[c] / pos[c]: coder state (initialised from the stream's first two
 // words) and next word index (2) -- caller-initialised, kept between steps; pix_all: [nsteps][npix] pixel lists (-1 = padding);
-// done: caller-zeroed int.  err_flag bit 2: a stream ended early.
+// done: caller-zeroed int.  err_flag bit 2: a stream ended early.  y_f16k (nullable): the latent also as F16K bf16 [ceil16(M) / 16][HW][16]
+// (exact for |value| <= 256) -- the input layout of the context model's kernels.
 extern "C" int masic_rans_decode_step(const uint32_t* words, const uint32_t* word_off, const uint32_t* word_cnt, uint64_t* state, uint32_t* pos,
                                       const uint16_t* starts, const int32_t* pix_all, int32_t* step, int npix, const int32_t* chan, int nch,
-                                      int L, int minmax, float* y_hat, int HW, int32_t* err_flag, int32_t* done, void* stream) {
+                                      int L, int minmax, float* y_hat, void* y_f16k, int HW, int32_t* err_flag, int32_t* done, void* stream) {
     MASIC_REQUIRE(words && word_off && word_cnt && state && pos && starts && pix_all && step && chan && y_hat && err_flag && done, MASIC_ERR_ARG,
                   "rans_decode_step: null pointer");
     MASIC_REQUIRE(npix >= 1 && nch >= 1 && L >= 1 && L <= CDF_MAX_L && L == 2 * minmax + 1, MASIC_ERR_SHAPE, "rans_decode_step: bad shape");
     hipLaunchKernelGGL(rans_decode_step_kernel, dim3(nch), dim3(64), 0, (hipStream_t)stream, (const unsigned*)words, (const unsigned*)word_off,
                        (unsigned long long*)state, (unsigned*)pos, (const unsigned short*)starts, (const int*)pix_all, (int*)step, npix,
-                       (const int*)chan, nch, L, minmax, y_hat, HW, (const unsigned*)word_cnt, (int*)err_flag, (int*)done);
+                       (const int*)chan, nch, L, minmax, y_hat, HW, (const unsigned*)word_cnt, (int*)err_flag, (int*)done, (unsigned short*)y_f16k);
     return masic_launch_status("rans_decode_step");
 }
 

@@ -570,6 +570,25 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
             for (int k = 0; k < NPI; ++k)
                 dma_buf16(rx, lds + (pdst[k] >= 0 ? PATCH0 + l * a.PB + pdst[k] : dummy_off), goff[k], l * (KS * plane_bytes));
     }
+    // the accumulators start at the bias (its 16 ... 64 scalar loads per lane fly with the prologue's DMA) instead of at zero with 64 adds
+    // behind a round trip to global memory in the epilogue; fp8 operands keep the add there (the dequantisation scale comes first)
+    if constexpr (!F8) {
+        if (a.bias != nullptr) {
+            const float* bp = a.bias + (blockIdx.y / a.msplit) * 128 + msub * 32 + 4 * h;
+            const int m0i = (blockIdx.y / a.msplit) * 128 + msub * 32;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                if (m0i + m * 32 < a.Cout) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float bv = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+                        for (int n = 0; n < NP; ++n) acc[n][m][e] = bv;
+                    }
+                }
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -744,27 +763,32 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
             }
         }
     }
-    if (a.bias != nullptr) {
-        const float* bp = a.bias + m0 + 4 * h;
+    if constexpr (F8) {
+        if (a.bias != nullptr) {
+            const float* bp = a.bias + m0 + 4 * h;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            if (m0 + m * 32 < a.Cout) {
-                float bv[16];
+            for (int m = 0; m < NM; ++m) {
+                if (m0 + m * 32 < a.Cout) {
+                    float bv[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+                    for (int e = 0; e < 16; ++e) bv[e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
 #pragma unroll
-                for (int n = 0; n < NP; ++n)
+                    for (int n = 0; n < NP; ++n)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[n][m][e] += bv[e];
+                        for (int e = 0; e < 16; ++e) acc[n][m][e] += bv[e];
+                }
             }
         }
     }
     if constexpr (GDN && F16K_ABLATE != 10) {
-        // The 64 KiB fragment image (+ beta^) is shared by the 8 waves through LDS (ring and patch buffers are free now): one
-        // DMA, one barrier.
+        // The fragment image (+ beta^) is shared by the 8 waves through LDS (ring and patch buffers are free now): one DMA, one barrier.
+        // Piece p = (m * 8 + k-step) * 2 + plane: the odd pieces are the low halves of the three-product split -- the one-product form
+        // (the default) leaves them where they are: 32 KiB per workgroup instead of 64
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gdn_img, 0, 65536 + 512, 0x00020000);
+        const bool x3 = (a.gdn_inverse & 2) != 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
+        for (int k = 0; k < 8; ++k)
+            if (x3 || (k & 1) == 0) dma_buf16(rg, lds + (wave * 8 + k) * 1024, lane * 16, (wave * 8 + k) * 1024);
         if (wave == 0) dma_buf16(rg, lds + 65536, lane * 16, 65536);          // 512 bytes of beta^; lanes >= 32 read past the end: zeros
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

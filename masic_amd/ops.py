@@ -1087,6 +1087,31 @@ def gemm_f16k_group(layers, B, H, W):
     return outs
 
 
+def pack_skinny_ctx_weight(weight):
+    """Fragment pack of a 5x5 type-A masked convolution's weight [Cout, Cin, 5, 5] (masked taps zero) for skinny_group(ctx=True)."""
+    _dev(weight, "weight")
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (5, 5):
+        raise RuntimeError("masic_amd.pack_skinny_ctx_weight: 5x5 kernels only")
+    out = torch.empty(lib.masic_skinny_ctx_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    check(lib.masic_skinny_ctx_pack_weight(_p(weight.contiguous()), _p(out), Cin, Cout, _stream()), "skinny_ctx_pack_weight")
+    return out
+
+
+def skinny_group(layers, pix, step, list_stride, npix, h, w, ctx=False, gate=None, gate_c=0):
+    """masic_skinny_group_fwd: up to three 1x1 layers (or one masked 5x5 convolution, ctx=True) on the pixels pix[step * list_stride + i],
+    i < npix, of one image.  layers: dicts with x (F16K), wp, bias, Cin, Cout, act, out_ctot, out_coff and the FULL-SIZE output buffer
+    y16 (F16K) or y32 (float32 [out_ctot, h, w]); pix / step: int32 device tensors (step may be None)."""
+    arr = (_lib.GemmGroup * len(layers))()
+    for g, L in zip(arr, layers):
+        g.x, g.w_packed, g.wscale, g.bias = _p(L["x"]), _p(L["wp"]), None, _p(L["bias"])
+        g.y_f16k, g.y_f8k, g.y_nchw = _p(L.get("y16")), None, _p(L.get("y32"))
+        g.out_inv_scale = 0.0
+        g.Cin, g.Cout, g.out_ctot, g.out_coff, g.act = L["Cin"], L["Cout"], L["out_ctot"], L.get("out_coff", 0), int(L["act"])
+    check(lib.masic_skinny_group_fwd(arr, len(layers), 1 if ctx else 0, _p(pix), _p(step), int(list_stride), int(npix), int(h), int(w),
+                                     _p(gate), int(gate_c), _stream()), "skinny_group_fwd")
+
+
 # --------------------------------------------------------------------------------------------- fp8 operand path (F8K)
 def f8k_to_nchw(y8, B, C, H, W, scale):
     """F8K uint8 buffer -> float32 NCHW (torch ops; tests only)."""
