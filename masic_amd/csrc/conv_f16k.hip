@@ -156,6 +156,7 @@ __device__ __forceinline__ void store_f16k_tile(const f32x16& t, unsigned short*
 // the same through a buffer resource: voff = byte offset of the lane's pixel in the first record + 16h, or any offset >= the resource's
 // size for a lane that has nothing to store (dropped by the range check) -- the instruction is issued unconditionally, so the number
 // of store instructions a wave has in flight is known at compile time (counted s_waitcnt vmcnt in conv_a_gdn_f16k)
+template <int AUX = 0>
 __device__ __forceinline__ void store_f16k_tile_buf(const f32x16& t, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned rec_stride_bytes) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -164,7 +165,7 @@ __device__ __forceinline__ void store_f16k_tile_buf(const f32x16& t, __amdgpu_bu
         const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         v4u st = {s0[0], s1[0], s0[1], s1[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(st, rs, (int)(voff + r * rec_stride_bytes), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs, (int)(voff + r * rec_stride_bytes), 0, AUX);
     }
 }
 
@@ -910,6 +911,7 @@ struct ConvAArgs {
     float out_inv_scale;
     unsigned short* y16_pre;      // also store conv + bias before the GDN (F16K), or null
     unsigned long long* stamps;   // diagnostics: s_memrealtime (100 MHz) at 6 points of every tile of workgroup 0 / wave 0, or null
+    int store_aux;                // cache policy of the output stores of the wave-private form: 0 plain, 2 nt, 16 sc1 (MASIC_CONVA_STORE_AUX)
 };
 
 #ifndef CONVA_ABLATE
@@ -1316,8 +1318,16 @@ __global__ __launch_bounds__(512, 1) void conv_a_gdn_f16k_w(const ConvAArgs a) {
             const int oh = (t / a.tiles_w) * 8 + wave, ow = (t % a.tiles_w) * 32 + j;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y16 + (size_t)b * 8 * oplane * 16), 0, (int)(8 * rec_bytes), 0x00020000);
             const unsigned voff = (oh < a.Ho && ow < a.Wo) ? ((unsigned)oh * a.Wo + ow) * 32 + 16 * h : 0xC0000000u;
+            if (a.store_aux == 16) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) store_f16k_tile_buf(acc[m], ry, voff + (unsigned)(2 * m) * rec_bytes, rec_bytes);
+                for (int m = 0; m < 4; ++m) store_f16k_tile_buf<16>(acc[m], ry, voff + (unsigned)(2 * m) * rec_bytes, rec_bytes);
+            } else if (a.store_aux == 2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) store_f16k_tile_buf<2>(acc[m], ry, voff + (unsigned)(2 * m) * rec_bytes, rec_bytes);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) store_f16k_tile_buf<0>(acc[m], ry, voff + (unsigned)(2 * m) * rec_bytes, rec_bytes);
+            }
         }
         if (stamp) { stamp[5] = __builtin_amdgcn_s_memrealtime(); stamp += 6; }
     }
@@ -1811,7 +1821,8 @@ int conv_a_launch(const float* x, const void* w_packed, const float* bias, const
     const int Ho = (Hi + 4 - 5) / 2 + 1, Wo = (Wi + 4 - 5) / 2 + 1;
     const int tiles_w = ceil_div(Wo, 32), tiles_per_img = tiles_w * ceil_div(Ho, 8), ntiles = tiles_per_img * B;
     ConvAArgs a{x, (const uint4*)w_packed, bias, (const uint4*)gdn_packed, (unsigned short*)y_f16k, gdn_inverse, Hi, Wi, in_ctot, in_coff,
-                Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale, (unsigned short*)y_pre, g_f16k_stamps};
+                Ho, Wo, tiles_w, tiles_per_img, ntiles, (unsigned char*)y_f8k, out_inv_scale, (unsigned short*)y_pre, g_f16k_stamps,
+                getenv("MASIC_CONVA_STORE_AUX") ? atoi(getenv("MASIC_CONVA_STORE_AUX")) : 0};
     const size_t lds_bytes = 65536 + CA_WIMG_BYTES + 1024 + 2 * CA_PATCH_BYTES;
     const dim3 grid(ntiles < 256 ? ntiles : 256);
 #define CONV_A_LAUNCH(X3V, OUTV)                                                                                                   \
