@@ -816,7 +816,7 @@ def test_training_step_bf16_mode_against_float32():
     """HSIC(128,192,5), 2 x 128 x 256 pairs, one training-mode forward + RD loss + backward in the bf16-operand mode (fused GDN
     backward, bf16 weight-gradient kernels incl. the 5x5 stride-2 and the GEMM-shaped 1x1 ones, F16K input gradients) against the
     float32 path with the same weights, inputs and noise.  Bounds are those of operand rounding, not of a parity claim: the
-    loss to 2e-3, the median parameter-gradient error to 2 % (measured 0.6 %), every gradient within 30 degrees (measured: the
+    loss to 2e-3, the median parameter-gradient error to 1 % (measured 0.6 %), every gradient's cosine >= 0.94 (measured: the
     worst -- the left hyper path, whose float32 gradients already move 9 % when only the INPUT is rounded to bf16 -- at 15)."""
     import MASIC
     from compressai.entropy_models import EntropyModel
@@ -856,5 +856,64 @@ def test_training_step_bf16_mode_against_float32():
         rel.append(float((a - b).norm() / (a.norm() + 1e-300)))
     print(f"bf16-operand training step vs float32: loss {lb:.4f} vs {lf:.4f} ({abs(lb - lf) / abs(lf):.1e}), gradient cosine min {min(cos):.4f}, "
           f"relative error median {sorted(rel)[len(rel) // 2]:.2e} / max {max(rel):.2e}")
-    assert min(cos) >= 0.866, min(cos)
-    assert sorted(rel)[len(rel) // 2] <= 2e-2, sorted(rel)[len(rel) // 2]
+    # bounds = what is measured plus margin (round 3: cosine min 0.9616 -- the left hyper path, whose float32 gradients already move 9 % when
+    # only the INPUT is rounded to bf16 -- median relative error 5.6e-3); the fused nodes themselves are held to cosine >= 0.995 per tensor
+    # against the float32 graph in test_fused_transform_training_nodes_vs_float32_graph / the GmmHeadsFn and EnhancementBlockFn tests
+    assert min(cos) >= 0.94, min(cos)
+    assert sorted(rel)[len(rel) // 2] <= 1e-2, sorted(rel)[len(rel) // 2]
+
+
+@pytest.mark.parametrize("which", ["analysis", "synthesis"])
+def test_fused_transform_training_nodes_vs_float32_graph(which, monkeypatch):
+    """The composite bf16 training nodes behind the quoted training step -- masic_amd/autograd.py: AnalysisFn (Encoder1: four strided
+    convolutions + three GDNs as ONE node on the DMA-staged F16K kernels) and SynthesisFn (Decoder1) -- against the float32 node-per-layer
+    graph of the same module (the parity path the 1e-4 gradient goldens pin), on synthetic weights, a random input and a random output
+    gradient.  Gates as for EnhancementBlockFn (tests/test_gpu_cqe.py): the output within 1 % relative L2, every gradient (input + 14
+    parameters) aligned with the float32 one (cosine >= 0.995) and no worse than 1.5 x the error the node-per-layer graph has with the
+    SAME bf16 operands -- a dropped or mis-scaled term in one tensor's gradient fails both."""
+    import MASIC
+    from masic_amd import autograd as A, nn as mnn, synth
+    net = MASIC.HSIC(128, 192, 5)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=41))
+    mod = (net.encoder1 if which == "analysis" else net.decoder1).to(DEV).train()
+    g = torch.Generator().manual_seed(41)
+    if which == "analysis":
+        x = torch.rand((2, 3, 128, 192), generator=g).to(DEV).requires_grad_(True)
+        fwd, sup = (lambda: mod.latent_train(x)), "analysis_supported"
+    else:
+        x = (torch.randn((2, 192, 8, 12), generator=g) * 4.0).to(DEV).requires_grad_(True)
+        fwd, sup = (lambda: mod.reconstruct_train(x)), "synthesis_supported"
+    gy = None
+
+    def run():
+        nonlocal gy
+        mod.zero_grad()
+        x.grad = None
+        y = fwd()
+        if gy is None:
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(42)).to(DEV)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in mod.parameters() if p.grad is not None]
+    r32 = run()                                                      # float32 mode: the node-per-layer graph
+    mnn.set_precision("bf16")
+    try:
+        assert getattr(A, sup)(mod, x)
+        fused = run()
+        monkeypatch.setattr(A, sup, lambda *a: False)
+        unfused = run()
+    finally:
+        mnn.set_precision("f32")
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    def cos(a, b):
+        return float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm()))
+    assert len(fused) == len(r32) == len(unfused) == 16
+    ef, eu = [rel(a, b) for a, b in zip(fused, r32)], [rel(a, b) for a, b in zip(unfused, r32)]
+    cs = [cos(a, b) for a, b in zip(fused, r32)]
+    print(f"{which} transform, fused bf16 node vs float32 graph: out {ef[0]:.2e}, dx {ef[1]:.2e} (node-per-layer bf16 {eu[1]:.2e}), parameter "
+          f"gradients worst {max(ef[2:]):.2e} (node-per-layer bf16 {max(eu[2:]):.2e}), lowest cosine {min(cs):.5f}")
+    assert ef[0] <= 1e-2 and min(cs) >= 0.995, (ef[0], cs)
+    for k in range(1, 16):
+        assert ef[k] <= 1.5 * eu[k] + 1e-3, (k, ef[k], eu[k])
