@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--no-cqe", action="store_true", help="skip the Independent_EN (CQE) forward / training-step extras")
     ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive timings (extras.with_upload)")
     ap.add_argument("--no-trained", action="store_true", help="skip extras.accuracy_vs_ref_trained (trains HSIC for --trained-steps steps first)")
-    ap.add_argument("--trained-steps", type=int, default=1500)
+    ap.add_argument("--trained-steps", type=int, default=3000)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full training steps (forward + RD loss + backward + gradient all-reduce + "

@@ -473,3 +473,70 @@ def test_two_models_training_in_one_process_share_the_pack_registry():
                     assert torch.equal(got["likelihoods"][k], want["likelihoods"][k]), (it, k)
     finally:
         mnn.set_precision("f32")
+
+
+# ---------------------------------------------------------------- evaluation driver (test2_real.py)
+def test_eval_driver_loop_vs_reference_golden():
+    """test2_real.py:81-114 (criterion; its ms_ssim / lpips report entries need pytorch_msssim / lpips, which are not in the image and do not
+    enter the loss) and :172-231 (test_epoch: eval mode, no_grad, AverageMeter updates with device tensors, model.aux_loss()) restated on the
+    caller side, on the product HSIC with the reference's weights and inputs of hsic_tiny.npz: every scalar the driver prints -- loss, mse,
+    bpp, bpp1 / bpp2, psnr1 / psnr2 -- against the reference's own (1e-4), after two passes over the same pair through the meters."""
+    class EvalLoss(nn.Module):
+        def __init__(self, lmbda=1e-2):
+            super().__init__()
+            self.mse = nn.MSELoss()
+            self.lmbda = lmbda
+
+        @staticmethod
+        def mse2psnr(mse):                          # test2_real.py:66-69
+            return 10 * math.log10(1 / mse)
+
+        def forward(self, output, target1, target2):
+            N, _, H, W = target1.size()
+            out = {}
+            num_pixels = N * H * W
+            out['bpp_loss'] = sum((torch.log(likelihoods).sum() / (-math.log(2) * num_pixels)) for likelihoods in output['likelihoods'].values())
+            out['mse_loss'] = self.mse(output['x1_hat'], target1) + self.mse(output['x2_hat'], target2)
+            out['bpp1'] = (torch.log(output['likelihoods']['y1']).sum() / (-math.log(2) * num_pixels)) + (
+                torch.log(output['likelihoods']['z1']).sum() / (-math.log(2) * num_pixels))
+            out['bpp2'] = (torch.log(output['likelihoods']['y2']).sum() / (-math.log(2) * num_pixels)) + (
+                torch.log(output['likelihoods']['z2']).sum() / (-math.log(2) * num_pixels))
+            out['loss'] = self.lmbda * 255 ** 2 * out['mse_loss'] + out['bpp_loss']
+            out['psnr1'] = self.mse2psnr(self.mse(output['x1_hat'], target1))
+            out['psnr2'] = self.mse2psnr(self.mse(output['x2_hat'], target2))
+            return out
+
+    class AverageMeter:
+        def __init__(self):
+            self.val = 0; self.avg = 0; self.sum = 0; self.count = 0
+
+        def update(self, val, n=1):
+            self.val = val
+            self.sum += val * n
+            self.count += n
+            self.avg = self.sum / self.count
+
+    fx, net, _ = _tiny()
+    d1, d2, hm = (torch.from_numpy(fx[k]).to(DEV) for k in ("x1", "x2", "h_matrix"))
+    criterion = EvalLoss(lmbda=float(fx["lmbda"]))
+    net.eval()
+    meters = {k: AverageMeter() for k in ("loss", "bpp_loss", "mse_loss", "aux_loss", "psnr1", "psnr2", "bpp1", "bpp2")}
+    with torch.no_grad():
+        for _ in range(2):
+            out_net = net(d1, d2, hm)
+            out_criterion = criterion(out_net, d1, d2)
+            meters["aux_loss"].update(net.aux_loss())
+            for k in ("loss", "bpp_loss", "mse_loss", "psnr1", "psnr2", "bpp1", "bpp2"):
+                meters[k].update(out_criterion[k])
+    line = (f'\tLoss: {meters["loss"].avg:.3f} |\tMSE loss: {meters["mse_loss"].avg:.4f} |\tPSNR (dB): {(meters["psnr1"].avg + meters["psnr2"].avg) / 2:.3f} |'
+            f'\tBpp loss: {meters["bpp_loss"].avg / 2:.4f} |\tBPP1: {meters["bpp1"].avg:.3f} |\tAux loss: {meters["aux_loss"].avg:.2f}')
+    assert "Loss:" in line
+    want = {"loss": "eval/loss_loss", "bpp_loss": "eval/loss_bpp_loss", "mse_loss": "eval/loss_mse_loss", "psnr1": "eval/loss_psnr1", "psnr2": "eval/loss_psnr2"}
+    for k, g in want.items():
+        a, b = float(meters[k].avg), float(fx[g])
+        assert abs(a - b) <= 1e-4 * abs(b), (k, a, b)
+    for k, (gy, gz) in {"bpp1": ("eval/loss_bpp_y1", "eval/loss_bpp_z1"), "bpp2": ("eval/loss_bpp_y2", "eval/loss_bpp_z2")}.items():
+        a, b = float(meters[k].avg), float(fx[gy]) + float(fx[gz])
+        assert abs(a - b) <= 1e-4 * abs(b), (k, a, b)
+    for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat", "x1_mask_R", "x1_mask_L"):
+        assert_close(out_net[k], torch.from_numpy(fx["eval/" + k]), "eval driver:" + k)
