@@ -540,3 +540,32 @@ def test_eval_driver_loop_vs_reference_golden():
         assert abs(a - b) <= 1e-4 * abs(b), (k, a, b)
     for k in ("x1_hat", "x2_hat", "y1_hat", "z1_hat", "x1_mask_R", "x1_mask_L"):
         assert_close(out_net[k], torch.from_numpy(fx["eval/" + k]), "eval driver:" + k)
+
+
+def test_cqe_eval_driver_loop_vs_reference_golden():
+    """test3_real.py:186-194 (the CQE evaluation driver: `out_net = model(d1, d2, h)`, `out_net2 = model2(out_net['x1_hat'], out_net['x2_hat'], h)`,
+    the distortion criterion on out_net2 and the rate criterion (`kind=1`) on out_net, under no_grad with both networks in eval mode) on the
+    product modules with the reference's weights: Independent_EN's outputs and loss against cqe_train.npz's chain entries (Independent_EN has
+    no mode-dependent layer), the rate against hsic_tiny.npz's eval goldens."""
+    import MASIC
+    from masic_amd import synth
+    fx = load_npz("cqe_train.npz")
+    tiny, hsic, _ = _tiny()
+    hsic.eval()
+    net2 = MASIC.Independent_EN()
+    net2.load_state_dict(synth.synth_state_dict(net2.state_dict(), seed=int(fx["seed_en"])))
+    net2 = net2.to(DEV).eval()
+    d1, d2, hm = (torch.from_numpy(tiny[k]).to(DEV) for k in ("x1", "x2", "h_matrix"))
+    criterion = DistortionLoss(lmbda=float(fx["lmbda"]))
+    with torch.no_grad():
+        out_net = hsic(d1, d2, hm)
+        out_net2 = net2(out_net['x1_hat'], out_net['x2_hat'], hm)
+        out_criterion = criterion(out_net2, d1, d2)
+        N, _, H, W = d1.size()
+        bpp = sum((torch.log(l).sum() / (-math.log(2) * N * H * W)) for l in out_net['likelihoods'].values())     # criterion(out_net, d1, d2, kind=1)
+        aux = hsic.aux_loss()
+    for k in ("x1_hat", "x2_hat"):
+        assert_close(out_net2[k], torch.from_numpy(fx["chain/" + k]), "cqe eval driver:" + k)
+    assert abs(out_criterion["loss"].item() - float(fx["chain/loss"])) <= 1e-4 * abs(float(fx["chain/loss"]))
+    assert abs(bpp.item() - float(tiny["eval/loss_bpp_loss"])) <= 1e-4 * float(tiny["eval/loss_bpp_loss"])
+    assert math.isfinite(aux.item()) and out_criterion["psnr1"] > 0
