@@ -231,6 +231,9 @@ struct F16kArgs {
     int xcd_images;               // B % 8 == 0: image b runs on XCD b % 8 (the halos of its tiles meet in one L2)
     int msplit;                   // workgroups per 128-channel co-block (4 / NM for layers whose grid would not fill the chip, else 1):
                                   //   blockIdx.y = co-block * msplit + sub-block, a sub-block = NM accumulator tiles of the slab
+    int exp_store;                // timing experiments only (MASIC_F16K_STORE_EXP; results are WRONG when set): 1 the F16K stores of the epilogue are
+                                  //   skipped at run time (the arithmetic stays), 2 a transposed layer's phases store to phase-planar positions
+                                  //   (pixel (r + oph Ho/2, c + opw Wo/2): every wave writes whole contiguous records, as if one workgroup owned both x-phases)
 };
 
 #ifndef F16K_DMA_SPREAD
@@ -799,7 +802,8 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
         if (NP > 1) __builtin_amdgcn_sched_barrier(0);      // one sub-tile's epilogue at a time (register pressure)
         const int r = r0 + (wave * NP + n) * a.SR + jr, c = c0 + jc;
         const bool pok = r < g.Hp && c < g.Wp;
-        const int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+        int oh = pok ? r * g.os + g.oph : 0, ow = pok ? c * g.os + g.opw : 0;
+        if (a.exp_store == 2 && g.os == 2 && pok) { oh = r + g.oph * (a.Ho >> 1); ow = c + g.opw * (a.Wo >> 1); }
         const size_t opix = (size_t)oh * a.Wo + ow;
         if constexpr (GDN) {
             if (a.y16_pre != nullptr && pok) {
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(512, D == 1 ? 2 : 1) void conv_f16k(const F16kArgs 
                 }
 #pragma unroll
                 for (int m = 0; m < NM; ++m)
-                    if (m0 + m * 32 < a.Cout) store_f16k_tile(acc[n][m], yb + (size_t)(2 * m) * op16, op16);
+                    if (m0 + m * 32 < a.Cout && a.exp_store != 1) store_f16k_tile(acc[n][m], yb + (size_t)(2 * m) * op16, op16);
             }
         }
     }
@@ -1708,6 +1712,8 @@ int f16k_launch(const void* x_f16k, const void* w_packed, const float* bias, con
                {c.stream_bytes[0], c.stream_bytes[1], c.stream_bytes[2], c.stream_bytes[3]}, geom_params(*d), np, d->B % 8 == 0, 1};
     const int msplit = f16k_msplit(*d, c, np, g, gdn_packed != nullptr, d2s != 0 || cout_store != 0 || y_f8k != nullptr);
     a.msplit = msplit;
+    static const int exp_store = getenv("MASIC_F16K_STORE_EXP") ? atoi(getenv("MASIC_F16K_STORE_EXP")) : 0;
+    a.exp_store = exp_store;
     dim3 grid(round_up(ntiles, 8) * np, c.ncb * msplit, d->B);
     hipStream_t st = (hipStream_t)stream;
 #define F16K_LAUNCH_D(KSV, TV, DV, PSPV, LV, GDNV, NMV, NPV)                                                                   \
