@@ -132,6 +132,9 @@ def _side_streams(device, n=4):
     return tuple(s for s in pool if s.cuda_stream != cur)[:n]
 
 
+_TRAIN_STREAMS = os.environ.get("MASIC_TRAIN_STREAMS", "1") != "0"      # 0: the whole TRAINING forward (and so its backward) on one stream (A/B timing)
+
+
 def _keep_until(t, stream):
     """Tensor.record_stream for a tensor used on another stream than the one it was allocated on.  Skipped inside a HIP-graph
     capture: there every cross-stream tensor of the forward lives until all streams have joined the capturing one (and
@@ -711,18 +714,31 @@ class HSIC(CompressionModel):
         y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)       # draw 3
         x1_hat = self.decoder1.reconstruct_train(y1_hat)
 
-        x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
-        y2 = self.encoder2(x1_warp, x2)
-        z2 = self._h_a2(y2)
-        z2_hat, z2_lik = self.entropy_bottleneck2(z2)                                   # draw 4
-        params2 = self._hyper_up(self.h_s2_up, z2_hat, None, 0)
-        ctx2 = self.context_prediction2.run(self.gaussian2._quantize(y2, "noise"))     # draw 5
-        x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
-        x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
-        gates = self.mask2weights_unit(x1_mask_R)
+        # The right view up to its entropy parameters needs nothing of the left view: with MASIC_TRAIN_STREAMS it is ISSUED here, in the
+        # reference's order (the noise draws are numbered by the host), but on a side stream, next to the main stream's backlog and to the
+        # left reconstruction's second analysis pass -- and autograd runs every node's backward on the stream of its forward, so the
+        # backward of this branch runs beside the left view's too.
+        fj = _ForkJoin()
+        sA = _side_streams(x1.device)[0] if (_TRAIN_STREAMS and not torch.cuda.is_current_stream_capturing()) else fj.main
+        fj.fork(sA)
+        with fj.on(sA):
+            x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
+            y2 = self.encoder2(x1_warp, x2)
+            z2 = self._h_a2(y2)
+            z2_hat, z2_lik = self.entropy_bottleneck2(z2)                                   # draw 4
+            params2 = self._hyper_up(self.h_s2_up, z2_hat, None, 0)
+            ctx2 = self.context_prediction2.run(self.gaussian2._quantize(y2, "noise"))     # draw 5
+            x1_mask_R = _hip.warp_perspective(None, m_fwd, (H, W), ones_like=(B, H, W))
+            x1_mask_L = _hip.warp_perspective(x1_mask_R, m_back, (H, W))
+            gates = self.mask2weights_unit(x1_mask_R)
         x1_hat_warp = _ag.WarpFn.apply(x1_hat, m_fwd, (H, W))
         y1_warp = self.encoder1.latent_train(x1_hat_warp)
         y1_warp_hat = self.gaussian1._quantize(y1_warp, "noise")                        # draw 6
+        if fj.join(sA) is not None:
+            for t in (m_fwd, m_back):
+                _keep_until(t, sA)
+            for t in (y2, z2_lik, params2, ctx2, x1_mask_R, x1_mask_L, gates):
+                _keep_until(t, fj.main)
         cat2 = _ag.cat(_ag.GateFn.apply(params2, gates, 0), _ag.GateFn.apply(ctx2, gates, 1),
                        _ag.GateFn.apply(y1_warp_hat, gates, 2))
         s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)

@@ -103,7 +103,10 @@ def conv_backward(mod, x, weight, y, g, act, need_gx=True, need_gw=True, need_gb
     F16K-operand kernel), float32 NCHW otherwise.
     x = None / g = None with x_shape / g_shape: the caller has that tensor in F16K only (x16 / g16 + gb) -- the picture-end layers, whose
     weight gradient reads the 128-channel operand in F16K (ops.pic_wgrad_f16k) and never needs its float32 NCHW form.
-    (Issuing dW / db on a side stream next to dx was measured: 24.9 -> 25.2 ms per HSIC training step, i.e. nothing -- not kept.)"""
+    (Issuing dW / db on a side stream next to dx was measured twice: 24.9 -> 25.2 ms per HSIC training step in round 2, 13.14 -> 13.00 in
+    round 3 and 12.33 -> 12.62 on top of the two-stream forward -- the eager step is bound by the host's launch rate, and a gradient
+    produced beside the node's stream is unsafe for a layer used twice in one forward, whose two contributions autograd adds on the node's
+    stream before `.grad` exists.  Not kept.)"""
     if g is None:
         if g16 is None or g_shape is None or act != ops.ACT_NONE or (need_gb and gb is None):
             raise RuntimeError("masic_amd.conv_backward: g = None needs g16, g_shape, the bias gradient and no activation")

@@ -434,7 +434,7 @@ _ws = {}
 
 
 def _workspace(device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, int(_stream().value or 0))
     if key not in _ws:
         _ws[key] = torch.empty(lib.masic_reduce_workspace_bytes() // 8, dtype=torch.float64, device=device)
     return _ws[key]
@@ -596,9 +596,10 @@ def gdn_bwd_fused(x, g, beta, gamma, inverse=False, beta_min=1e-6):
     B, C, H, W = x.shape
     if g.shape != x.shape or not (x.is_contiguous() and g.is_contiguous()):
         raise RuntimeError("masic_amd.gdn_bwd_fused: x and g must be contiguous and of one shape")
-    ws = _GDN_BWD_WS.get(x.device)
+    key = (x.device, int(_stream().value or 0))        # per stream: two streams' kernels must not share the partial sums
+    ws = _GDN_BWD_WS.get(key)
     if ws is None:
-        ws = _GDN_BWD_WS[x.device] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        ws = _GDN_BWD_WS[key] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=x.device)
     gx = torch.empty_like(x)
     g_beta = torch.empty(C, dtype=torch.float32, device=x.device)
     g_gamma = torch.empty(C, C, dtype=torch.float32, device=x.device)
@@ -623,9 +624,10 @@ def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, wan
     if not (want_nchw or want_f16k or want_b16):
         raise RuntimeError("masic_amd.gdn_bwd_fused_ex: no output requested")
     dev = x.device
-    ws = _GDN_BWD_WS.get(dev)
+    key = (dev, int(_stream().value or 0))
+    ws = _GDN_BWD_WS.get(key)
     if ws is None:
-        ws = _GDN_BWD_WS[dev] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = _GDN_BWD_WS[key] = torch.empty(lib.masic_gdn_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
     gx = torch.empty(shape, dtype=torch.float32, device=dev) if (want_nchw and not want_b16) else None
     gxb = torch.empty(shape, dtype=torch.bfloat16, device=dev) if want_b16 else None
     gx16 = torch.empty(B * C * H * W, dtype=torch.int16, device=dev) if want_f16k else None

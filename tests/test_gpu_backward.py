@@ -917,3 +917,61 @@ def test_fused_transform_training_nodes_vs_float32_graph(which, monkeypatch):
     assert ef[0] <= 1e-2 and min(cs) >= 0.995, (ef[0], cs)
     for k in range(1, 16):
         assert ef[k] <= 1.5 * eu[k] + 1e-3, (k, ef[k], eu[k])
+
+
+def test_two_stream_training_forward_is_the_one_stream_computation():
+    """HSIC._forward_graph issues the right view's front part (warp, encoder2, h_a2, EB2, h_s2_up, context model 2, masks, gates) on a
+    side stream; autograd runs each node's backward on its forward's stream.  Same noise draws in host order, same kernels: outputs and
+    all 166 gradients must agree with the one-stream schedule to the run-to-run floor of the float atomics, every time (a workspace shared
+    by two streams' kernels -- the GDN backward's partial sums were, once -- shows as an occasional O(1) difference)."""
+    import MASIC
+    from compressai.entropy_models import EntropyModel
+    from masic_amd import nn as mnn, synth
+    from masic_amd.loss import rate_distortion
+    N, M, K, B, H, W = 128, 192, 5, 1, 128, 128
+    sd0 = synth.synth_state_dict(MASIC.HSIC(N, M, K).state_dict(), seed=57)
+    batch = tuple(t.to(DEV) for t in synth.synth_inputs(B, H, W, seed=61))
+    noise = synth.synth_noise(B, N, M, H, W, seed=71)
+    slots = [noise[k].to(DEV) for k in O.NOISE_KEYS]
+    state = {"i": 0}
+
+    def static_noise(self, x):
+        t = slots[state["i"] % len(slots)]
+        state["i"] += 1
+        return t.reshape(x.shape)
+
+    orig, prev = EntropyModel._get_noise_cached, MASIC._TRAIN_STREAMS
+    EntropyModel._get_noise_cached = static_noise
+    mnn.set_precision("bf16")
+    try:
+        net = MASIC.HSIC(N, M, K)
+        net.load_state_dict(sd0)
+        net = net.to(DEV).train()
+
+        def run(streams):
+            MASIC._TRAIN_STREAMS = streams
+            state["i"] = 0
+            for _, p in net.named_parameters():
+                p.grad = None
+            out = net(*batch)
+            crit = rate_distortion(out, batch[0], batch[1], 0.01)
+            crit["loss"].backward()
+            torch.cuda.synchronize()
+            return float(crit["loss"]), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if p.grad is not None}
+
+        run(False)
+        l0, g0 = run(False)
+        l1, g1 = run(False)
+        floor = max(float((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-30)) for n in g0)
+        worst = 0.0
+        for _ in range(12):
+            l2, g2 = run(True)
+            assert g2.keys() == g0.keys()
+            assert abs(l2 - l0) <= 1e-6 * abs(l0)
+            worst = max(worst, max(float((g0[n] - g2[n]).norm() / (g0[n].norm() + 1e-30)) for n in g0))
+        print(f"two-stream vs one-stream gradients, worst relative difference over 12 runs {worst:.2e} (one-stream run-to-run floor {floor:.2e})")
+        assert worst <= max(1e-5, 20 * floor), (worst, floor)
+    finally:
+        EntropyModel._get_noise_cached = orig
+        MASIC._TRAIN_STREAMS = prev
+        mnn.set_precision("f32")

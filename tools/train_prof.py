@@ -16,4 +16,5 @@ for _ in range(2): train_step(net, opt, aopt, x1, x2, hm, 0.01)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = int(os.environ.get("TRAIN_PROF_STEPS", "3"))
 for _ in range(n): train_step(net, opt, aopt, x1, x2, hm, 0.01)
-torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / n * 1e3)
+th = time.perf_counter()
+torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / n * 1e3, " of which the host needs", (th - t0) / n * 1e3, "to enqueue a step")
