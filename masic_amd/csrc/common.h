@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include "masic_hip.h"
 
@@ -24,16 +25,21 @@ static inline int masic_launch_status(const char* what) {
     return MASIC_OK;
 }
 
-// Zero fill as a KERNEL node.  hipMemsetAsync becomes a memset node when the stream is being captured, and in a replayed graph of the
-// training step those nodes were observed to run out of order with the kernels around them on this ROCm (weight-gradient workspaces
-// read back with garbage in them, different tensors from run to run; masic_amd/graph.py: GraphedTrainStep) -- a kernel node keeps
-// its place.  bytes must be a multiple of 4 and ptr 4-byte aligned.
+// Zero fill as a KERNEL node.  hipMemsetAsync becomes a memset node when the stream is being captured, and the first memset node of a
+// graph captured by torch.cuda.graph runs unordered with the kernels around it from the second replay on when the graph is replayed on
+// torch's default stream (ROCm 7.2 / torch 2.10: tools/memset_node_repro.py shows it with torch kernels only) --
+// a kernel node keeps its place.  bytes must be a multiple of 4 and ptr 4-byte aligned.
 __global__ static void masic_zero_kernel(unsigned* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
-static inline hipError_t masic_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+static inline hipError_t masic_zero_async(void* ptr, size_t bytes, hipStream_t st, int site = 0) {
     const size_t n = bytes / 4;
     if (n == 0) return hipSuccess;
+    // experiment (tools/micro/memset_graph.hip): MASIC_ZERO_MEMSET=1|2 issues the fills as hipMemsetAsync (memset nodes
+    // under capture); MASIC_ZERO_MEMSET_SITES = bit mask of the call sites that do (default all)
+    static const bool as_memset = getenv("MASIC_ZERO_MEMSET") != nullptr && (getenv("MASIC_ZERO_MEMSET")[0] == '2');
+    static const int sites = getenv("MASIC_ZERO_MEMSET_SITES") ? atoi(getenv("MASIC_ZERO_MEMSET_SITES")) : -1;
+    if (as_memset && ((sites >> site) & 1)) return hipMemsetAsync(ptr, 0, bytes, st);
     size_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(masic_zero_kernel, dim3((unsigned)nb), dim3(256), 0, st, (unsigned*)ptr, n);

@@ -892,14 +892,14 @@ int wgrad_launch(const void* xv, const void* dyv, float* dw, void* workspace, co
         int nsplit = ceil_div(512, base);
         if (nsplit > g.ntk) nsplit = g.ntk;
         g.nsplit = nsplit < 1 ? 1 : nsplit;
-        if (masic_zero_async(dw, wbytes, st) != hipSuccess) {
+        if (masic_zero_async(dw, wbytes, st, 0) != hipSuccess) {
             masic_set_error("conv2d_wgrad: memset failed");
             return MASIC_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(conv_wgrad_1x1_bf16, dim3(base, 1, g.nsplit), dim3(256), 0, st, g);
         return masic_launch_status("conv2d_wgrad");
     }
-    if (!workspace_clean && masic_zero_async(workspace, wbytes, st) != hipSuccess) {
+    if (!workspace_clean && masic_zero_async(workspace, wbytes, st, 1) != hipSuccess) {
         masic_set_error("conv2d_wgrad: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }

@@ -611,7 +611,7 @@ extern "C" int masic_conv3x3_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
                   "conv3x3_wgrad_f16k: needs Cin, Cout multiples of 32");
     MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv3x3_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (!workspace_clean && masic_zero_async(workspace, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+    if (!workspace_clean && masic_zero_async(workspace, masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout), st, 2) != hipSuccess) {
         masic_set_error("conv3x3_wgrad_f16k: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
@@ -664,7 +664,7 @@ extern "C" int masic_conv5x5_wgrad_f16k_ws(const void* x_f16k, const void* dy_f1
                   "conv5x5_wgrad_f16k: needs Cin, Cout multiples of 32");
     MASIC_REQUIRE((long)B * (Cin > Cout ? Cin : Cout) * H * W * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "conv5x5_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (!workspace_clean && masic_zero_async(workspace, masic_conv5x5_wgrad_f16k_workspace_bytes(Cin, Cout), st) != hipSuccess) {
+    if (!workspace_clean && masic_zero_async(workspace, masic_conv5x5_wgrad_f16k_workspace_bytes(Cin, Cout), st, 3) != hipSuccess) {
         masic_set_error("conv5x5_wgrad_f16k: workspace memset failed");
         return MASIC_ERR_LAUNCH;
     }
@@ -732,7 +732,7 @@ extern "C" int masic_gemm_wgrad_bias_f16k(const void* rows_f16k, const void* col
     MASIC_REQUIRE((long)B * (CA > CQ ? CA : CQ) * HW * 2 < (1l << 31), MASIC_ERR_UNSUPPORTED, "gemm_wgrad_f16k: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
     const size_t nb = bias_of == 1 ? CA : (bias_of == 2 ? CQ : 0);
-    if (masic_zero_async(dw, ((size_t)CA * CQ + nb) * sizeof(float), st) != hipSuccess) {
+    if (masic_zero_async(dw, ((size_t)CA * CQ + nb) * sizeof(float), st, 4) != hipSuccess) {
         masic_set_error("gemm_wgrad_f16k: zero fill failed");
         return MASIC_ERR_LAUNCH;
     }

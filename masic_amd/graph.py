@@ -189,9 +189,10 @@ class GraphedTrainStep:
     What makes the step capturable: no host synchronisation inside it (masic_amd/loss.py: LazyPSNR; device-side loss-gradient
     scalars; sampling matrices from the device kernel -- reduced operand precision only, the float32 parity path evaluates them on
     the host), torch's Adam in its `capturable` form, every buffer from torch's caching allocator (graph-private pool during capture),
-    and zero fills as KERNEL nodes: hipMemsetAsync / torch.zeros become memset nodes, which ran out of order with the kernels around
-    them in the replayed graph on this ROCm (weight-gradient workspaces read back with garbage, different tensors from run to run;
-    masic_amd/csrc/common.h: masic_zero_async, ops.zeros).
+    and zero fills as KERNEL nodes: the library's hipMemsetAsync calls became memset nodes, and the first memset node of a graph
+    captured by torch.cuda.graph loses its ordering from the second replay on when the graph is replayed on torch's default stream
+    (ROCm 7.2 / torch 2.10; reduced to 25 lines without this library in tools/memset_node_repro.py) -- weight
+    gradients read back with garbage, different tensors from run to run (masic_amd/csrc/common.h: masic_zero_async).
 
     Measured (tools/train_prof.py, TRAIN_PROF_GRAPH=1): the replay is NOT faster than the eager, synchronisation-free step on this
     ROCm -- 20.8 vs 19.9 ms at 8 x 512 x 512, 11.1 vs 11.3 ms at 1 x 512 x 512 -- because the ~880 nodes of a step cost the device

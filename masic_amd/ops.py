@@ -53,8 +53,9 @@ _current_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice
 
 
 def zeros(shape, dtype=torch.float32, device=None):
-    """torch.zeros through a fill KERNEL: torch's zeros / zero_ use hipMemsetAsync, which becomes a memset node under stream capture, and
-    those nodes were observed to run out of order inside a replayed training-step graph (masic_amd/csrc/common.h: masic_zero_async)."""
+    """A zero tensor by an explicit fill kernel.  (torch.zeros is a fill kernel as well on this build -- rocprofv3 shows FillFunctor for
+    zeros / zero_ / fill_(0) -- so this is equivalent; what must not be used for fills inside a captured step is hipMemsetAsync,
+    masic_amd/csrc/common.h: masic_zero_async.)"""
     return torch.empty(shape, dtype=dtype, device=device).fill_(0)
 
 
