@@ -633,7 +633,8 @@ extern "C" int masic_slice_copy(const float* x, float* y, int B, int C, int HW, 
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "slice_copy: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "slice_copy: view out of range");
     const size_t total = (size_t)B * C * HW;
-    hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, ctot, coff, total);
+    if (!masic_plane_copy(x, nullptr, nullptr, y, B, C, HW, ctot, coff, C, 0, 0, 0, 3, (hipStream_t)stream))
+        hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, ctot, coff, total);
     return masic_launch_status("slice_copy");
 }
 

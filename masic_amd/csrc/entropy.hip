@@ -219,8 +219,9 @@ extern "C" int masic_quantize_fwd(const float* x, const float* noise, const floa
     MASIC_REQUIRE(mode != 1 || noise, MASIC_ERR_ARG, "quantize_fwd: noise mode without a noise tensor");
     MASIC_REQUIRE(out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "quantize_fwd: output view out of range");
     const size_t total = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, noise, gate, y,
-                       C, H * W, out_ctot, out_coff, gate_ctot, gate_c, mode, total);
+    if (!masic_plane_copy(x, noise, gate, y, B, C, H * W, C, 0, out_ctot, out_coff, gate_ctot, gate_c, mode, (hipStream_t)stream))
+        hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, noise, gate, y,
+                           C, H * W, out_ctot, out_coff, gate_ctot, gate_c, mode, total);
     return masic_launch_status("quantize_fwd");
 }
 

@@ -28,22 +28,27 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // float32 NCHW (channel view) -> F16K bf16
 __global__ __launch_bounds__(256) void nchw_to_f16k_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
                                                            int C, int Cpad, int HW, int ctot, int coff, int op) {
-    // one thread per (pixel, 8-channel half record): 8 coalesced plane reads, one 16-byte write
-    const int b = blockIdx.z, c8 = blockIdx.y;
+    // one thread per (pixel, 16-channel record): 16 coalesced plane reads, all issued before the first use, and ONE whole 32-byte record
+    // written (2 KiB contiguous per wave).  (Round 2's form gave a thread half a record: every wave wrote 16-byte pieces at a 32-byte
+    // stride and the other half came from another workgroup -- 4.0 TB/s; tools/bench_elementwise.py.)
+    const int b = blockIdx.z, c16 = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const float* xb = x + ((size_t)b * ctot + coff) * HW + p;
-    float v[8];
+    float v[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = c8 * 8 + i;
-        const float t = xb[(size_t)(c < C ? c : C - 1) * HW];
-        v[i] = c < C ? apply_inop(t, op) : 0.0f;
+    for (int i = 0; i < 16; ++i) {
+        const int c = c16 * 16 + i;
+        v[i] = xb[(size_t)(c < C ? c : C - 1) * HW];
     }
-    uint4 q;
-    q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
-    unsigned short* yb = y + (((size_t)b * (Cpad >> 4) + (c8 >> 1)) * HW + p) * 16 + (c8 & 1) * 8;
-    *reinterpret_cast<uint4*>(yb) = q;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = c16 * 16 + i < C ? apply_inop(v[i], op) : 0.0f;
+    uint4 q0, q1;
+    q0.x = pack2(v[0], v[1]); q0.y = pack2(v[2], v[3]); q0.z = pack2(v[4], v[5]); q0.w = pack2(v[6], v[7]);
+    q1.x = pack2(v[8], v[9]); q1.y = pack2(v[10], v[11]); q1.z = pack2(v[12], v[13]); q1.w = pack2(v[14], v[15]);
+    uint4* yb = reinterpret_cast<uint4*>(y + (((size_t)b * (Cpad >> 4) + c16) * HW + p) * 16);
+    yb[0] = q0;
+    yb[1] = q1;
 }
 
 struct GemmArgs {
@@ -200,7 +205,7 @@ extern "C" int masic_nchw_to_f16k_op(const float* x, void* y, int B, int C, int 
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "nchw_to_f16k: null pointer");
     MASIC_REQUIRE(coff >= 0 && coff + C <= ctot, MASIC_ERR_SHAPE, "nchw_to_f16k: view out of range");
     const int Cpad = round_up(C, 16);
-    hipLaunchKernelGGL(nchw_to_f16k_kernel, dim3(ceil_div(HW, 256), Cpad / 8, B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(nchw_to_f16k_kernel, dim3(ceil_div(HW, 256), Cpad / 16, B), dim3(256), 0, (hipStream_t)stream,
                        x, (unsigned short*)y, C, Cpad, HW, ctot, coff, in_op);
     return masic_launch_status("nchw_to_f16k");
 }

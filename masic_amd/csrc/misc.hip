@@ -181,8 +181,9 @@ extern "C" int masic_copy_view(const float* x, float* y, int B, int C, int HW, i
     MASIC_REQUIRE(x && y, MASIC_ERR_ARG, "copy_view: null pointer");
     MASIC_REQUIRE(out_coff >= 0 && out_coff + C <= out_ctot, MASIC_ERR_SHAPE, "copy_view: output view out of range");
     const size_t total = (size_t)B * C * HW;
-    hipLaunchKernelGGL(copy_view_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW,
-                       out_ctot, out_coff, total);
+    if (!masic_plane_copy(x, nullptr, nullptr, y, B, C, HW, C, 0, out_ctot, out_coff, 0, 0, 3, (hipStream_t)stream))
+        hipLaunchKernelGGL(copy_view_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW,
+                           out_ctot, out_coff, total);
     return masic_launch_status("copy_view");
 }
 
