@@ -528,6 +528,12 @@ int masic_entropy_bottleneck_aux_step(const float* const* params, const float* c
 /* warp backward w.r.t. the source image; g_src [B,C,Hs,Ws] must be ZERO-FILLED by the caller (float atomics) */
 int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,
                                int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
+/* The same adjoint (autograd's backward of kornia.warp_perspective -> F.grid_sample, reference MASIC.py:781, :1461-1480) as a gather over
+ * source pixels: no atomics, a fixed summation order, g_src written once and needing NO zero fill.  flag: one int32 on the device, zero
+ * on entry; set to 1 when some source pixel's footprint was outside the gather form's bounds (horizon inside the picture, magnification
+ * beyond ~2 x) -- the call has then redone the whole tensor with the scatter form above (device-side test of the flag, no host round trip). */
+int masic_warp_perspective_bwd_gather(const float* g_dst, const float* minv_norm, float* g_src, int* flag,
+                                      int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side entropy coding (no device work).  Bit-exact replacements of the reference's pybind11

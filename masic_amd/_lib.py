@@ -180,6 +180,7 @@ SIGNATURES = {
     "masic_entropy_bottleneck_auxloss_bwd": (c_int, [_P, _P, _P, c_int, c_double, c_float, _P]),
     "masic_entropy_bottleneck_aux_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
     "masic_warp_perspective_bwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
+    "masic_warp_perspective_bwd_gather": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
 }
 
 

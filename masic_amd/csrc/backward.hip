@@ -602,6 +602,174 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- the same adjoint as a GATHER: one thread per SOURCE pixel q collects g[p] w(p, q) from every destination pixel p whose bilinear
+// footprint contains q.  The scatter form above spends four float atomics per element -- 268 M of them for a 32-channel feature map
+// at 8 x 512 x 512, at the chip's atomic rate of ~1.3 TB/s of added bytes: 1.1 ms per launch, two per CQE training step.  Here:
+//   * the destination pixels that can reach q are those whose sampling point s(p) lies in (qx - 1, qx + 1) x (qy - 1, qy + 1); s is a
+//     projective map, so they lie inside the image of that square under s^-1 -- a convex quadrilateral as long as the homogeneous
+//     coordinate keeps its sign on the four corners; its bounding box (padded by 0.05 pixels for rounding) is the candidate set;
+//   * every candidate's sampling point and weights are evaluated with exactly the forward kernel's float operations, and a candidate
+//     counts iff floor(s(p)) puts q among its four taps: the weight pairs (p, q) are the forward's, bit for bit -- an exact adjoint,
+//     summed in a fixed order (no atomics: results are reproducible, which the scatter form's are not);
+//   * up to WG_MAX matches are kept in registers and applied channel by channel: g is read ~4 x through the caches, g_src written once
+//     (no zero fill before it).
+// A pixel whose corners straddle the horizon of the homography, whose box holds more than WG_BOX candidates or which finds more than
+// WG_MAX matches (magnification beyond ~2 x: (2 s)^2 destination pixels reach a source pixel at s destination pixels per source pixel)
+// raises *flag: the caller then runs zero fill + scatter over the whole tensor (the two launches
+// that follow test the flag on the device, no host round trip).
+constexpr int WG_MAX = 16, WG_BOX = 196;
+template <int N>
+__device__ __forceinline__ void warp_gather_channels(const float* __restrict__ gb, float* __restrict__ sb, const int (&mp)[WG_MAX], const float (&mwx)[WG_MAX],
+                                                     const float (&mwy)[WG_MAX], int C, size_t dplane, size_t splane) {
+    int c = 0;
+    for (; c + 2 <= C; c += 2) {
+        const float* g0 = gb + (size_t)c * dplane;
+        const float* g1 = g0 + dplane;
+        float v0[N], v1[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { v0[k] = g0[mp[k]]; v1[k] = g1[mp[k]]; }
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { a0 += v0[k] * mwx[k] * mwy[k]; a1 += v1[k] * mwx[k] * mwy[k]; }
+        sb[(size_t)c * splane] = a0;
+        sb[(size_t)(c + 1) * splane] = a1;
+    }
+    for (; c < C; ++c) {
+        const float* g0 = gb + (size_t)c * dplane;
+        float a0 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) a0 += g0[mp[k]] * mwx[k] * mwy[k];
+        sb[(size_t)c * splane] = a0;
+    }
+}
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ g_dst, const float* __restrict__ minv, float* __restrict__ g_src,
+                                                              int* __restrict__ flag, int C, int Hs, int Ws, int Hd, int Wd, int align_corners) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Hs * Ws) return;
+    const int qy = q / Ws, qx = q - qy * Ws;
+    const float* m = minv + b * 9;
+    // s^-1 on normalised coordinates = inverse(minv) (float64 cofactors; only used for the candidate box)
+    const double a0 = m[0], a1 = m[1], a2 = m[2], a3 = m[3], a4 = m[4], a5 = m[5], a6 = m[6], a7 = m[7], a8 = m[8];
+    const double c0 = a4 * a8 - a5 * a7, c1 = a2 * a7 - a1 * a8, c2 = a1 * a5 - a2 * a4;
+    const double c3 = a5 * a6 - a3 * a8, c4 = a0 * a8 - a2 * a6, c5 = a2 * a3 - a0 * a5;
+    const double c6 = a3 * a7 - a4 * a6, c7 = a1 * a6 - a0 * a7, c8 = a0 * a4 - a1 * a3;
+    double lo_x = 1e30, hi_x = -1e30, lo_y = 1e30, hi_y = -1e30;
+    int sign = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double sx = qx + ((k & 1) ? 1.0 : -1.0), sy = qy + ((k & 2) ? 1.0 : -1.0);
+        const double nx = align_corners ? 2.0 * sx / (Ws - 1) - 1.0 : (2.0 * sx + 1.0) / Ws - 1.0;
+        const double ny = align_corners ? 2.0 * sy / (Hs - 1) - 1.0 : (2.0 * sy + 1.0) / Hs - 1.0;
+        const double X = c0 * nx + c1 * ny + c2, Y = c3 * nx + c4 * ny + c5, Z = c6 * nx + c7 * ny + c8;
+        const int sg = Z > 0.0 ? 1 : -1;
+        if (k == 0) sign = sg;
+        if (sg != sign || !(fabs(Z) > 1e-12)) bad = true;
+        const double px = (X / Z * 0.5 + 0.5) * (Wd - 1), py = (Y / Z * 0.5 + 0.5) * (Hd - 1);
+        lo_x = fmin(lo_x, px); hi_x = fmax(hi_x, px); lo_y = fmin(lo_y, py); hi_y = fmax(hi_y, py);
+    }
+    if (!(lo_x == lo_x && hi_x == hi_x && lo_y == lo_y && hi_y == hi_y)) bad = true;
+    int px0 = 0, px1 = -1, py0 = 0, py1 = -1;
+    if (!bad) {
+        // (the box of the quadrilateral already holds every p with s(p) in the open square; the pad only has to cover the difference between
+        // this float64 inverse and the forward's float32 evaluation of s: ~1e-4 pixels at these picture sizes)
+        const double pad = 0.05;
+        const double fx0 = fmax(lo_x - pad, -1.0), fx1 = fmin(hi_x + pad, (double)Wd), fy0 = fmax(lo_y - pad, -1.0), fy1 = fmin(hi_y + pad, (double)Hd);
+        px0 = (int)ceil(fx0); px1 = (int)floor(fx1); py0 = (int)ceil(fy0); py1 = (int)floor(fy1);
+        px0 = px0 < 0 ? 0 : px0; py0 = py0 < 0 ? 0 : py0;
+        px1 = px1 > Wd - 1 ? Wd - 1 : px1; py1 = py1 > Hd - 1 ? Hd - 1 : py1;
+        if (px1 >= px0 && py1 >= py0 && (long)(px1 - px0 + 1) * (py1 - py0 + 1) > WG_BOX) bad = true;
+    }
+    int mp[WG_MAX];
+    float mwx[WG_MAX], mwy[WG_MAX];
+#pragma unroll
+    for (int k = 0; k < WG_MAX; ++k) { mp[k] = 0; mwx[k] = 0.0f; mwy[k] = 0.0f; }
+    int nm = 0;
+    if (!bad) {
+        for (int oy = py0; oy <= py1; ++oy) {
+            const float gy = __fmul_rn(__fsub_rn(__fdiv_rn((float)oy, (float)(Hd - 1)), 0.5f), 2.0f);
+            for (int ox = px0; ox <= px1; ++ox) {
+                const float gx = __fmul_rn(__fsub_rn(__fdiv_rn((float)ox, (float)(Wd - 1)), 0.5f), 2.0f);
+                const float X = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[0]), __fmul_rn(gy, m[1])), m[2]);
+                const float Y = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[3]), __fmul_rn(gy, m[4])), m[5]);
+                const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
+                const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
+                const float fx = masic_grid_unnormalize(__fmul_rn(X, scale), Ws, align_corners);
+                const float fy = masic_grid_unnormalize(__fmul_rn(Y, scale), Hs, align_corners);
+                if (!(fx == fx) || !(fy == fy)) continue;
+                const float x0f = floorf(fx), y0f = floorf(fy);
+                const float lim = 1.0e9f;
+                const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+                if ((qx != x0 && qx != x0 + 1) || (qy != y0 && qy != y0 + 1)) continue;
+                const float wx = fx - x0f, wy = fy - y0f;
+                if (nm == WG_MAX) { bad = true; break; }
+                const int pi = oy * Wd + ox;
+                const float vx = qx == x0 ? 1.0f - wx : wx, vy = qy == y0 ? 1.0f - wy : wy;
+#pragma unroll
+                for (int k = 0; k < WG_MAX; ++k)         // (static indices: the three lists stay in registers)
+                    if (k == nm) { mp[k] = pi; mwx[k] = vx; mwy[k] = vy; }
+                ++nm;
+            }
+            if (bad) break;
+        }
+    }
+    if (bad) {
+        *flag = 1;               // (benign race: every writer stores 1)
+        return;
+    }
+    const size_t splane = (size_t)Hs * Ws, dplane = (size_t)Hd * Wd;
+    const float* gb = g_dst + (size_t)b * C * dplane;
+    float* sb = g_src + (size_t)b * C * splane + q;
+    // the channel loop without branches: unused slots hold pixel 0 with weight 0, and the slot count is the wave's largest match count
+    // rounded up to 4 / 6 / 9 / 16 (near-identity homographies: 4) -- every load of a channel is in flight before the first use
+    int nmax = nm;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    if (nmax <= 4) warp_gather_channels<4>(gb, sb, mp, mwx, mwy, C, dplane, splane);
+    else if (nmax <= 6) warp_gather_channels<6>(gb, sb, mp, mwx, mwy, C, dplane, splane);
+    else if (nmax <= 9) warp_gather_channels<9>(gb, sb, mp, mwx, mwy, C, dplane, splane);
+    else warp_gather_channels<WG_MAX>(gb, sb, mp, mwx, mwy, C, dplane, splane);
+}
+__global__ __launch_bounds__(256) void zero_if_kernel(float* __restrict__ p, size_t n, const int* __restrict__ flag) {
+    if (*flag == 0) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.0f;
+}
+__global__ __launch_bounds__(256) void warp_bwd_if_kernel(const float* __restrict__ g_dst, const float* __restrict__ minv, float* __restrict__ g_src,
+                                                          int C, int Hs, int Ws, int Hd, int Wd, int align_corners, const int* __restrict__ flag) {
+    if (*flag == 0) return;
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hd * Wd) return;
+    const int oy = pix / Wd, ox = pix - oy * Wd;
+    const float* m = minv + b * 9;
+    const float gx = __fmul_rn(__fsub_rn(__fdiv_rn((float)ox, (float)(Wd - 1)), 0.5f), 2.0f);
+    const float gy = __fmul_rn(__fsub_rn(__fdiv_rn((float)oy, (float)(Hd - 1)), 0.5f), 2.0f);
+    const float X = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[0]), __fmul_rn(gy, m[1])), m[2]);
+    const float Y = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[3]), __fmul_rn(gy, m[4])), m[5]);
+    const float Z = __fadd_rn(__fadd_rn(__fmul_rn(gx, m[6]), __fmul_rn(gy, m[7])), m[8]);
+    const float scale = fabsf(Z) > 1e-8f ? __fdiv_rn(1.0f, __fadd_rn(Z, 1e-8f)) : 1.0f;
+    const float fx = masic_grid_unnormalize(__fmul_rn(X, scale), Ws, align_corners);
+    const float fy = masic_grid_unnormalize(__fmul_rn(Y, scale), Hs, align_corners);
+    if (!(fx == fx) || !(fy == fy)) return;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
+    const float lim = 1.0e9f;
+    const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Ws, vx1 = x1 >= 0 && x1 < Ws, vy0 = y0 >= 0 && y0 < Hs, vy1 = y1 >= 0 && y1 < Hs;
+    const size_t splane = (size_t)Hs * Ws, dplane = (size_t)Hd * Wd;
+    for (int c = 0; c < C; ++c) {
+        const float g = g_dst[((size_t)b * C + c) * dplane + pix];
+        float* s = g_src + ((size_t)b * C + c) * splane;
+        if (vx0 && vy0) atomicAdd(s + (size_t)y0 * Ws + x0, g * ex * ey);
+        if (vx1 && vy0) atomicAdd(s + (size_t)y0 * Ws + x1, g * wx * ey);
+        if (vx0 && vy1) atomicAdd(s + (size_t)y1 * Ws + x0, g * ex * wy);
+        if (vx1 && vy1) atomicAdd(s + (size_t)y1 * Ws + x1, g * wx * wy);
+    }
+}
+
 }  // namespace
 
 extern "C" int masic_elementwise(const float* a, const float* b, float* y, size_t n, int op, float s0, float s1, void* stream) {
@@ -777,6 +945,21 @@ extern "C" int masic_entropy_bottleneck_aux_step(const float* const* params, con
     hipLaunchKernelGGL(eb_aux_fused_kernel, dim3(ceil_div(pitch, 256), n), dim3(256), 0, st, a, workspace, pitch);
     hipLaunchKernelGGL(eb_aux_sum_kernel, dim3(1), dim3(256), 0, st, a, (const float*)workspace, pitch, loss);
     return masic_launch_status("entropy_bottleneck_aux_step");
+}
+
+// The gather form (see warp_bwd_gather_kernel): g_src needs NO zero fill; flag: one int32 on the device, zero on entry (set when some
+// pixel's footprint was outside the gather form's bounds -- the scatter form has then redone the whole tensor, still inside this call).
+extern "C" int masic_warp_perspective_bwd_gather(const float* g_dst, const float* minv_norm, float* g_src, int* flag,
+                                                 int B, int C, int Hs, int Ws, int Hd, int Wd, void* stream) {
+    MASIC_REQUIRE(g_dst && minv_norm && g_src && flag, MASIC_ERR_ARG, "warp_perspective_bwd_gather: null pointer");
+    MASIC_REQUIRE(B > 0 && C > 0 && Hs > 1 && Ws > 1 && Hd > 1 && Wd > 1, MASIC_ERR_SHAPE, "warp_perspective_bwd_gather: sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int ac = masic_warp_align_corners_value();
+    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3(ceil_div(Hs * Ws, 256), B), dim3(256), 0, st, g_dst, minv_norm, g_src, flag, C, Hs, Ws, Hd, Wd, ac);
+    const size_t n = (size_t)B * C * Hs * Ws;
+    hipLaunchKernelGGL(zero_if_kernel, dim3(grid_for(n)), dim3(256), 0, st, g_src, n, (const int*)flag);
+    hipLaunchKernelGGL(warp_bwd_if_kernel, dim3(ceil_div(Hd * Wd, 256), B), dim3(256), 0, st, g_dst, minv_norm, g_src, C, Hs, Ws, Hd, Wd, ac, (const int*)flag);
+    return masic_launch_status("warp_perspective_bwd_gather");
 }
 
 extern "C" int masic_warp_perspective_bwd(const float* g_dst, const float* minv_norm, float* g_src,

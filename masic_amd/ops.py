@@ -746,13 +746,25 @@ def entropy_bottleneck_auxloss_bwd(table, quantiles, gout, tail_mass=1e-9):
     return g_q
 
 
-def warp_perspective_bwd(g_dst, minv_norm, src_shape):
+_WARP_BWD_GATHER = _os.environ.get("MASIC_WARP_BWD_GATHER", "1") != "0"      # 0: the scatter form (float atomics) always (A/B timing)
+
+
+def warp_perspective_bwd(g_dst, minv_norm, src_shape, want_flag=False):
+    """d loss / d src of warp_perspective.  Default: the gather form (masic_warp_perspective_bwd_gather: no atomics, reproducible, no zero
+    fill), which falls back to the scatter form on the device when the homography is outside its bounds; want_flag: also return the int32
+    device flag that says it did."""
     _dev(g_dst); _dev(minv_norm)
     B, C, Hs, Ws = src_shape
     Hd, Wd = g_dst.shape[-2:]
+    if _WARP_BWD_GATHER and min(Hs, Ws, Hd, Wd) > 1:
+        g_src = torch.empty(src_shape, dtype=torch.float32, device=g_dst.device)
+        flag = torch.empty(1, dtype=torch.int32, device=g_dst.device).fill_(0)
+        check(lib.masic_warp_perspective_bwd_gather(_p(g_dst), _p(minv_norm), _p(g_src), _p(flag), B, C, Hs, Ws, Hd, Wd, _stream()),
+              "warp_perspective_bwd_gather")
+        return (g_src, flag) if want_flag else g_src
     g_src = zeros(src_shape, torch.float32, g_dst.device)
     check(lib.masic_warp_perspective_bwd(_p(g_dst), _p(minv_norm), _p(g_src), B, C, Hs, Ws, Hd, Wd, _stream()), "warp_perspective_bwd")
-    return g_src
+    return (g_src, None) if want_flag else g_src
 
 
 # --------------------------------------------------------------------------------------------- bf16 1x1 GEMM stacks

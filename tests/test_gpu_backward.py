@@ -710,6 +710,15 @@ def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
             load_noise(it)
             crit, aux = train.train_step(net_e, opt, aopt, *batches[it], 0.01)
             want.append((float(crit["loss"]), float(aux), float(crit["psnr1"])))
+        # eager once more: what two runs of the SAME path differ by after three Adam steps (float atomics; Adam turns a sign flip of a
+        # near-zero gradient element into a full +-lr step, so small, noisy tensors -- the last hyper-analysis layer sees a 2 x 2 output at
+        # this picture size -- move by ~10 % of their three-step update from run to run)
+        net_e2 = fresh()
+        opt2 = torch.optim.Adam(list(net_e2.parameters()), lr=1e-4, capturable=True, fused=True)
+        aopt2 = torch.optim.Adam(list(net_e2.aux_parameters()), lr=1e-3, capturable=True, fused=True)
+        for it in range(3):
+            load_noise(it)
+            train.train_step(net_e2, opt2, aopt2, *batches[it], 0.01)
         # graphed
         net_g = fresh()
         load_noise(0)
@@ -725,9 +734,16 @@ def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
         for w, g in zip(want, got):
             for a, b in zip(w, g):
                 assert abs(a - b) <= 5e-4 * abs(a) + 1e-6, (want, got)      # (float atomics in the weight gradients: run-to-run differences, amplified by Adam over three steps -- measured up to 2.1e-4 on the third)
-        for (n, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
-            de, dg = (pe.detach().cpu() - sd0[n]).double(), (pg.detach().cpu() - sd0[n]).double()
-            assert float((de - dg).norm()) <= 0.1 * float(de.norm()) + 1e-12, (n, float((de - dg).norm()), float(de.norm()))
+        worst_floor = 0.0
+        for (n, pe), (_, pg), (_, p2) in zip(net_e.named_parameters(), net_g.named_parameters(), net_e2.named_parameters()):
+            de, dg, d2 = ((q.detach().cpu() - sd0[n]).double() for q in (pe, pg, p2))
+            floor = float((de - d2).norm()) / (float(de.norm()) + 1e-30)
+            worst_floor = max(worst_floor, floor)
+            # (0.2: two eager runs are bit-identical most of the time and up to 0.07 apart when the atomics land in another order; the replay,
+            # with its own timing, was measured up to 0.11 from the eager run on that layer; a stale pack or a misordered node moves whole
+            # tensors by O(1))
+            assert float((de - dg).norm()) <= max(0.2, 3.0 * floor) * float(de.norm()) + 1e-12, (n, float((de - dg).norm()), float(de.norm()), floor)
+        print(f"largest eager-vs-eager difference of a tensor's three-step update: {worst_floor:.3f} of its norm")
         # the model still works eagerly after replays: its pack caches must not serve the packs of the capture
         net_g.eval()
         net_e.eval()
@@ -975,3 +991,58 @@ def test_two_stream_training_forward_is_the_one_stream_computation():
         EntropyModel._get_noise_cached = orig
         MASIC._TRAIN_STREAMS = prev
         mnn.set_precision("f32")
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "identity", "rotation", "magnify", "minify", "strong_minify", "strong_magnify", "horizon", "to_smaller"])
+def test_warp_backward_gather_form_is_the_adjoint(kind):
+    """masic_warp_perspective_bwd_gather against autograd through the oracle's kornia.warp_perspective restatement (reference
+    MASIC.py:781) and against the scatter form: the synthetic pairs, identity, a 12 degree rotation, 1.5 x magnification, 0.6 x and 0.2 x
+    minification stay on the gather path (flag 0); 4 x magnification (~64 destination pixels reach every source pixel) and a horizon
+    inside the picture raise the flag and come out of the device-side scatter fallback -- the same values either way.  Also a destination
+    of another size."""
+    import math
+    from masic_amd import ops, synth
+    from masic_amd.homography import warp_matrices
+    B, C, H, W = 2, 5, 48, 64
+    Hd, Wd = (H, W) if kind != "to_smaller" else (32, 40)
+    x, _, hm = synth.synth_inputs(B, H, W, seed=14)
+    x = torch.cat([x, x[:, :2] * 0.5], 1)
+    cx, cy = (W - 1) / 2, (H - 1) / 2
+
+    def about_centre(a, b_, c, d):         # [[a, b], [c, d]] about the picture centre
+        return torch.tensor([[a, b_, cx - a * cx - b_ * cy], [c, d, cy - c * cx - d * cy], [0.0, 0.0, 1.0]])
+    if kind == "identity":
+        hm = torch.eye(3).repeat(B, 1, 1)
+    elif kind == "rotation":
+        t = math.radians(12)
+        hm = about_centre(math.cos(t), -math.sin(t), math.sin(t), math.cos(t)).repeat(B, 1, 1)
+    elif kind == "magnify":
+        hm = about_centre(1.5, 0.0, 0.0, 1.5).repeat(B, 1, 1)
+    elif kind == "minify":
+        hm = about_centre(0.6, 0.0, 0.0, 0.6).repeat(B, 1, 1)
+    elif kind == "strong_minify":
+        hm = about_centre(0.2, 0.0, 0.0, 0.2).repeat(B, 1, 1)
+    elif kind == "strong_magnify":
+        hm = about_centre(4.0, 0.0, 0.0, 4.0).repeat(B, 1, 1)
+    elif kind == "horizon":
+        hm = torch.eye(3).repeat(B, 1, 1)
+        hm[:, 2, 0] = -1.0 / 40.0           # w = 1 - x / 40 changes sign inside the picture
+    elif kind == "to_smaller":
+        hm = hm.clone()
+        hm[:, :2] *= 0.6
+    xr = x.clone().requires_grad_(True)
+    yr = O.warp_perspective(xr, hm, (Hd, Wd))
+    go = _rand(*yr.shape, seed=15)
+    yr.backward(go)
+    m, _ = warp_matrices(hm.to(DEV), (H, W), (Hd, Wd))
+    g = go.to(DEV).contiguous()
+    got, flag = ops.warp_perspective_bwd(g, m, (B, C, H, W), want_flag=True)
+    ref = ops.zeros((B, C, H, W), torch.float32, DEV)
+    ops.check(ops.lib.masic_warp_perspective_bwd(ops._p(g), ops._p(m), ops._p(ref), B, C, H, W, Hd, Wd, ops._stream()), "warp_perspective_bwd")
+    fell_back = bool(int(flag.item()))
+    print(f"{kind}: gather form {'fell back to the scatter form' if fell_back else 'used'}; max |gather - scatter| = {float((got - ref).abs().max()):.3e}, "
+          f"max |gather - oracle| = {float((got.cpu() - xr.grad).abs().max()):.3e}, max |oracle| = {float(xr.grad.abs().max()):.3e}")
+    assert fell_back == (kind in ("strong_magnify", "horizon")), (kind, fell_back)
+    assert_close(got, ref.cpu(), "warp gather vs scatter", 2e-5)
+    if kind != "horizon":                   # (on the horizon the sampling points are unbounded: the oracle's float32 grid and ours agree only off it)
+        assert_close(got, xr.grad, "warp gather vs oracle autograd", GTOL)
