@@ -48,13 +48,11 @@ class EntropyModel(nn.Module):
         raise NotImplementedError()
 
     def _get_noise_cached(self, x):
-        """One cached buffer per module, redrawn from the device's global generator on every call
-        (reference :89-96) -- keeps the training-mode draw order of SURVEY.md appendix D."""
-        if not hasattr(self, "_noise"):
-            setattr(self, "_noise", x.new(x.size()))
-        self._noise.resize_(x.size())
-        self._noise.uniform_(-0.5, 0.5)
-        return self._noise
+        """U(-1/2, 1/2) of x's shape from the device's global generator, one draw per call in call order (reference :89-96: one cached
+        buffer per module, refilled by every call -- the draw order of SURVEY.md appendix D is what parity depends on, not the buffer).
+        A FRESH tensor per call: gaussian1 serves three draws of a training forward, and with the entropy chains on side streams
+        (HSIC._forward_graph) a refill of a shared buffer on one stream would race the previous draw's reader on another."""
+        return x.new_empty(x.size()).uniform_(-0.5, 0.5)
 
     def _quantize(self, inputs, mode, means=None):
         if mode not in ("noise", "dequantize", "symbols"):
@@ -375,6 +373,13 @@ class GaussianMixtureConditional(_GaussianBase):
                                      self.K, training=True, noise=torch.zeros_like(inputs),
                                      scale_bound=self._scale_bound_value, lik_bound=0.0)
         return lik
+
+    def likelihood_of(self, y_hat, scales, means, weights, weights_are_logits=False):
+        """Training mode, differentiable: the likelihood of an ALREADY quantised latent (y + noise drawn by the caller through
+        `_quantize(y, "noise")`, at the position of this module's draw in the reference's order): forward() without its draw."""
+        from masic_amd import autograd as A
+        lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        return A.GmmLikFn.apply(y_hat, scales, means, weights, self.K, self._scale_bound_value, lb, bool(weights_are_logits))
 
     def forward(self, inputs, scales, means=None, weights=None, weights_are_logits=False):
         noise = self._get_noise_cached(inputs) if self.training else None

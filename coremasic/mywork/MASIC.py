@@ -706,20 +706,28 @@ class HSIC(CompressionModel):
         from masic_amd import nn as _mnn
         m_fwd, m_back = _warp_matrices(h_matrix, (H, W), (H, W), want_inverse=True, device=_mnn.reduced_precision())
         y1 = self.encoder1.latent_train(x1)
-        z1 = self._h_a1(y1)
-        z1_hat, z1_lik = self.entropy_bottleneck1(z1)                                   # draw 1
-        params1 = self._hyper_up(self.h_s1_up, z1_hat, None, 0)
-        ctx1 = self.context_prediction1.run(self.gaussian1._quantize(y1, "noise"))     # draw 2
-        s1, m1, l1 = self._h_s1_same_resolution.heads(_ag.cat(params1, ctx1))
-        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, l1, weights_are_logits=True)       # draw 3
+        # Two branches of the step need nothing of the main chain (encoder1 -> y1 + noise -> decoder1 -> warp -> encoder1 -> heads2 ->
+        # decoder2) until late: the left view's entropy chain (only its likelihoods leave it) and the right view up to its entropy
+        # parameters.  With MASIC_TRAIN_STREAMS each is ISSUED where the reference has it -- the noise draws are numbered by the host --
+        # but on a side stream of its own, beside the main stream's work; autograd runs every node's backward on the stream of its
+        # forward, so their backward passes run beside the main chain's too.  (Not inside a HIP-graph capture: one stream there.)
+        fj = _ForkJoin()
+        side = _side_streams(x1.device) if (_TRAIN_STREAMS and not torch.cuda.is_current_stream_capturing()) else None
+        sA, sE = (side[0], side[1]) if side is not None else (fj.main, fj.main)
+        fj.fork(sE)
+        with fj.on(sE):
+            z1 = self._h_a1(y1)
+            z1_hat, z1_lik = self.entropy_bottleneck1(z1)                                   # draw 1
+            params1 = self._hyper_up(self.h_s1_up, z1_hat, None, 0)
+            ctx1 = self.context_prediction1.run(self.gaussian1._quantize(y1, "noise"))     # draw 2
+            s1, m1, l1 = self._h_s1_same_resolution.heads(_ag.cat(params1, ctx1))
+        # gaussian1(y1, s1, m1, l1) of the reference (:767) in its two halves: the draw here, the likelihood beside the synthesis transform
+        y1_hat = self.gaussian1._quantize(y1, "noise")                                      # draw 3
+        fj.fork(sE)
+        with fj.on(sE):
+            y1_lik = self.gaussian1.likelihood_of(y1_hat, s1, m1, l1, weights_are_logits=True)
         x1_hat = self.decoder1.reconstruct_train(y1_hat)
 
-        # The right view up to its entropy parameters needs nothing of the left view: with MASIC_TRAIN_STREAMS it is ISSUED here, in the
-        # reference's order (the noise draws are numbered by the host), but on a side stream, next to the main stream's backlog and to the
-        # left reconstruction's second analysis pass -- and autograd runs every node's backward on the stream of its forward, so the
-        # backward of this branch runs beside the left view's too.
-        fj = _ForkJoin()
-        sA = _side_streams(x1.device)[0] if (_TRAIN_STREAMS and not torch.cuda.is_current_stream_capturing()) else fj.main
         fj.fork(sA)
         with fj.on(sA):
             x1_warp = _hip.warp_perspective(x1, m_fwd, (H, W))
@@ -744,6 +752,11 @@ class HSIC(CompressionModel):
         s2, m2, l2 = self._h_s2_same_resolution.heads(cat2)
         y2_hat, y2_lik = self.gaussian2(y2, s2, m2, l2, weights_are_logits=True)       # draw 7
         x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        if fj.join(sE) is not None:
+            for t in (y1, y1_hat):
+                _keep_until(t, sE)
+            for t in (y1_lik, z1_lik, z1_hat):
+                _keep_until(t, fj.main)
         return {
             "x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "z1_hat": z1_hat,
             "x1_mask_R": x1_mask_R, "x1_mask_L": x1_mask_L,

@@ -376,6 +376,8 @@ int masic_entropy_bottleneck_auxloss(const float* params, const float* quantiles
  * weights_are_logits=1 fuses the softmax over K of MASIC.py:389-393/459-464 into the kernel
  * (wts then holds the raw gmm_weights head output, and wts_out, if non-NULL, receives the
  * normalised weights).
+ * training: 0 round(y), 1 y + noise, 2 y is the quantised latent already -- likelihood only, y_hat may be NULL
+ * (the training forward draws y + noise where the reference does and evaluates the likelihood beside the synthesis transform).
  */
 int masic_gmm_likelihood_fwd(const float* y, const float* noise, const float* sigma, const float* mu,
                              const float* wts, float* y_hat, float* lik, float* wts_out,

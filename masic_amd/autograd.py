@@ -350,6 +350,26 @@ class GmmFn(Function):
         return g_y, None, g_s, g_m, g_w, None, None, None, None
 
 
+class GmmLikFn(Function):
+    """The likelihood half of GmmFn: (y_hat, sigma, mu, weights) -> likelihood, y_hat = y + noise drawn by the caller (AddNoiseFn) where the
+    reference draws it.  Same kernels, same gradients (d lik / d y reaches y through y_hat either way); split so that the synthesis
+    transform, which needs y_hat only, does not wait for the entropy parameters (HSIC._forward_graph)."""
+
+    @staticmethod
+    def forward(ctx, y_hat, sigma, mu, logits, K, scale_bound, lik_bound, are_logits=True):
+        y_hat, sigma, mu, logits = _c(y_hat), _c(sigma), _c(mu), _c(logits)
+        _, lik = ops.gmm_likelihood(y_hat, sigma, mu, logits, K, training=2, weights_are_logits=are_logits, scale_bound=scale_bound, lik_bound=lik_bound)
+        ctx.K, ctx.sb, ctx.lb, ctx.are_logits = K, scale_bound, lik_bound, bool(are_logits)
+        ctx.save_for_backward(y_hat, sigma, mu, logits)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g_lik):
+        y_hat, sigma, mu, logits = ctx.saved_tensors
+        g_y, g_s, g_m, g_w = ops.gmm_likelihood_bwd(y_hat, sigma, mu, logits, _c(g_lik), None, ctx.K, ctx.are_logits, ctx.sb, ctx.lb)
+        return g_y, g_s, g_m, g_w, None, None, None, None
+
+
 class AddNoiseFn(Function):
     """_quantize(x, 'noise'): x + U(-1/2,1/2); identity gradient."""
 

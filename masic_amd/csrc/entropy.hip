@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
     const size_t base = ((size_t)b * K * M + m) * HW + p;    // component k at + k*M*HW
     const size_t kstride = (size_t)M * HW;
     float yv = y[i];
-    yv = training ? yv + noise[i] : rintf(yv);
+    yv = training == 1 ? yv + noise[i] : (training == 2 ? yv : rintf(yv));      // 2: y IS the quantised latent (likelihood only)
     float wk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) wk[k] = wts[base + k * kstride];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
         const float term = __fmul_rn(up - lo, wk[k]);
         l = (k == 0) ? term : __fadd_rn(l, term);
     }
-    y_hat[i] = yv;
+    if (y_hat != nullptr) y_hat[i] = yv;
     lik[i] = fmaxf(l, lik_bound);
 }
 
@@ -256,8 +256,9 @@ extern "C" int masic_gmm_likelihood_fwd(const float* y, const float* noise, cons
                                         const float* wts, float* y_hat, float* lik, float* wts_out,
                                         int B, int M, int K, int H, int W, int training, int weights_are_logits,
                                         float scale_bound, float lik_bound, void* stream) {
-    MASIC_REQUIRE(y && sigma && mu && wts && y_hat && lik, MASIC_ERR_ARG, "gmm_likelihood_fwd: null pointer");
-    MASIC_REQUIRE(!training || noise, MASIC_ERR_ARG, "gmm_likelihood_fwd: training without noise");
+    MASIC_REQUIRE(y && sigma && mu && wts && lik && (y_hat || training == 2), MASIC_ERR_ARG, "gmm_likelihood_fwd: null pointer");
+    MASIC_REQUIRE(training >= 0 && training <= 2, MASIC_ERR_ARG, "gmm_likelihood_fwd: training = %d", training);
+    MASIC_REQUIRE(training != 1 || noise, MASIC_ERR_ARG, "gmm_likelihood_fwd: training without noise");
     MASIC_REQUIRE(K >= 1 && K <= 8, MASIC_ERR_UNSUPPORTED, "gmm_likelihood_fwd: K=%d", K);
     const size_t total = (size_t)B * M * H * W;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);

@@ -309,16 +309,20 @@ def gmm_likelihood(y, sigma, mu, wts, K, training=False, noise=None, weights_are
     for t, n in ((sigma, "sigma"), (mu, "mu"), (wts, "weights")):
         if tuple(t.shape) != (B, K * M, H, W):
             raise RuntimeError(f"masic_amd.gmm_likelihood: {n} {tuple(t.shape)} != {(B, K * M, H, W)}")
-    if training:
+    if training == 2:            # y is the quantised latent: likelihood only (y_hat = y, nothing written)
+        noise = None
+    elif training:
         _dev(noise, "noise")
         if noise.numel() != y.numel():
             raise RuntimeError("masic_amd.gmm_likelihood: noise size mismatch")
-    y_hat = torch.empty_like(y)
+    y_hat = torch.empty_like(y) if training != 2 else None
     lik = torch.empty_like(y)
     wout = torch.empty_like(wts) if (weights_are_logits and want_weights) else None
     check(lib.masic_gmm_likelihood_fwd(_p(y), _p(noise), _p(sigma), _p(mu), _p(wts), _p(y_hat), _p(lik), _p(wout),
                                        B, M, K, H, W, int(training), int(weights_are_logits),
                                        float(scale_bound), float(lik_bound), _stream()), "gmm_likelihood_fwd")
+    if training == 2:
+        y_hat = y
     return (y_hat, lik, wout) if want_weights else (y_hat, lik)
 
 

@@ -936,8 +936,9 @@ def test_fused_transform_training_nodes_vs_float32_graph(which, monkeypatch):
 
 
 def test_two_stream_training_forward_is_the_one_stream_computation():
-    """HSIC._forward_graph issues the right view's front part (warp, encoder2, h_a2, EB2, h_s2_up, context model 2, masks, gates) on a
-    side stream; autograd runs each node's backward on its forward's stream.  Same noise draws in host order, same kernels: outputs and
+    """HSIC._forward_graph issues the right view's front part (warp, encoder2, h_a2, EB2, h_s2_up, context model 2, masks, gates) and the
+    left view's entropy chain (h_a1, EB1, h_s1_up, context model 1, heads, mixture likelihood) on side streams; autograd runs each
+    node's backward on its forward's stream.  Same noise draws in host order, same kernels: outputs and
     all 166 gradients must agree with the one-stream schedule to the run-to-run floor of the float atomics, every time (a workspace shared
     by two streams' kernels -- the GDN backward's partial sums were, once -- shows as an occasional O(1) difference)."""
     import MASIC

@@ -73,10 +73,19 @@ def test_first_training_steps_from_default_init_match_the_oracle_loop():
     optimizer, aux_optimizer = make_optimizers(net, fused=False)
     got = []
     d1, d2, h = x1.to(DEV), x2.to(DEV), hm.to(DEV)
-    for it in range(5):
-        with _noise_ctx([noises[it][k].to(DEV) for k in O.NOISE_KEYS]):
-            crit, aux = train_step(net, optimizer, aux_optimizer, d1, d2, h, LMBDA)
-        got.append((float(crit["loss"]), float(aux)))
+    # On ONE stream: the float32 step is then bit-reproducible (five runs: identical losses) and the comparison is with the oracle alone.
+    # With the side streams of HSIC._forward_graph the float atomics of the weight gradients land in another order from run to run --
+    # gradients agree to 5e-7 (test_two_stream_training_forward_is_the_one_stream_computation) -- and Adam, whose first update is
+    # lr * sign(g) for every element, turns the sign of the few elements with |g| below that noise into +-2 lr: the losses then agree to
+    # 1e-7 on steps 1-2, 1e-6 on step 3 and 1e-4 on step 5 (measured, tools/scratch/first_steps_var.py), which says nothing about parity.
+    prev_streams, MASIC._TRAIN_STREAMS = MASIC._TRAIN_STREAMS, False
+    try:
+        for it in range(5):
+            with _noise_ctx([noises[it][k].to(DEV) for k in O.NOISE_KEYS]):
+                crit, aux = train_step(net, optimizer, aux_optimizer, d1, d2, h, LMBDA)
+            got.append((float(crit["loss"]), float(aux)))
+    finally:
+        MASIC._TRAIN_STREAMS = prev_streams
     print("first steps from default init, (loss, aux): oracle", [f"{a:.4f}/{b:.2f}" for a, b in ref], "| HIP f32", [f"{a:.4f}/{b:.2f}" for a, b in got])
     assert ref[-1][0] < 0.95 * ref[0][0]                   # the steps do move the loss (train_log.txt: 35.6 -> 15.8 in ten at batch 1)
     for it, ((lr_, ar), (lg, ag)) in enumerate(zip(ref, got)):

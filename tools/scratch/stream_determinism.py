@@ -19,7 +19,7 @@ def static_noise(self, x):
     t = slots[state["i"] % len(slots)]; state["i"] += 1
     return t.reshape(x.shape)
 EntropyModel._get_noise_cached = static_noise
-mnn.set_precision("bf16")
+mnn.set_precision(os.environ.get("SD_PREC", "bf16"))
 net = MASIC.HSIC(N, M, K); net.load_state_dict(sd0); net = net.cuda().train()
 def grads(streams):
     MASIC._TRAIN_STREAMS = streams
