@@ -74,9 +74,47 @@ def conv_out_hw(Hi, Wi, KH, KW, stride, pad, transposed):
     return ((Hi + 2 * pad - KH) // stride + 1, (Wi + 2 * pad - KW) // stride + 1)
 
 
-def make_conv_desc(B, Cin, Hi, Wi, Cout, KH, KW, stride, pad, transposed=False, masked=False,
-                   in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, in_op=INOP_NONE, act=ACT_NONE,
-                   gate_ctot=0, gate_c=0, prec=_lib.PREC_F32):
+# ---- host cost.  A training step makes ~620 calls through the C ABI of which ~290 launch nothing: "is this shape supported", "how many
+# bytes does the pack / workspace take" -- 2-3 us each through ctypes, and with the side streams of the training forward the step is bound
+# by the host's launch rate.  Descriptors are therefore interned (one immutable ConvDesc per argument tuple: nothing in the package writes
+# to a descriptor after it is made), the answers to descriptor queries are kept on the descriptor object, and the pure-integer size
+# queries are lru-cached.
+_DESC_CACHE = {}
+
+
+def make_conv_desc(*args, **kw):
+    key = (args, tuple(sorted(kw.items()))) if kw else args
+    d = _DESC_CACHE.get(key)
+    if d is None:
+        if len(_DESC_CACHE) > 4096:
+            _DESC_CACHE.clear()
+        d = _DESC_CACHE[key] = _make_conv_desc(*args, **kw)
+    return d
+
+
+def _desc_query(name, desc):
+    """lib.<name>(&desc) for a query without side effects, answered once per descriptor object."""
+    memo = desc.__dict__.get("_memo")
+    if memo is None:
+        memo = desc.__dict__["_memo"] = {}
+    v = memo.get(name)
+    if v is None:
+        v = memo[name] = getattr(lib, name)(ctypes.byref(desc))
+    return v
+
+
+import functools as _functools
+
+
+@_functools.lru_cache(maxsize=4096)
+def _int_query(name, *args):
+    """lib.<name>(ints...) for a pure size query."""
+    return getattr(lib, name)(*args)
+
+
+def _make_conv_desc(B, Cin, Hi, Wi, Cout, KH, KW, stride, pad, transposed=False, masked=False,
+                    in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, in_op=INOP_NONE, act=ACT_NONE,
+                    gate_ctot=0, gate_c=0, prec=_lib.PREC_F32):
     Ho, Wo = conv_out_hw(Hi, Wi, KH, KW, stride, pad, transposed)
     return ConvDesc(B=B, Cin=Cin, Hi=Hi, Wi=Wi, in_ctot=in_ctot if in_ctot is not None else Cin, in_coff=in_coff,
                     Cout=Cout, Ho=Ho, Wo=Wo, out_ctot=out_ctot if out_ctot is not None else Cout, out_coff=out_coff,
@@ -87,7 +125,7 @@ def make_conv_desc(B, Cin, Hi, Wi, Cout, KH, KW, stride, pad, transposed=False, 
 def pack_conv_weight(weight, desc):
     """Re-lays a Conv2d / ConvTranspose2d weight out as [phase-tap][ci][co] (include/masic_hip.h)."""
     _dev(weight, "weight")
-    nbytes = lib.masic_conv_packed_bytes(ctypes.byref(desc))
+    nbytes = _desc_query("masic_conv_packed_bytes", desc)
     if nbytes == 0:
         check(-1, "conv_packed_bytes")
     packed = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=weight.device)
@@ -528,7 +566,7 @@ def channel_sum(x, C=None, coff=0):
     C = ctot if C is None else C
     HW = x.numel() // (B * ctot)
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(lib.masic_channel_sum_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
+    ws = torch.empty(_int_query("masic_channel_sum_workspace_bytes", C) // 8, dtype=torch.float64, device=x.device)
     check(lib.masic_channel_sum(_p(x), _p(out), _p(ws), B, C, HW, ctot, coff, _stream()), "channel_sum")
     return out
 
@@ -648,7 +686,7 @@ def gdn_bwd_fused_ex(x, g, shape, beta, gamma, inverse=False, beta_min=1e-6, wan
 
 def conv2d_wgrad_b16_supported(desc):
     """True if conv2d_wgrad takes bf16 NCHW operands for this layer (the 5x5 stride-2 layers of the bf16 mode)."""
-    return bool(lib.masic_conv2d_wgrad_bf16in_supported(ctypes.byref(desc)))
+    return bool(_desc_query("masic_conv2d_wgrad_bf16in_supported", desc))
 
 
 def conv2d_wgrad(x, dy, desc, weight_shape):
@@ -666,7 +704,7 @@ def conv2d_wgrad(x, dy, desc, weight_shape):
     if tuple(x.shape) != (desc.B, desc.in_ctot, desc.Hi, desc.Wi):
         raise RuntimeError(f"masic_amd.conv2d_wgrad: x {tuple(x.shape)} does not match the descriptor")
     dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
-    nbytes = lib.masic_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    nbytes = _desc_query("masic_conv2d_wgrad_workspace_bytes", desc)
     if desc.Cin * desc.Cout * desc.KH * desc.KW != dw.numel() or nbytes < dw.numel() * 4:
         raise RuntimeError("masic_amd.conv2d_wgrad: weight shape does not match the descriptor")
     ws = _clean_workspace(x.device, nbytes // 4)       # (>= the weight: the few-channel 5x5 kernel keeps per-workgroup partials in it)
@@ -777,14 +815,14 @@ def nchw_to_f16k(x, C=None, coff=0, in_op=INOP_NONE):
     _dev(x, "x")
     B, ctot, H, W = x.shape
     C = ctot if C is None else C
-    y = torch.empty(lib.masic_f16k_bytes(B, C, H * W) // 2, dtype=torch.int16, device=x.device)
+    y = torch.empty(_int_query("masic_f16k_bytes", B, C, H * W) // 2, dtype=torch.int16, device=x.device)
     check(lib.masic_nchw_to_f16k_op(_p(x), _p(y), B, C, H * W, ctot, coff, int(in_op), _stream()), "nchw_to_f16k")
     return y
 
 
 def pack_gemm1x1_weight(weight, Cin, Cout, transposed):
     _dev(weight, "weight")
-    wp = torch.empty(lib.masic_gemm1x1_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    wp = torch.empty(_int_query("masic_gemm1x1_packed_bytes", Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_gemm1x1_pack_weight(_p(weight), _p(wp), Cin, Cout, int(transposed), _stream()), "gemm1x1_pack_weight")
     return wp
 
@@ -798,7 +836,7 @@ def gemm1x1_bf16(x_f16k, wp, bias, B, Cin, Cout, H, W, act, out_nchw=None, out_c
         y32 = out_nchw if out_nchw is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_f16k.device)
         out_ctot = y32.shape[1]
     else:
-        y16 = torch.empty(lib.masic_f16k_bytes(B, Cout, HW) // 2, dtype=torch.int16, device=x_f16k.device)
+        y16 = torch.empty(_int_query("masic_f16k_bytes", B, Cout, HW) // 2, dtype=torch.int16, device=x_f16k.device)
     check(lib.masic_gemm1x1_bf16_fwd(_p(x_f16k), _p(wp), _p(bias), _p(y16), _p(y32), B, Cin, Cout, HW, out_ctot, out_coff, int(act), _stream()),
           "gemm1x1_bf16_fwd")
     return y32 if y32 is not None else y16
@@ -813,7 +851,7 @@ def f16k_to_nchw(y16, B, C, H, W):
 
 
 def conv_f16k_supported(desc):
-    return bool(lib.masic_conv_f16k_supported(ctypes.byref(desc)))
+    return bool(_desc_query("masic_conv_f16k_supported", desc))
 
 
 def pack_conv_f16k_weight(weight, desc, persistent=False):
@@ -823,7 +861,7 @@ def pack_conv_f16k_weight(weight, desc, persistent=False):
     _dev(weight, "weight")
     if persistent and _PACK_MULTI:
         return _stream_packs(weight.device).get(weight, desc)
-    nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+    nbytes = _desc_query("masic_conv_f16k_packed_bytes", desc)
     if nbytes == 0:
         check(-1, "conv_f16k_packed_bytes")
     packed = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
@@ -851,7 +889,7 @@ class StreamPacks:
         self.job_bytes = lib.masic_conv_f16k_pack_job_bytes()
 
     def _register(self, key, weight, desc):
-        nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+        nbytes = _desc_query("masic_conv_f16k_packed_bytes", desc)
         if nbytes == 0:
             check(-1, "conv_f16k_packed_bytes")
         out = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
@@ -929,7 +967,7 @@ def _stream_packs(device):
 def pack_gdn_f16k(beta, gamma, beta_min=1e-6):
     """A 128-channel GDN's stored parameters in the fragment order of conv_f16k's fused epilogue."""
     _dev(beta, "beta"); _dev(gamma, "gamma")
-    packed = torch.empty(lib.masic_gdn_f16k_packed_bytes() // 2, dtype=torch.int16, device=beta.device)
+    packed = torch.empty(_int_query("masic_gdn_f16k_packed_bytes") // 2, dtype=torch.int16, device=beta.device)
     check(lib.masic_gdn_pack_f16k(_p(beta), _p(gamma), _p(packed), beta.numel(), float(beta_min), _stream()), "gdn_pack_f16k")
     return packed
 
@@ -980,7 +1018,7 @@ def pack_conv_a_weight(weight):
     _dev(weight, "weight")
     if tuple(weight.shape) != (128, 3, 5, 5):
         raise RuntimeError("masic_amd.pack_conv_a_weight: the first-layer kernel is built for Conv2d(3, 128, 5, stride 2)")
-    packed = torch.empty(lib.masic_conv_a_packed_bytes() // 2, dtype=torch.int16, device=weight.device)
+    packed = torch.empty(_int_query("masic_conv_a_packed_bytes") // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_conv_a_pack_weight(_p(weight), _p(packed), _stream()), "conv_a_pack_weight")
     return packed
 
@@ -1045,7 +1083,7 @@ def conv5s1_pair(xa, xb, packed, bias, gdn_in=None, gdn_out=None, beta_min=1e-6)
 def pack_gemm_f16k_weights(jobs):
     """jobs: [(weight, Cin, Cout, transposed), ...] (<= 18) -> the packs pack_gemm_f16k_weight would make, in ONE launch."""
     n = len(jobs)
-    outs = [torch.empty(lib.masic_gemm_f16k_packed_bytes(ci, co) // 2, dtype=torch.int16, device=w.device) for w, ci, co, _ in jobs]
+    outs = [torch.empty(_int_query("masic_gemm_f16k_packed_bytes", ci, co) // 2, dtype=torch.int16, device=w.device) for w, ci, co, _ in jobs]
     for w, _, _, _ in jobs:
         _dev(w, "weight")
     W = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _, _ in jobs])
@@ -1057,7 +1095,7 @@ def pack_gemm_f16k_weights(jobs):
 
 def pack_gemm_f16k_weight(weight, Cin, Cout, transposed):
     _dev(weight, "weight")
-    wp = torch.empty(lib.masic_gemm_f16k_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    wp = torch.empty(_int_query("masic_gemm_f16k_packed_bytes", Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_gemm_f16k_pack_weight(_p(weight), _p(wp), Cin, Cout, int(transposed), _stream()), "gemm_f16k_pack_weight")
     return wp
 
@@ -1112,7 +1150,7 @@ def pack_skinny_ctx_weight(weight):
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (5, 5):
         raise RuntimeError("masic_amd.pack_skinny_ctx_weight: 5x5 kernels only")
-    out = torch.empty(lib.masic_skinny_ctx_packed_bytes(Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
+    out = torch.empty(_int_query("masic_skinny_ctx_packed_bytes", Cin, Cout) // 2, dtype=torch.int16, device=weight.device)
     check(lib.masic_skinny_ctx_pack_weight(_p(weight.contiguous()), _p(out), Cin, Cout, _stream()), "skinny_ctx_pack_weight")
     return out
 
@@ -1144,7 +1182,7 @@ def nchw_to_f8k(x, scale, C=None, coff=0, in_op=INOP_NONE):
     _dev(x, "x")
     B, ctot, H, W = x.shape
     C = ctot if C is None else C
-    y = torch.empty(lib.masic_f8k_bytes(B, C, H * W), dtype=torch.uint8, device=x.device)
+    y = torch.empty(_int_query("masic_f8k_bytes", B, C, H * W), dtype=torch.uint8, device=x.device)
     check(lib.masic_nchw_to_f8k(_p(x), _p(y), B, C, H * W, ctot, coff, int(in_op), 1.0 / float(scale), _stream()), "nchw_to_f8k")
     return y
 
@@ -1164,7 +1202,7 @@ def absmax(t, into=None):
 def pack_conv_f8k_weight(weight, desc):
     """-> (fp8 slab stream, per-output-channel weight scales [Cout]) for masic_conv_f8k_fwd (desc.prec = PREC_FP8)."""
     _dev(weight, "weight")
-    nbytes = lib.masic_conv_f16k_packed_bytes(ctypes.byref(desc))
+    nbytes = _desc_query("masic_conv_f16k_packed_bytes", desc)
     if nbytes == 0:
         check(-1, "conv_f8k_packed_bytes")
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
@@ -1234,7 +1272,7 @@ def conv_a_gdn_f8k(x, packed, bias, gdn, out_scale, in_coff=0):
 
 def pack_gemm_f8k_weight(weight, Cin, Cout, transposed):
     _dev(weight, "weight")
-    wp = torch.empty(lib.masic_gemm_f8k_packed_bytes(Cin, Cout), dtype=torch.uint8, device=weight.device)
+    wp = torch.empty(_int_query("masic_gemm_f8k_packed_bytes", Cin, Cout), dtype=torch.uint8, device=weight.device)
     ws = torch.empty(Cout, dtype=torch.float32, device=weight.device)
     check(lib.masic_gemm_f8k_pack_weight(_p(weight), _p(wp), _p(ws), Cin, Cout, int(transposed), _stream()), "gemm_f8k_pack_weight")
     return wp, ws
@@ -1372,7 +1410,7 @@ def pack_conv3x3_resident_weight(weight, transposed=False):
     _dev(weight, "weight")
     co, ci = weight.shape[:2]
     cin, cout = (co, ci) if transposed else (ci, co)
-    nbytes = lib.masic_conv3x3_resident_packed_bytes(cin, cout)
+    nbytes = _int_query("masic_conv3x3_resident_packed_bytes", cin, cout)
     if tuple(weight.shape[2:]) != (3, 3) or nbytes == 0:
         raise RuntimeError("masic_amd.pack_conv3x3_resident_weight: a 3x3 weight with a resident configuration (Cout 32 | 64, Cin <= Cout) expected")
     wp = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
@@ -1414,7 +1452,7 @@ def f16k_channel_sum(x16, B, C, HW):
     if x16.dtype != torch.int16 or C % 16 or x16.numel() != B * C * HW:
         raise RuntimeError("masic_amd.f16k_channel_sum: buffer does not match (B, C, HW), C % 16 == 0")
     out = torch.empty(C, dtype=torch.float32, device=x16.device)
-    ws = torch.empty(lib.masic_f16k_channel_sum_workspace_bytes(B, C) // 4, dtype=torch.float32, device=x16.device)
+    ws = torch.empty(_int_query("masic_f16k_channel_sum_workspace_bytes", B, C) // 4, dtype=torch.float32, device=x16.device)
     check(lib.masic_f16k_channel_sum(_p(x16), _p(out), _p(ws), B, C, HW, _stream()), "f16k_channel_sum")
     return out
 
@@ -1517,7 +1555,7 @@ def conv5x5_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:
         raise RuntimeError("masic_amd.conv5x5_wgrad_f16k: F16K buffer sizes do not match (B, C, H, W)")
     dw = torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x16.device)
-    n = lib.masic_conv5x5_wgrad_f16k_workspace_bytes(Cin, Cout) // 4
+    n = _int_query("masic_conv5x5_wgrad_f16k_workspace_bytes", Cin, Cout) // 4
     ws = _clean_workspace(x16.device, n)
     try:
         check(lib.masic_conv5x5_wgrad_f16k_ws(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, 1, _stream()), "conv5x5_wgrad_f16k")
@@ -1532,7 +1570,7 @@ def conv3x3_wgrad_f16k(x16, dy16, B, Cin, Cout, H, W):
     if x16.dtype != torch.int16 or dy16.dtype != torch.int16 or x16.numel() != B * Cin * H * W or dy16.numel() != B * Cout * H * W:
         raise RuntimeError("masic_amd.conv3x3_wgrad_f16k: F16K buffer sizes do not match (B, C, H, W)")
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x16.device)
-    n = lib.masic_conv3x3_wgrad_f16k_workspace_bytes(Cin, Cout) // 4
+    n = _int_query("masic_conv3x3_wgrad_f16k_workspace_bytes", Cin, Cout) // 4
     ws = _clean_workspace(x16.device, n)
     try:
         check(lib.masic_conv3x3_wgrad_f16k_ws(_p(x16), _p(dy16), _p(dw), _p(ws), B, Cin, Cout, H, W, 1, _stream()), "conv3x3_wgrad_f16k")

@@ -6,7 +6,7 @@ from masic_amd import synth, nn as mnn
 from masic_amd.train import make_optimizers, train_step
 mnn.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 net = MASIC.HSIC(128, 192, 5); net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100)); net = net.cuda().train()
-x1, x2, hm = (t.cuda() for t in synth.synth_inputs(int(os.environ.get("TRAIN_PROF_B", "8")), 512, 512, seed=100))
+x1, x2, hm = (t.cuda() for t in synth.synth_inputs(int(os.environ.get("TRAIN_PROF_B", "8")), int(os.environ.get("TRAIN_PROF_H", "512")), int(os.environ.get("TRAIN_PROF_H", "512")), seed=100))
 opt, aopt = make_optimizers(net, fused=os.environ.get("TRAIN_PROF_FUSED", "1") != "0")
 if os.environ.get("TRAIN_PROF_GRAPH"):            # the whole step as one HIP-graph replay (masic_amd/graph.py: GraphedTrainStep)
     from masic_amd.graph import GraphedTrainStep
