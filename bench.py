@@ -733,7 +733,7 @@ def main():
         net.train()
         optimizer, aux_optimizer = make_optimizers(net)
         reducer = GradientAllReducer(net) if world > 1 else None
-        for _ in range(2):                                                         # warm-up (weight packs of both kinds, optimizer state, allocator pools)
+        for _ in range(3):                                                         # warm-up (weight packs of both kinds, optimizer state, the allocator pools of the main and the two side streams)
             train_step(net, optimizer, aux_optimizer, x1, x2, hm, 0.01, reducer)
         barrier()
         t0 = time.perf_counter()

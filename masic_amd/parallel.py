@@ -63,6 +63,7 @@ class GradientAllReducer:
         self._got = set()
         self._need = [set(id(p) for p in b) for b in self.buckets]      # per bucket: expected ids whose gradient has not landed yet
         self._inflight = {}
+        self._events = [[] for _ in self.buckets]      # per bucket: events of the streams its gradients were produced on (see _on_grad)
         self._armed = False
         self._cancelled = False          # this step's overlap is off: every bucket is launched from finish()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -84,6 +85,7 @@ class GradientAllReducer:
             self._need = [set(id(p) for p in b if id(p) in self._expected) for b in self.buckets]
         self._got = set()
         self._inflight = {}
+        self._events = [[] for _ in self.buckets]
         self._cancelled = False
         self._armed = True
 
@@ -113,6 +115,13 @@ class GradientAllReducer:
                                    "changing graphs")
             self._cancelled = True
             return
+        if p.is_cuda and self.overlap:
+            # The training forward runs branches on side streams and autograd runs their backward there: the gradients of one bucket are
+            # produced on several streams, and the hook that completes the bucket runs on ONE of them.  Every hook leaves an event on its
+            # stream; the launch makes its stream wait for all of them before the collective reads the bucket.
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[i].append(ev)
         self._need[i].discard(pid)
         if not self._need[i] and self.overlap and not self._cancelled:
             self._launch(i)
@@ -121,6 +130,11 @@ class GradientAllReducer:
         if i in self._inflight:
             return
         work = None
+        if self._events[i]:
+            cur = torch.cuda.current_stream(self.flat[i].device)
+            for ev in self._events[i]:
+                cur.wait_event(ev)
+            self._events[i] = []
         if self.world > 1:
             work = dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight[i] = work
