@@ -51,5 +51,5 @@ for name, log, n in (("train", "prof_train", 3), ("cqe", "prof_cqe", 3), ("cqe_t
     m = re.search(r"ms/step ([0-9.]+)", open(R + f"gpurun_out/{log}.log").read()) if os.path.exists(R + f"gpurun_out/{log}.log") else None
     if dbs and m:
         txt = subprocess.run([sys.executable, R + "tools/prof_stats.py", dbs[0], str(n), m.group(1), "60"], capture_output=True, text=True).stdout
-        open(R + f"profiles/{TAG}_{name}_step_kernels.txt", "w").write(f"# rocprofv3 --kernel-trace -- python3 tools/{'train_prof.py bf16' if name == 'train' else ('cqe_prof.py bf16 train' if name == 'cqe_train' else 'cqe_prof.py bf16')} (commit {head}); ms/step under the profiler {m.group(1)}\n" + txt)
+        open(R + f"profiles/{TAG}_{name}_step_kernels.txt", "w").write(f"# rocprofv3 --kernel-trace -- python3 tools/{'train_prof.py bf16' if name == 'train' else ('cqe_prof.py bf16 train' if name == 'cqe_train' else 'cqe_prof.py bf16')} (commit {head}); ms/step under the profiler {m.group(1)}" + (" -- the step runs on three streams (MASIC.py: _forward_graph): kernels share the chip, so a kernel's duration here is longer than alone and the column adds up to more than the step; MASIC_TRAIN_STREAMS=0 gives the one-stream table" if name == "train" else "") + "\n" + txt)
 print(dom, "value", d["value"], "frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
