@@ -292,6 +292,16 @@ int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed, int Cin, 
 int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
                                const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int Cin, int Cout, int H, int W,
                                int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream);
+/* ... for the backward chain of a residual block (autograd of reference layers.py:160-190 / MASIC.py:149-164 through the node of
+ * masic_amd/autograd.py: EnhancementBlockFn): additionally y2 = bf16(y) * act'(mask2) -- the next layer's dy, exactly what a separate
+ * g * act'(u) pass over the stored y would give -- and sum_out[Cout] = per-channel sums (a bias gradient) of the value before the residual
+ * adds (sum_of = 1) or of y2 (sum_of = 2), bf16-rounded as stored, from per-wave partials in sum_workspace
+ * (masic_conv3x3_resident_sum_workspace_bytes()) by a fixed-order finishing launch.  mask2 / y2: res_ctot-channel tensors. */
+size_t masic_conv3x3_resident_sum_workspace_bytes(void);
+int masic_conv3x3_resident_ex_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                                  const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, const void* mask2, float mask2_slope,
+                                  void* y2_f16k, int sum_of, float* sum_out, void* sum_workspace, int B, int Cin, int Cout, int H, int W,
+                                  int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream);
 /* diagnostics: 16 uint64 on the device, filled by every following conv_f16k launch with {core-clock, 100 MHz} stamp pairs at kernel
  * entry, K-loop entry, K-loop exit and kernel exit of its first and of its last workgroup; NULL switches it off (tools/f16k_stamps.py) */
 void masic_conv_f16k_set_stamps(void* device_buffer);

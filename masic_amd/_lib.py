@@ -107,6 +107,8 @@ SIGNATURES = {
     "masic_conv3x3_resident_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "masic_conv3x3_resident_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "masic_conv3x3_resident_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "masic_conv3x3_resident_sum_workspace_bytes": (ctypes.c_size_t, []),
+    "masic_conv3x3_resident_ex_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, _P, c_float, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),
     "masic_set_warp_align_corners": (None, [c_int]),
     "masic_get_warp_align_corners": (c_int, []),
     "masic_conv_f16k_res_ex_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, ctypes.POINTER(ConvDesc), _P]),

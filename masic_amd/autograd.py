@@ -462,6 +462,9 @@ class AddFn(Function):
         return g, g
 
 
+_EB_FUSED_EPILOGUES = os.environ.get("MASIC_EB_FUSED_EPILOGUES", "1") != "0"      # 0: g * act'(u) and the bias sums of the block nodes as separate passes (A/B timing)
+
+
 class EnhancementBlockFn(Function):
     """Enhancement_Block -- three residual blocks and the skip over all of them (reference MASIC.py:149-164) -- as ONE node of the CQE
     training step in bf16 mode, forward AND backward on F16K buffers (conv_f16k.hip, wgrad_f16k.hip, f16k_ops.hip):
@@ -527,18 +530,31 @@ class EnhancementBlockFn(Function):
             if resident:
                 return ops.conv3x3_resident(g16, ops.pack_conv3x3_resident_weight(w.detach(), transposed=True), None, B, C, C, H, W, res_ctot=C, **kw)
             return ops.conv2d_f16k_res(g16, ops.pack_conv_f16k_weight(w.detach(), d16, persistent=w.is_leaf and w.is_contiguous()), None, d16, res_ctot=C, **kw)
-        go = g_out
+        # With the resident-weight kernels (32 / 64 channels) the input-gradient launches also write what the separate passes made: the
+        # bias gradient of the layer they differentiate through (channel sums of their own output) and, for the launch that ends a block,
+        # the NEXT block's g_u = g_o * L'(u) as a second output -- per block one elementwise pass and two reduction passes over
+        # full-resolution tensors less (masic_conv3x3_resident_ex_fwd); the values are the same bf16 values summed / masked.
+        fused = resident and _EB_FUSED_EPILOGUES
+        go, gu, gu_sum = g_out, None, None
         for i in (2, 1, 0):
             rb, x_in, t, u = blocks[i]
             w1, w2 = params[4 * i], params[4 * i + 2]
-            gu = ops.f16k_act_bwd(go, u, 0.01)
+            if gu is None:
+                gu, gu_sum = ops.f16k_act_bwd(go, u, 0.01), None
             grads[4 * i + 2] = ops.conv3x3_wgrad_f16k(t, gu, B, C, C, H, W)
-            grads[4 * i + 3] = ops.f16k_channel_sum(gu, B, C, H * W)
-            gt = dgrad(gu, w2, mask=t, mask_slope=0.01)
+            grads[4 * i + 3] = gu_sum if gu_sum is not None else ops.f16k_channel_sum(gu, B, C, H * W)
+            if fused:
+                gt, _, gt_sum = dgrad(gu, w2, mask=t, mask_slope=0.01, sum_of=1)
+            else:
+                gt = dgrad(gu, w2, mask=t, mask_slope=0.01)
+                gt_sum = ops.f16k_channel_sum(gt, B, C, H * W)
             del gu
             grads[4 * i] = ops.conv3x3_wgrad_f16k(x_in, gt, B, C, C, H, W)
-            grads[4 * i + 1] = ops.f16k_channel_sum(gt, B, C, H * W)
-            go = dgrad(gt, w1, res1=go, res2=g_out if i == 0 else None)
+            grads[4 * i + 1] = gt_sum
+            if fused and i > 0:
+                go, gu, gu_sum = dgrad(gt, w1, res1=go, mask2=blocks[i - 1][3], mask2_slope=0.01, sum_of=2)
+            else:
+                go, gu, gu_sum = dgrad(gt, w1, res1=go, res2=g_out if i == 0 else None), None, None
             del gt
         gx = ops.f16k_to_nchw_dev(go, B, C, H, W) if ctx.needs_input_grad[0] else None
         return (gx, None, None, g_res) + tuple(grads) + (() if tail is None else (g_tw, g_tb))

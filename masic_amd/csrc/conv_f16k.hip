@@ -2461,6 +2461,11 @@ struct C3Args {
     int B, H, W, in_ctot16, in_c16off, out_ctot, out_coff, res_ctot, act;
     float mask_slope;
     int tiles_w, tiles_per_image, ntiles;
+    // backward chains of a residual block (masic_amd/autograd.py: EnhancementBlockFn): a SECOND output y2 = y * act'(mask2) -- the next
+    // layer's dy, which a separate elementwise pass used to make -- and per-channel sums (the bias gradient) of the value before the
+    // residual adds (sum_of = 1) or of y2 (sum_of = 2), bf16-rounded as stored, as per-wave partials [gridDim.x * 8][32]
+    const unsigned short* mask2; unsigned short* y2; float mask2_slope;
+    float* sum_part; int sum_of;
 };
 
 namespace {
@@ -2473,7 +2478,7 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int CI, int C>      // input channels (a multiple of 16), output channels
+template <int CI, int C, bool EX = false>      // input channels (a multiple of 16), output channels; EX: the second output / channel sums of C3Args
 __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) {
     constexpr int KB = CI / 16;                        // 16-channel blocks = 32-byte records per input pixel
     constexpr int NM = C / 32;                         // 32-channel accumulator tiles per pixel; a wave owns one of them for two image rows
@@ -2504,7 +2509,10 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
     const int t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
     const int t_first = xcd * per + slot;
     const int n_my = t_first < t_end ? (t_end - t_first + nslot - 1) / nslot : 0;
-    if (n_my == 0) return;
+    if (n_my == 0) {
+        if (EX && a.sum_part != nullptr && wave < 8 && lane < 32) a.sum_part[((size_t)blockIdx.x * 8 + wave) * 32 + lane] = 0.0f;
+        return;
+    }
     const int HW = a.H * a.W;
     const int plane_bytes = HW * 32;
 
@@ -2571,6 +2579,9 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = a.bias != nullptr ? a.bias[mt * 32 + 4 * h + (e & 3) + 8 * (e >> 2)] : 0.0f;
+    float bs[EX ? 16 : 1];                                              // per-lane channel sums over all tiles of this workgroup (sum_of)
+#pragma unroll
+    for (int e = 0; e < (EX ? 16 : 1); ++e) bs[e] = 0.0f;
     wg_barrier();                                                       // weights + tile 0 are in LDS
     for (int i = 0; i < n_my; ++i) {
         const unsigned char* pb = lds + pbl + (i % NBUF) * PBYTES;
@@ -2590,7 +2601,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
                 const size_t o = ro0 + (size_t)n * a.W * 16 + (size_t)(q >> 1) * op16 + 8 * (q & 1);
                 if (a.res1 != nullptr) rv1[n][q] = *reinterpret_cast<const uint2*>(a.res1 + o);
                 if (a.res2 != nullptr) rv2[n][q] = *reinterpret_cast<const uint2*>(a.res2 + o);
-                if (a.mask16 != nullptr) mv[n][q] = *reinterpret_cast<const uint2*>(a.mask16 + o);
+                if (!EX && a.mask16 != nullptr) mv[n][q] = *reinterpret_cast<const uint2*>(a.mask16 + o);      // (EX: read in the epilogue -- registers)
             }
         f32x16 acc[2];
 #pragma unroll
@@ -2623,6 +2634,10 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][e] = apply_act(acc[n][e] + bv[e], a.act);
             if (a.mask16 != nullptr) {
+                if constexpr (EX) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mv[n][q] = *reinterpret_cast<const uint2*>(a.mask16 + ro0 + (size_t)n * a.W * 16 + (size_t)(q >> 1) * op16 + 8 * (q & 1));
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[n][4 * q + 0] *= __builtin_bit_cast(float, mv[n][q].x << 16) > 0.0f ? 1.0f : a.mask_slope;
@@ -2632,6 +2647,12 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
                 }
             }
             if (a.y_pre != nullptr) store_f16k_tile(acc[n], a.y_pre + ro0 + (size_t)n * a.W * 16 + 4 * h, op16);
+            if constexpr (EX) {
+                if (a.sum_of == 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) bs[e] += (float)(__bf16)acc[n][e];
+                }
+            }
             if (a.res1 != nullptr) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) add4(acc[n], q, rv1[n][q]);
@@ -2641,9 +2662,50 @@ __global__ __launch_bounds__(768, 1) void conv3x3_resident_f16k(const C3Args a) 
                 for (int q = 0; q < 4; ++q) add4(acc[n], q, rv2[n][q]);
             }
             store_f16k_tile(acc[n], a.y16 + (((size_t)b * (a.out_ctot >> 4) + (a.out_coff >> 4) + 2 * mt) * HW + opix) * 16 + 8 * h, op16);
+            if constexpr (EX) {
+                if (a.y2 != nullptr) {       // y2 = bf16(y) * act'(mask2): what the elementwise pass computed from the stored y (mask2 is read here,
+                                             // not ahead of the MFMAs: the kernel has no registers left for a third prefetched operand)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint2 m2 = *reinterpret_cast<const uint2*>(a.mask2 + ro0 + (size_t)n * a.W * 16 + (size_t)(q >> 1) * op16 + 8 * (q & 1));
+                        acc[n][4 * q + 0] = (float)(__bf16)acc[n][4 * q + 0] * (__builtin_bit_cast(float, m2.x << 16) > 0.0f ? 1.0f : a.mask2_slope);
+                        acc[n][4 * q + 1] = (float)(__bf16)acc[n][4 * q + 1] * (__builtin_bit_cast(float, m2.x & 0xffff0000u) > 0.0f ? 1.0f : a.mask2_slope);
+                        acc[n][4 * q + 2] = (float)(__bf16)acc[n][4 * q + 2] * (__builtin_bit_cast(float, m2.y << 16) > 0.0f ? 1.0f : a.mask2_slope);
+                        acc[n][4 * q + 3] = (float)(__bf16)acc[n][4 * q + 3] * (__builtin_bit_cast(float, m2.y & 0xffff0000u) > 0.0f ? 1.0f : a.mask2_slope);
+                    }
+                    store_f16k_tile(acc[n], a.y2 + ro0 + (size_t)n * a.W * 16 + 4 * h, op16);
+                    if (a.sum_of == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) bs[e] += (float)(__bf16)acc[n][e];
+                    }
+                }
+            }
         }
         wg_barrier();          // tile i + 1 has landed (loader); this tile's buffer may be refilled
     }
+    if (EX && a.sum_part != nullptr) {       // lanes of one half-wave hold the same 16 channels for 32 different pixels
+#pragma unroll
+        for (int e = 0; e < (EX ? 16 : 1); ++e) {
+            float v = bs[e];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+            if (j == 0) a.sum_part[((size_t)blockIdx.x * 8 + wave) * 32 + 4 * h + (e & 3) + 8 * (e >> 2)] = v;
+        }
+    }
+}
+
+// out[c] = sum of the per-wave partials of conv3x3_resident_f16k (wave w of a workgroup holds channel tile w % NM): one block per channel,
+// a lane takes every 64th partial, then a tree -- float64, fixed order
+__global__ __launch_bounds__(64) void c3_sum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nblocks) {
+    const int c = blockIdx.x, NM = C / 32, mt = c / 32, cl = c - mt * 32, per = 8 / NM, K = nblocks * per;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const int b = k / per, w = mt + (k - b * per) * NM;
+        s += (double)part[((size_t)b * 8 + w) * 32 + cl];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // weights of Conv2d(cin -> C, 3x3) [C][cin][3][3] float32 -> bf16 fragment slabs [tap][kb][k-half][co][8 k] with the input channels
@@ -2698,7 +2760,21 @@ extern "C" int masic_conv3x3_resident_pack_weight(const float* w, void* w_packed
 extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
                                           const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, int B, int Cin, int Cout, int H, int W,
                                           int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream) {
+    return masic_conv3x3_resident_ex_fwd(x_f16k, w_packed, bias, res1, res2, res_ctot, mask, mask_slope, y_pre_f16k, y_f16k, nullptr, 0.0f, nullptr, 0, nullptr,
+                                         nullptr, B, Cin, Cout, H, W, in_ctot, in_coff, out_ctot, out_coff, act, stream);
+}
+extern "C" size_t masic_conv3x3_resident_sum_workspace_bytes(void) { return (size_t)256 * 8 * 32 * sizeof(float); }
+// ... + y2 = y * act'(mask2) (res_ctot-channel tensors) and sum_out[Cout] = per-channel sums of the value before the residual adds
+// (sum_of = 1) or of y2 (sum_of = 2), bf16-rounded as stored; sum_workspace: masic_conv3x3_resident_sum_workspace_bytes()
+extern "C" int masic_conv3x3_resident_ex_fwd(const void* x_f16k, const void* w_packed, const float* bias, const void* res1, const void* res2, int res_ctot,
+                                             const void* mask, float mask_slope, void* y_pre_f16k, void* y_f16k, const void* mask2, float mask2_slope,
+                                             void* y2_f16k, int sum_of, float* sum_out, void* sum_workspace, int B, int Cin, int Cout, int H, int W,
+                                             int in_ctot, int in_coff, int out_ctot, int out_coff, int act, void* stream) {
     const int CI = round_up(Cin, 16), C = Cout;
+    MASIC_REQUIRE((mask2 == nullptr) == (y2_f16k == nullptr), MASIC_ERR_ARG, "conv3x3_resident_fwd: mask2 and y2 come together");
+    MASIC_REQUIRE(sum_of >= 0 && sum_of <= 2 && (sum_of == 0) == (sum_out == nullptr) && (sum_of == 0 || sum_workspace != nullptr) && (sum_of != 2 || y2_f16k != nullptr),
+                  MASIC_ERR_ARG, "conv3x3_resident_fwd: sum_of / sum_out / sum_workspace");
+    MASIC_REQUIRE(y2_f16k == nullptr || (res_ctot % 16 == 0 && res_ctot >= C), MASIC_ERR_SHAPE, "conv3x3_resident_fwd: y2 / mask2 need res_ctot >= Cout channels");
     MASIC_REQUIRE(x_f16k && w_packed && y_f16k, MASIC_ERR_ARG, "conv3x3_resident_fwd: null pointer");
     MASIC_REQUIRE(masic_conv3x3_resident_supported(B, Cin, Cout, H, W), MASIC_ERR_UNSUPPORTED,
                   "conv3x3_resident_fwd: needs Cin <= 64, Cout = 32 (H %% 16 == 0) or 64 (H %% 8 == 0), W %% 32 == 0");
@@ -2711,21 +2787,27 @@ extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_pack
     const int TH = 512 / C, tiles_w = W / 32, tiles_h = H / TH;
     C3Args a{(const unsigned short*)x_f16k, (const unsigned short*)w_packed, bias, (const unsigned short*)res1, (const unsigned short*)res2,
              (const unsigned short*)mask, (unsigned short*)y_pre_f16k, (unsigned short*)y_f16k, B, H, W, in_ctot / 16, in_coff / 16, out_ctot, out_coff,
-             res_ctot, act, mask_slope, tiles_w, tiles_w * tiles_h, B * tiles_w * tiles_h};
+             res_ctot, act, mask_slope, tiles_w, tiles_w * tiles_h, B * tiles_w * tiles_h,
+             (const unsigned short*)mask2, (unsigned short*)y2_f16k, mask2_slope, (float*)sum_workspace, sum_of};
     // LDS: weights + patch ring + sink (the kernel's constants)
     const int wbytes = 9 * (CI / 16) * 2 * C * 16, pbytes = ((CI / 16) * 2 * (TH + 2) * 34 + 63) / 64 * 1024;
     const int lds_bytes = wbytes + (wbytes + 3 * pbytes + 1024 <= 160 * 1024 ? 3 : 2) * pbytes + 1024;
     int grid = 256;                                                  // one persistent workgroup per CU
     if (a.ntiles < grid) grid = round_up(a.ntiles, 8);
     hipStream_t st = (hipStream_t)stream;
-#define C3_LAUNCH(CIV, CV)                                                                                                    \
+#define C3_LAUNCH_E(CIV, CV, EXV)                                                                                             \
     do {                                                                                                                       \
         static bool attr_set = false;                                                                                          \
         if (!attr_set) {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<CIV, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv3x3_resident_f16k<CIV, CV, EXV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL((conv3x3_resident_f16k<CIV, CV>), dim3(grid), dim3(768), lds_bytes, st, a);                         \
+        hipLaunchKernelGGL((conv3x3_resident_f16k<CIV, CV, EXV>), dim3(grid), dim3(768), lds_bytes, st, a);                    \
+    } while (0)
+#define C3_LAUNCH(CIV, CV)                                                                                                    \
+    do {                                                                                                                       \
+        if (y2_f16k != nullptr || sum_of) C3_LAUNCH_E(CIV, CV, true);                                                          \
+        else C3_LAUNCH_E(CIV, CV, false);                                                                                      \
     } while (0)
     if (C == 32) {
         if (CI == 16) C3_LAUNCH(16, 32);
@@ -2736,5 +2818,7 @@ extern "C" int masic_conv3x3_resident_fwd(const void* x_f16k, const void* w_pack
         else C3_LAUNCH(64, 64);
     }
 #undef C3_LAUNCH
+#undef C3_LAUNCH_E
+    if (sum_of) hipLaunchKernelGGL(c3_sum_finish_kernel, dim3(C), dim3(64), 0, st, (const float*)sum_workspace, sum_out, C, grid);
     return masic_launch_status("conv3x3_resident_fwd");
 }

@@ -1419,9 +1419,11 @@ def pack_conv3x3_resident_weight(weight, transposed=False):
 
 
 def conv3x3_resident(x16, packed, bias, B, Cin, Cout, H, W, act=ACT_NONE, y16=None, out_ctot=None, out_coff=0, in_ctot=None, in_coff=0,
-                     res1=None, res2=None, res_ctot=0, mask=None, mask_slope=0.0, y_pre=None):
+                     res1=None, res2=None, res_ctot=0, mask=None, mask_slope=0.0, y_pre=None, mask2=None, mask2_slope=0.0, sum_of=0):
     """y = act(conv3x3(x) + bias) * act'(mask) + res1 + res2 on F16K buffers with LDS-resident weights (csrc/conv_f16k.hip:
-    conv3x3_resident_f16k); operands as conv2d_f16k_res.  The input buffer holds ceil16(Cin) channels per pixel."""
+    conv3x3_resident_f16k); operands as conv2d_f16k_res.  The input buffer holds ceil16(Cin) channels per pixel.
+    mask2: also y2 = y * act'(mask2) (the next layer's dy of a backward chain); sum_of = 1 / 2: also the per-channel sums of the value
+    before the residual adds / of y2 (a bias gradient).  Returns y, or (y, y2, sums) -- None where not asked -- when either is given."""
     in_ctot = (Cin + 15) // 16 * 16 if in_ctot is None else in_ctot
     out_ctot = Cout if out_ctot is None else out_ctot
     if x16.dtype != torch.int16 or x16.numel() != B * in_ctot * H * W:
@@ -1430,12 +1432,20 @@ def conv3x3_resident(x16, packed, bias, B, Cin, Cout, H, W, act=ACT_NONE, y16=No
         y16 = torch.empty(B * out_ctot * H * W, dtype=torch.int16, device=x16.device)
     elif y16.dtype != torch.int16 or y16.numel() != B * out_ctot * H * W:
         raise RuntimeError("masic_amd.conv3x3_resident: output buffer does not match (B, out_ctot, H, W)")
-    for r in (res1, res2, mask, y_pre):
+    for r in (res1, res2, mask, y_pre, mask2):
         if r is not None and (r.dtype != torch.int16 or r.numel() != B * res_ctot * H * W):
             raise RuntimeError("masic_amd.conv3x3_resident: residual / mask / pre buffer does not match (B, res_ctot, H, W)")
-    check(lib.masic_conv3x3_resident_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(mask), float(mask_slope), _p(y_pre), _p(y16),
-                                         B, Cin, Cout, H, W, in_ctot, in_coff, out_ctot, out_coff, int(act), _stream()), "conv3x3_resident_fwd")
-    return y16
+    if mask2 is None and not sum_of:
+        check(lib.masic_conv3x3_resident_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(mask), float(mask_slope), _p(y_pre), _p(y16),
+                                             B, Cin, Cout, H, W, in_ctot, in_coff, out_ctot, out_coff, int(act), _stream()), "conv3x3_resident_fwd")
+        return y16
+    y2 = torch.empty(B * res_ctot * H * W, dtype=torch.int16, device=x16.device) if mask2 is not None else None
+    sums = torch.empty(Cout, dtype=torch.float32, device=x16.device) if sum_of else None
+    ws = torch.empty(_int_query("masic_conv3x3_resident_sum_workspace_bytes") // 4, dtype=torch.float32, device=x16.device) if sum_of else None
+    check(lib.masic_conv3x3_resident_ex_fwd(_p(x16), _p(packed), _p(bias), _p(res1), _p(res2), int(res_ctot), _p(mask), float(mask_slope), _p(y_pre), _p(y16),
+                                            _p(mask2), float(mask2_slope), _p(y2), int(sum_of), _p(sums), _p(ws),
+                                            B, Cin, Cout, H, W, in_ctot, in_coff, out_ctot, out_coff, int(act), _stream()), "conv3x3_resident_ex_fwd")
+    return y16, y2, sums
 
 
 def f16k_act_bwd(g16, y16, slope):

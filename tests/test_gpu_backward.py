@@ -696,6 +696,12 @@ def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
     orig = EntropyModel._get_noise_cached
     EntropyModel._get_noise_cached = static_noise
     mnn.set_precision("bf16")
+    # The capture is a one-stream step (HSIC._forward_graph keeps its side streams out of a capture): the eager step it is compared with
+    # runs on one stream too.  With the side streams the float atomics of the weight gradients land in another order, and three Adam steps
+    # turn that into percent-level differences of the reconstructions (2.3e-2 against this test's 2e-2 on a cold box, once in seven runs) --
+    # which says nothing about the replay; tests/test_gpu_backward.py::test_two_stream_training_forward_is_the_one_stream_computation
+    # covers the streams.
+    prev_streams, MASIC._TRAIN_STREAMS = MASIC._TRAIN_STREAMS, False
     try:
         def fresh():
             net = MASIC.HSIC(N, M, K)
@@ -753,6 +759,7 @@ def test_graphed_train_step_equals_eager_steps(N, M, K, B, H, W):
         with pytest.raises(RuntimeError):
             step(*batches[0])                      # eval mode: the capture was of the training-mode step
     finally:
+        MASIC._TRAIN_STREAMS = prev_streams
         EntropyModel._get_noise_cached = orig
         mnn.set_precision("f32")
 
