@@ -275,6 +275,9 @@ int masic_conv_f16k_res_ex_fwd(const void* x_f16k, const void* w_packed, const f
 int masic_f16k_act_bwd(const void* g, const void* y, void* out, size_t n, float slope, void* stream);
 size_t masic_f16k_channel_sum_workspace_bytes(int B, int C);
 int masic_f16k_channel_sum(const void* x, float* out, void* workspace, int B, int C, int HW, void* stream);
+/* out = g * act'(y) (as masic_f16k_act_bwd) and sums[C] = its per-channel sums (as masic_f16k_channel_sum of out) in one pass over the
+ * tensors; workspace: masic_f16k_channel_sum_workspace_bytes(B, C) */
+int masic_f16k_act_bwd_sum(const void* g, const void* y, void* out, float* sums, void* workspace, int B, int C, int HW, float slope, void* stream);
 /* mask2weights_EN (reference MASIC.py:1411-1434, Kw = 2) in one launch: gates [B,2,H,W] = softmax over channels of four 3x3
  * stride-1 convolutions 1 -> 2 -> 4 -> 4 -> 2 with ReLUs on mask [B,1,H,W]; w_i [Cout][Cin][3][3], b_i [Cout], float32 on the
  * device.  Bit-identical to the four-launch form (masic_conv2d_fwd per layer). */

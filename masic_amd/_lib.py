@@ -115,6 +115,7 @@ SIGNATURES = {
     "masic_f16k_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
     "masic_f16k_channel_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "masic_f16k_channel_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "masic_f16k_act_bwd_sum": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "masic_conv_f16k_res_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, ctypes.POINTER(ConvDesc), _P]),
     "masic_conv_f16k_few_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.POINTER(ConvDesc), _P]),
     "masic_f16k_gate": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),

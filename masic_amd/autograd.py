@@ -540,7 +540,7 @@ class EnhancementBlockFn(Function):
             rb, x_in, t, u = blocks[i]
             w1, w2 = params[4 * i], params[4 * i + 2]
             if gu is None:
-                gu, gu_sum = ops.f16k_act_bwd(go, u, 0.01), None
+                gu, gu_sum = ops.f16k_act_bwd_sum(go, u, 0.01, B, C, H * W) if _EB_FUSED_EPILOGUES else (ops.f16k_act_bwd(go, u, 0.01), None)
             grads[4 * i + 2] = ops.conv3x3_wgrad_f16k(t, gu, B, C, C, H, W)
             grads[4 * i + 3] = gu_sum if gu_sum is not None else ops.f16k_channel_sum(gu, B, C, H * W)
             if fused:

@@ -182,6 +182,49 @@ __global__ __launch_bounds__(256) void f16k_channel_sum_stage2(const float* __re
     if (threadIdx.x < 16) out[c] = (float)red[threadIdx.x];
 }
 
+// g' = g * act'(y) AND the per-channel sums of g' (bf16-rounded, as stored): f16k_act_bwd_kernel + f16k_channel_sum_stage1 in one pass --
+// the block layout of the latter (pixel chunk, 16-channel block, image), two loads in flight per lane and operand
+__global__ __launch_bounds__(256) void f16k_act_bwd_sum_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y, uint4* __restrict__ out, float* __restrict__ partial,
+                                                               int C16, int HW, int chunks, float slope) {
+    const int chunk = blockIdx.x, cb = blockIdx.y, b = blockIdx.z;
+    const int per = (HW + chunks - 1) / chunks;
+    const int lo = chunk * per, hi = lo + per < HW ? lo + per : HW;
+    const size_t base = ((size_t)b * C16 + cb) * HW * 2;          // 2 uint4 per record
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int half = threadIdx.x & 1;
+    for (int px = lo + (threadIdx.x >> 1); px < hi; px += 256) {
+        const bool two = px + 128 < hi;
+        const size_t i0 = base + 2 * (size_t)px + half, i1 = i0 + 256;
+        const uint4 a0 = g[i0], m0 = y[i0];
+        uint4 a1 = make_uint4(0u, 0u, 0u, 0u), m1 = a1;
+        if (two) { a1 = g[i1]; m1 = y[i1]; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !two) break;
+            const uint4 a = r ? a1 : a0, m = r ? m1 : m0;
+            const unsigned av[4] = {a.x, a.y, a.z, a.w}, mv[4] = {m.x, m.y, m.z, m.w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = pack2(bf_lo(av[k]) * (bf_lo(mv[k]) > 0.0f ? 1.0f : slope), bf_hi(av[k]) * (bf_hi(mv[k]) > 0.0f ? 1.0f : slope));
+                acc[2 * k] += bf_lo(o[k]);
+                acc[2 * k + 1] += bf_hi(o[k]);
+            }
+            out[r ? i1 : i0] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __shared__ float red[256][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int c = threadIdx.x;
+        float s = 0.0f;
+        for (int t = (c >> 3); t < 256; t += 2) s += red[t][c & 7];
+        partial[((size_t)(b * chunks + chunk)) * (C16 * 16) + cb * 16 + c] = s;
+    }
+}
+
 }  // namespace
 
 // out = g * act'(y), all F16K of n bf16 elements (n % 8 == 0); slope: 0.01 LeakyReLU, 0 ReLU
@@ -202,6 +245,16 @@ extern "C" int masic_f16k_channel_sum(const void* x, float* out, void* workspace
     hipLaunchKernelGGL(f16k_channel_sum_stage1, dim3(F16K_CS_CHUNKS, C / 16, B), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (float*)workspace, C / 16, HW, F16K_CS_CHUNKS);
     hipLaunchKernelGGL(f16k_channel_sum_stage2, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, C, B * F16K_CS_CHUNKS);
     return masic_launch_status("f16k_channel_sum");
+}
+
+// out = g * act'(y) and sums[c] = sum over (b, pixel) of out, one pass over the tensors + the finishing reduce (workspace:
+// masic_f16k_channel_sum_workspace_bytes(B, C)): the elementwise pass and the bias-gradient pass of a residual block's backward in one
+extern "C" int masic_f16k_act_bwd_sum(const void* g, const void* y, void* out, float* sums, void* workspace, int B, int C, int HW, float slope, void* stream) {
+    MASIC_REQUIRE(g && y && out && sums && workspace && B > 0 && C > 0 && C % 16 == 0 && HW > 0, MASIC_ERR_ARG, "f16k_act_bwd_sum: bad argument");
+    hipLaunchKernelGGL(f16k_act_bwd_sum_kernel, dim3(F16K_CS_CHUNKS, C / 16, B), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (const uint4*)y, (uint4*)out,
+                       (float*)workspace, C / 16, HW, F16K_CS_CHUNKS, slope);
+    hipLaunchKernelGGL(f16k_channel_sum_stage2, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, sums, C, B * F16K_CS_CHUNKS);
+    return masic_launch_status("f16k_act_bwd_sum");
 }
 
 // dst[:, dst_coff : dst_coff + C] = (minv ? warp(src, minv) : src) * (gate ? gate[:, gate_c] : 1); src: F16K of exactly C channels,

@@ -1457,6 +1457,17 @@ def f16k_act_bwd(g16, y16, slope):
     return out
 
 
+def f16k_act_bwd_sum(g16, y16, slope, B, C, HW):
+    """(g * act'(y), its per-channel sums [C]) in one pass (masic_f16k_act_bwd_sum)."""
+    if g16.dtype != torch.int16 or y16.dtype != torch.int16 or g16.numel() != y16.numel() or g16.numel() != B * C * HW or C % 16:
+        raise RuntimeError("masic_amd.f16k_act_bwd_sum: F16K buffers of (B, C, HW), C % 16 == 0 expected")
+    out = torch.empty_like(g16)
+    sums = torch.empty(C, dtype=torch.float32, device=g16.device)
+    ws = torch.empty(_int_query("masic_f16k_channel_sum_workspace_bytes", B, C) // 4, dtype=torch.float32, device=g16.device)
+    check(lib.masic_f16k_act_bwd_sum(_p(g16), _p(y16), _p(out), _p(sums), _p(ws), B, C, HW, float(slope), _stream()), "f16k_act_bwd_sum")
+    return out, sums
+
+
 def f16k_channel_sum(x16, B, C, HW):
     """float32 [C] sums over (image, pixel) of an F16K tensor (a bias gradient)."""
     if x16.dtype != torch.int16 or C % 16 or x16.numel() != B * C * HW:
