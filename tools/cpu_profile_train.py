@@ -7,7 +7,7 @@ from masic_amd import synth, nn as mnn
 from masic_amd.train import make_optimizers, train_step
 mnn.set_precision("bf16")
 net = MASIC.HSIC(128, 192, 5); net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=100)); net = net.cuda().train()
-x1, x2, hm = (t.cuda() for t in synth.synth_inputs(8, 512, 512, seed=100))
+x1, x2, hm = (t.cuda() for t in synth.synth_inputs(int(os.environ.get("CPU_PROF_B", "8")), int(os.environ.get("CPU_PROF_H", "512")), int(os.environ.get("CPU_PROF_H", "512")), seed=100))
 opt, aopt = make_optimizers(net)
 for _ in range(3): train_step(net, opt, aopt, x1, x2, hm, 0.01)
 torch.cuda.synchronize()
