@@ -575,7 +575,9 @@ def main():
                     head_bytes(5 * Mh, [6 * Mh] * 3, True)(False), head_bytes([6 * Mh] * 3, [4 * Mh, 4 * Mh, K * Mh], False)(False),
                     head_bytes([4 * Mh, 4 * Mh, K * Mh], [K * Mh] * 3, False)(True)]
         alg = {"gemm_f16k2": sum(launches) / len(launches), "gemm_f16k<2, false>": sum(launches) / len(launches),
-               "conv_a_gdn_f16k_w": B * 3 * H * W * 4 + B * 128 * (H // 2) * (W // 2) * 2, "conv_a_gdn_f16k<false, 0>": B * 3 * H * W * 4 + B * 128 * (H // 2) * (W // 2) * 2}
+               "conv_a_gdn_f16k_w": B * 3 * H * W * 4 + B * 128 * (H // 2) * (W // 2) * 2, "conv_a_gdn_f16k<false, 0>": B * 3 * H * W * 4 + B * 128 * (H // 2) * (W // 2) * 2,
+               # the transposed 128 -> 128 layer with its fused IGDN at (H/4)^2 -> (H/2)^2 (two launches per forward): input + output in bf16 F16K
+               "conv_f16k<2, 2, 2, 5, 1, true, 4, 2, false>": B * N * ((H // 4) * (W // 4) + (H // 2) * (W // 2)) * 2}
         roofline["traffic_vs_algorithmic_other_kernels"] = {
             n: {"launches": pmc[n]["launches"], "traffic_bytes_per_launch": (2.0 * pmc[n].get("FETCH_SIZE", 0.0) + pmc[n].get("WRITE_SIZE", 0.0)) * 1024.0,
                 "algorithmic_bytes_per_launch": float(ab), "ratio": (2.0 * pmc[n].get("FETCH_SIZE", 0.0) + pmc[n].get("WRITE_SIZE", 0.0)) * 1024.0 / float(ab)}
