@@ -525,11 +525,20 @@ def main():
         # Roofline pass (not part of `value`): the same forward issued eagerly -- kernels inside a graph replay cannot be
         # bracketed individually -- first with HIP events around every conv launch to find the dominant kernel symbol and
         # the per-kernel split, then `steps` more with events around that symbol only.
-        survey = ops.KernelTimer()
-        ops.set_kernel_timer(survey)
-        net(x1, x2, hm)
-        ops.set_kernel_timer(None)
-        survey_agg = survey.summary()
+        # (the survey is three passes and a kernel's time the MEDIAN of its three pass totals: with events between every launch of a
+        # three-stream forward a side-stream kernel's interval now and then includes a long wait for the CUs -- one pass once made a
+        # 40-us hyper-synthesis layer "dominant" at 0.9 ms)
+        passes = []
+        for _ in range(3):
+            survey = ops.KernelTimer()
+            ops.set_kernel_timer(survey)
+            net(x1, x2, hm)
+            ops.set_kernel_timer(None)
+            passes.append(survey.summary())
+        survey_agg = {}
+        for k in passes[0]:
+            if all(k in p_ for p_ in passes):
+                survey_agg[k] = sorted((p_[k] for p_ in passes), key=lambda v: v["ms"])[1]
         dom = max(survey_agg, key=lambda k: survey_agg[k]["ms"])
         timer = ops.KernelTimer(only=dom)
         ops.set_kernel_timer(timer)
