@@ -31,8 +31,13 @@ from ._lib import check, lib
 MAGIC = b"MSR2"
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=16)
 def wavefront_steps(h, w):
-    """Pixel indices (i * w + j), rows ascending, of each wavefront t = j + 3 i."""
+    """Pixel indices (i * w + j), rows ascending, of each wavefront t = j + 3 i.  (A function of the latent's shape alone: cached -- the
+    125 numpy selections of a 32 x 32 latent were 0.5 ms of every encode_view / decode_view call.  Callers must not write to the arrays.)"""
     ii = np.arange(h)
     steps = []
     for t in range(w + 3 * (h - 1)):
@@ -150,6 +155,24 @@ def encode_view(params_fn, y_hat, M, K, chan, minmax, scale_bound):
     return encode_channels(sf.cpu().numpy(), pix.numel(), chan.numel())
 
 
+_STEP_LISTS = {}
+
+
+def _step_lists(h, w, device):
+    """int32 [steps][h] on the device: the pixels of every coding wavefront (at most one per row), -1 padded; per shape and device, kept."""
+    key = (h, w, str(device))
+    t = _STEP_LISTS.get(key)
+    if t is None:
+        steps = wavefront_steps(h, w)
+        pix_np = np.full((len(steps), h), -1, dtype=np.int32)
+        for i, p in enumerate(steps):
+            pix_np[i, :p.size] = p
+        if len(_STEP_LISTS) >= 16:
+            _STEP_LISTS.clear()
+        t = _STEP_LISTS[key] = torch.from_numpy(pix_np.reshape(-1)).to(device)
+    return t
+
+
 def decode_view(params_fn, data, shape, M, K, chan, minmax, scale_bound, device, use_graph=True):
     """Coding step by coding step, entirely on the device: parameters from what is decoded so far -> tables of the step's pixels ->
     one wavefront per channel stream finds the symbols and writes them into the latent.  The device side of a step (context
@@ -165,15 +188,13 @@ def decode_view(params_fn, data, shape, M, K, chan, minmax, scale_bound, device,
     if len(streams) != nch or any(len(s_) < 8 or len(s_) % 4 for s_ in streams):
         raise ValueError("masic_amd.codec: the y stream does not hold one rANS stream per coded channel")
     steps = wavefront_steps(h, w)
-    pix_np = np.full((len(steps), h), -1, dtype=np.int32)             # a wavefront holds at most one pixel per row
-    for t, p in enumerate(steps):
-        pix_np[t, :p.size] = p
+    pix_d = _step_lists(h, w, device)
     words = np.frombuffer(b"".join(streams), dtype=np.uint32)
     cnt = np.array([len(s_) // 4 for s_ in streams], dtype=np.uint32)
     off = np.concatenate(([0], np.cumsum(cnt)[:-1])).astype(np.uint32)
     state0 = words[off].astype(np.uint64) | (words[off + 1].astype(np.uint64) << np.uint64(32))
     dev_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(device)
-    words_d, off_d, cnt_d, pix_d = dev_i32(words), dev_i32(off), dev_i32(cnt), dev_i32(pix_np.reshape(-1))
+    words_d, off_d, cnt_d = dev_i32(words), dev_i32(off), dev_i32(cnt)
     state_init = torch.from_numpy(state0.view(np.int64)).to(device)
     state_d = state_init.clone()
     pos_d = torch.full((nch,), 2, dtype=torch.int32, device=device)
